@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the temporal-walk-matrix hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch: pairwise readout of (src,dst) and (src,neg) on the pre-batch
+state + update() of the batch (the decoder-level unit of SURVEY.md §8d).  Workload = BASELINE.json configs[1]
+(C2: Wikipedia-shaped stream, d=128, batch=1000, L=3, fp32); inputs are resident in HBM when the timed region
+starts.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_workload(cfg, n_batches, rank):
+    from tpnet_amd.stream import synthetic_stream, synthetic_negatives
+    B = cfg["B"]
+    E = n_batches * B
+    span = cfg["span"] * (E / cfg["E"])          # same edge rate as the dataset-shaped stream
+    src, dst, t, N = synthetic_stream(cfg["U"], cfg["I"], E, span, seed=1000 * rank)
+    neg = synthetic_negatives(cfg["U"], N, E, B, seed=1 + 1000 * rank)
+    return src, dst, neg, t, N
+
+
+def cpu_baseline(cfg, src, dst, neg, t, N, P0, budget_s=12.0):
+    """The torch-CPU port of the reference ops (oracle/torch_port.py), timed on this box's host cores on a bounded
+    prefix of the same workload."""
+    from oracle.torch_port import TorchPort
+    threads = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    B = cfg["B"]
+    port = TorchPort(P0, 3, cfg["lam"], 0.0)
+    nb_max = len(src) // B
+    done, t0 = 0, None
+    for b in range(nb_max):
+        s = slice(b * B, (b + 1) * B)
+        if b == 2:
+            t0 = time.perf_counter()           # 2 warm-up batches
+        port.pair_gram(src[s], dst[s])
+        port.pair_gram(src[s], neg[s])
+        port.update(src[s], dst[s], t[s])
+        if t0 is not None:
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    el = time.perf_counter() - t0
+    return {"value": done * B / el, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"first {done} batches of {B} edges after 2 warm-up batches, torch-CPU port of the reference "
+                      f"ops incl. its eager dense decay, {threads} threads, pre-mlp features"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import tpnet_amd
+    from tpnet_amd import _lib
+    from tpnet_amd.stream import CONFIGS, bytes_per_edge
+    cfg = CONFIGS[args.config]
+    B, d, L = cfg["B"], cfg["d"], 3
+    K, W = args.steps, args.warmup
+
+    src, dst, neg, t, N = make_workload(cfg, W + K, rank)
+    torch.manual_seed(0)
+    P0 = torch.normal(0, 1 / np.sqrt(d), (N, d))
+    rp = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=cfg["E"], dim_factor=10, num_layer=L,
+                                          time_decay_weight=cfg["lam"], device=str(dev), use_matrix=False,
+                                          beginning_time=np.float64(0.0), not_scale=False, enforce_dim=d)
+    rp.random_projections[0].data = P0.clone()
+    rp = rp.to(dev)
+    to_dev = lambda x: torch.from_numpy(x).to(dev)
+    d_src, d_dst, d_neg, d_t = to_dev(src), to_dev(dst), to_dev(neg), to_dev(t)
+    NG = rp.pair_wise_feature_dim
+    out_pos = torch.empty((K * B, NG), dtype=torch.float32, device=dev)
+    out_neg = torch.empty((K * B, NG), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: W untimed steps (also sizes the workspace for the timed call)
+    rp._workspace(K * B, B)
+    if W > 0:
+        rp.run_stream(d_src[:W * B], d_dst[:W * B], d_neg[:W * B], d_t[:W * B], B, out_pos=out_pos[:W * B],
+                      out_neg=out_neg[:W * B], t_end=float(t[W * B - 1]))
+    sl = slice(W * B, (W + K) * B)
+    a_src, a_dst, a_neg, a_t = d_src[sl], d_dst[sl], d_neg[sl], d_t[sl]
+    barrier()
+    t0 = time.perf_counter()
+    rp.run_stream(a_src, a_dst, a_neg, a_t, B, out_pos=out_pos, out_neg=out_neg, t_end=float(t[(W + K) * B - 1]))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    rp.check_device_errors()
+
+    # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side), one extra
+    # pass over the same K batches (state keeps advancing; throughput above is not affected)
+    roof = None
+    if rank == 0:
+        lib = _lib.load()
+        st = rp._state()
+        ws = rp._workspace(K * B, B)
+        total_ms, kern_ms = C.c_float(0), C.c_float(0)
+        lid = rp._next_launch_ids(3 * K + 8)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.tpnet_time_stream(C.byref(st), a_src.data_ptr(), a_dst.data_ptr(), a_neg.data_ptr(),
+                                         a_t.data_ptr(), K * B, B, float(t[(W + K) * B - 1]), cfg["lam"], lid, 0,
+                                         out_pos.data_ptr(), out_neg.data_ptr(), ws.data_ptr(), ws.numel(), 1,
+                                         C.byref(total_ms), C.byref(kern_ms), stream), "time_stream")
+        bpe = bytes_per_edge(d, L)
+        achieved = bpe * B / (kern_ms.value * 1e-3) / 1e9 if kern_ms.value > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_step (fused readout + update of one batch)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": bpe * B, "avg_kernel_us": kern_ms.value * 1e3,
+                "stream_ms_events": total_ms.value}
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, src, dst, neg, t, N, P0.numpy())
+        total_edges = K * B * world
+        line = {
+            "metric": "temporal edges/sec (proj-update + pairwise readout)",
+            "value": total_edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['desc']}, L=3, synthetic S({cfg['U']},{cfg['I']},E,span) "
+                                   f"stream of {(W + K) * B} edges, decoder-level unit (2 readouts + update per edge)",
+                       "batch": B, "dim": d, "num_layer": L, "nodes": N,
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one stream each)"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * tpnet_hip.h -- C ABI of the MI355X (gfx950) implementation of TPNet's temporal-walk-matrix hot path.
+ *
+ * Drop-in boundary: the functions below are what a binding for the reference's
+ * `RandomProjectionModule` (reference: models/TPNet.py:9-157) calls instead of the stock ATen ops.
+ * Plain C: device pointers, sizes, a hipStream_t passed as void*; no torch types.  All device buffers
+ * are owned by the caller (e.g. the PyTorch caching allocator); nothing is allocated or freed inside;
+ * kernels are enqueued on the given stream and the functions do not synchronise unless stated.
+ *
+ * Every function returns 0 on success or a negative tpnet_status code; tpnet_strerror() names it.
+ *
+ * ---------------------------------------------------------------------------------------------------
+ * State layout in HBM (one instance per RandomProjectionModule):
+ *   p0   float [N][d]            layer 0 (the random projection matrix P[0]; never written by update)
+ *   q    float [2][N][L][d]      layers 1..L as per-node "bundles" (L*d contiguous floats), two copies
+ *                                (ping-pong): a batch reads the pre-batch copy and writes the other one,
+ *                                which removes the read/write hazard between layers inside ONE launch
+ *   meta tpnet_node_meta [N]     per node: which copy is current + the time its bundle was last decayed to
+ * Mathematical state (what the reference keeps eagerly, models/TPNet.py:83-85):
+ *   P[i][n] = q[c][n][i-1] * exp(-lambda * i * (now_time - meta[n].tref[c])),  c = cur(n), i = 1..L
+ * i.e. the dense per-batch decay of the reference is carried lazily per row and applied on read.
+ * ---------------------------------------------------------------------------------------------------
+ */
+#ifndef TPNET_HIP_H
+#define TPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPNET_ABI_VERSION 1
+#define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
+
+typedef enum tpnet_status {
+    TPNET_OK = 0,
+    TPNET_ERR_BAD_ARG = -1,     /* null pointer, negative size, L out of range, d < 1 */
+    TPNET_ERR_WORKSPACE = -2,   /* workspace too small (see tpnet_workspace_bytes) */
+    TPNET_ERR_HIP = -3,         /* a HIP runtime call failed; tpnet_last_hip_error() has the hipError_t */
+    TPNET_ERR_INDEX = -4,       /* a node id outside [0, N) was found (checked on device; such ids are skipped,
+                                   never dereferenced) -- reported by tpnet_check_errors() */
+    TPNET_ERR_NO_DEVICE = -5
+} tpnet_status;
+
+/* 32-byte per-node record.  tref is kept per copy so that a launch rewriting a node never disturbs what a
+ * concurrent reader of the same launch needs (the pre-batch copy and its reference time). */
+typedef struct tpnet_node_meta {
+    uint32_t ver;   /* (launch_id << 1) | current_copy */
+    uint32_t pad0;
+    double tref[2]; /* time each copy's bundle is expressed at (f64, like now_time: models/TPNet.py:36-37,99) */
+    uint64_t pad1;
+} tpnet_node_meta;
+
+typedef struct tpnet_state {
+    float* p0;             /* [N][d] */
+    float* q;              /* [2][N][L][d] */
+    tpnet_node_meta* meta; /* [N] */
+    int64_t N;             /* rows, including padding row 0 (reference node_num) */
+    int32_t d;             /* projection dimension (any d >= 1; d % 4 == 0 takes the vector path) */
+    int32_t L;             /* num_layer */
+    uint32_t* err;         /* [4] device error words, zeroed by tpnet_state_init; err[0] = bad-id count */
+} tpnet_state;
+
+/* flags */
+#define TPNET_FLAG_NOT_SCALE 1u     /* readout: return the raw Gram (reference not_scale=True, TPNet.py:124-125) */
+#define TPNET_FLAG_EAGER_DECAY 2u   /* update: dense decay of every row first, exactly models/TPNet.py:83-85 */
+#define TPNET_FLAG_SEQUENTIAL 4u    /* update: never split a target's contributions over several wave groups:
+                                       the sum is then accumulated in the reference's index order (src side,
+                                       then dst side, models/TPNet.py:93-96) */
+
+const char* tpnet_strerror(int status);
+int tpnet_abi_version(void);
+int tpnet_last_hip_error(void);
+/* number of HIP devices visible (0 without a GPU; never initialises a context) */
+int tpnet_device_count(void);
+
+/* Bytes the caller must allocate for q and meta. */
+size_t tpnet_q_bytes(int64_t N, int32_t d, int32_t L);
+size_t tpnet_meta_bytes(int64_t N);
+
+/* Zero q, set meta[n] = {ver 0, tref = t0}, zero err.  (reset_random_projections, models/TPNet.py:131-139,
+ * minus the P[0] redraw which stays with the caller's RNG.) */
+int tpnet_state_init(const tpnet_state* st, double t0, void* stream);
+
+/* layers[i-1] (device, row-major [N][d], i = 1..L)  ->  q (copy 0), meta = {0, now_time}.
+ * (reload_random_projections / load_state_dict / .to(): models/TPNet.py:149-157) */
+int tpnet_import_layers(const tpnet_state* st, const float* const* layers, double now_time, void* stream);
+
+/* q -> layers[i-1][N][d] with the pending decay applied: the eager matrices the reference would hold at
+ * now_time.  (backup_random_projections / state_dict: models/TPNet.py:141-147) */
+int tpnet_export_layers(const tpnet_state* st, float* const* layers, double now_time, double lambda, void* stream);
+
+/* Eager dense decay, P[i] <- P[i] * factors[i-1] (host array, L floats), tref <- t_new for all rows.
+ * (models/TPNet.py:83-85; factors = f32(exp(-lambda*(t_new-now))^i) computed by the caller in f64) */
+int tpnet_decay(const tpnet_state* st, const float* factors, double t_new, void* stream);
+
+/* get_random_projections (models/TPNet.py:101-110): out[(i*n + k)*d + :] = P[i][ids[k]] at now_time, i = 0..L. */
+int tpnet_gather_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda,
+                      float* out, void* stream);
+
+/* get_pair_wise_feature up to (not including) self.mlp (models/TPNet.py:112-128):
+ * out[p][(2L+2)*a + b] = <R_a, R_b>, R = [P0[u_p]..PL[u_p], P0[v_p]..PL[v_p]] at now_time; then, unless
+ * TPNET_FLAG_NOT_SCALE, x<0 -> 0 and log(x+1).  u, v: device int64[n]; out: device float[n][(2L+2)^2]. */
+int tpnet_pair_gram(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
+                    double lambda, uint32_t flags, float* out, void* stream);
+
+/* Workspace for tpnet_update / tpnet_run_stream with at most max_edges edges per call. */
+size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
+
+/* update (models/TPNet.py:67-99) for one batch: src, dst device int64[B], t device double[B] (absolute times,
+ * chronological; t[B-1] is the new now_time).  now_time = the module's clock before the call; launch_id = a
+ * caller-kept counter, strictly increasing over calls that write the state (start at 1).  The host value of
+ * t[B-1] is passed as t_last so that no device->host copy is needed. */
+int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
+                 double t_last, double now_time, double lambda, uint32_t launch_id, uint32_t flags,
+                 void* workspace, size_t ws_bytes, void* stream);
+
+/* The caller loop of train_link_prediction.py:253-373 / evaluate_models_utils.py:56-184 for a device-resident
+ * edge stream: for each chronological batch of `batch` edges (last one partial): readout (src,dst) and
+ * (src,neg) on the pre-batch state, then update.  out_pos/out_neg: device float[E][(2L+2)^2] (pre-mlp
+ * features); either may be NULL to skip that readout.  neg may be NULL (then out_neg must be NULL).
+ * now_time: in = clock before the stream; the new clock is t[E-1] (returned through *t_end_out if non-NULL,
+ * which costs one 8-byte device->host copy + stream sync at the end; pass NULL to stay asynchronous).
+ * launch_id_base: first launch id; the call uses ids launch_id_base .. launch_id_base + ceil(E/batch) - 1. */
+int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                     const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                     uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
+                     void* workspace, size_t ws_bytes, double* t_end_out, void* stream);
+
+/* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
+ * the last call (and clears the words), TPNET_OK otherwise. */
+int tpnet_check_errors(const tpnet_state* st, void* stream);
+
+/* Timing aid for bench.py: elapsed milliseconds of `reps` back-to-back tpnet_run_stream calls measured with
+ * hipEvents recorded on `stream` (the stream the kernels run on).  The state is advanced `reps` times; the
+ * caller resets it.  kernel_ms_out (may be NULL) receives the summed duration of the per-batch step kernels
+ * only, from events around each launch of the LAST rep. */
+int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                      const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                      uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
+                      void* workspace, size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPNET_HIP_H */

@@ -1,0 +1,124 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/tpnet_hip.h declares; the ctypes binding lists exactly those; the Python module mirrors the reference
+operator's surface.  No compute call is made here (no GPU in this tier)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tpnet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tpnet_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound(hip_lib):
+    from tpnet_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/tpnet_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES.keys()) == syms
+    assert hip_lib.tpnet_abi_version() == 1
+    assert hip_lib.tpnet_strerror(-4) == b"node id out of range"
+
+
+def test_struct_layouts_match_header():
+    from tpnet_amd import _lib
+    assert ctypes.sizeof(_lib.NodeMeta) == 32
+    assert _lib.State.p0.offset == 0 and _lib.State.q.offset == 8 and _lib.State.meta.offset == 16
+    assert _lib.State.N.offset == 24 and _lib.State.d.offset == 32 and _lib.State.L.offset == 36
+    assert _lib.State.err.offset == 40 and ctypes.sizeof(_lib.State) == 48
+
+
+def test_size_helpers(hip_lib):
+    assert hip_lib.tpnet_q_bytes(9228, 128, 3) == 2 * 9228 * 3 * 128 * 4
+    assert hip_lib.tpnet_meta_bytes(9228) == 9228 * 32
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
+    from tpnet_amd import _lib
+    st = _lib.State(p0=None, q=None, meta=None, N=10, d=16, L=3, err=None)
+    assert hip_lib.tpnet_state_init(ctypes.byref(st), 0.0, None) == -1          # null pointers
+    st = _lib.State(p0=8, q=8, meta=8, N=10, d=16, L=7, err=8)
+    assert hip_lib.tpnet_pair_gram(ctypes.byref(st), None, None, 0, 0.0, 0.0, 0, None, None) == -1   # L > 4
+
+
+def _mk(**kw):
+    from tpnet_amd import RandomProjectionModule
+    args = dict(node_num=50, edge_num=120, dim_factor=10, num_layer=3, time_decay_weight=1e-6, device="cpu",
+                use_matrix=False, beginning_time=np.float64(12.5), not_scale=False, enforce_dim=32)
+    args.update(kw)
+    return RandomProjectionModule(**args)
+
+
+def test_module_surface_matches_reference(golden_dir):
+    """Constructor keywords, attributes, state-dict keys/dtypes/shapes as the reference (fixture G5 stores the
+    reference's own state_dict keys)."""
+    g = np.load(os.path.join(golden_dir, "g5_backup_reload.npz"))
+    rp = _mk(node_num=int(g["N"]), enforce_dim=int(g["d"]))
+    sd = rp.state_dict()
+    assert sorted(sd.keys()) == [str(k) for k in g["state_dict_keys"]]
+    got = [str(sd[k].dtype) + str(tuple(sd[k].shape)) for k in sorted(sd.keys())]
+    assert got == [str(x) for x in g["state_dict_dtypes"]]
+    assert rp.pair_wise_feature_dim == 64 and rp.dim == int(g["d"]) and rp.num_layer == 3
+    assert rp.now_time.dtype == torch.float64 and rp.begging_time.dtype == torch.float64
+    assert all(not p.requires_grad for p in rp.random_projections)
+    assert isinstance(rp.mlp, torch.nn.Sequential) and rp.mlp[0].in_features == 64 and rp.mlp[2].out_features == 64
+    for name in ("update", "get_random_projections", "get_pair_wise_feature", "reset_random_projections",
+                 "backup_random_projections", "reload_random_projections"):
+        assert callable(getattr(rp, name))
+
+
+def test_dim_rule_and_use_matrix():
+    rp = _mk(enforce_dim=-1, edge_num=157474 + 1, node_num=9228)     # Wikipedia: int(ln(2E))*10 = 120
+    assert rp.dim == 120
+    rp = _mk(use_matrix=True, node_num=30, enforce_dim=-1)
+    assert rp.dim == 30 and torch.equal(rp.random_projections[0], torch.eye(30))
+
+
+def test_triple_registration_state_dict_keys():
+    """The reference registers the same module under three parents; keys must nest the same way."""
+    rp = _mk()
+
+    class Holder(torch.nn.Module):
+        def __init__(self, r):
+            super().__init__()
+            self.random_projections = r
+
+    model = torch.nn.Sequential(Holder(rp), Holder(rp))
+    keys = model.state_dict().keys()
+    assert "0.random_projections.random_projections.3" in keys and "1.random_projections.now_time" in keys
+    model.load_state_dict(model.state_dict())
+
+
+def test_no_cpu_fallback():
+    from tpnet_amd import TPNetHipError
+    rp = _mk()
+    ids = np.array([1, 2, 3])
+    with pytest.raises(TPNetHipError):
+        rp.update(ids, ids, np.array([1.0, 2.0, 3.0]))
+    with pytest.raises(TPNetHipError):
+        rp.get_pair_wise_feature(ids, ids)
+    with pytest.raises(TPNetHipError):
+        rp.get_random_projections(ids)
+    # state-management methods that need no kernel keep working on the CPU copy (checkpoint round trips)
+    bk = rp.backup_random_projections()
+    rp.reload_random_projections(bk)
+    rp.reset_random_projections()
+    assert float(rp.now_time) == 12.5
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tpnet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"

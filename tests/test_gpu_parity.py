@@ -1,0 +1,326 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI by the drop-in module,
+against (1) the golden vectors produced by the reference itself, (2) the numpy oracle on seeded random inputs,
+(3) size-independent properties at BASELINE.json's full C2 size.
+
+Tolerances (north_star: 1e-4 relative fp32):
+  state P[i]      rtol 1e-4, atol 1e-6 * max|P[i]|         (exact mode: rtol 2e-6 -- only expf differs)
+  raw Gram        |delta| <= 1e-4 * ||R_a|| * ||R_b||       (entries are near-cancelling sums of d products)
+  log(relu(G)+1)  rtol 1e-4, atol 1e-5
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tpnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: run on the MI355X box (python -m pytest -m gpu)")
+
+
+def _module(N, d, L, lam, t0, P0=None, not_scale=False, use_matrix=False, exact=False, E=1000):
+    from tpnet_amd import RandomProjectionModule
+    rp = RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L, time_decay_weight=lam, device=DEV,
+                                use_matrix=use_matrix, beginning_time=np.float64(t0), not_scale=not_scale,
+                                enforce_dim=-1 if use_matrix else d, exact=exact)
+    if P0 is not None:
+        rp.random_projections[0].data = torch.from_numpy(np.ascontiguousarray(P0))
+    return rp.to(DEV)
+
+
+def _layers(rp):
+    return np.stack([rp.random_projections[i].detach().cpu().numpy() for i in range(1, rp.num_layer + 1)])
+
+
+def _assert_state(got, want, rtol, what=""):
+    for i in range(want.shape[0]):
+        scale = max(1e-30, float(np.abs(want[i]).max()))
+        np.testing.assert_allclose(got[i], want[i], rtol=rtol, atol=1e-6 * scale, err_msg=f"{what} layer {i + 1}")
+
+
+def _gram_bound(P, u, v, L, rel):
+    R = np.stack([P[i][u] for i in range(L + 1)] + [P[i][v] for i in range(L + 1)], axis=1).astype(np.float64)
+    nrm = np.linalg.norm(R, axis=2)
+    return (rel * nrm[:, :, None] * nrm[:, None, :]).reshape(len(u), -1) + 1e-30
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (1) golden vectors from the reference
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("name", ["g1_update_d16_L3.npz", "g2_update_d120_L2.npz",
+                                  "g2b_update_d64_L3_fastdecay.npz", "g6_use_matrix_N30.npz"])
+def test_golden_update_trajectory(golden_dir, name, exact):
+    _need_gpu()
+    g = np.load(os.path.join(golden_dir, name))
+    L, B, N = int(g["L"]), int(g["B"]), int(g["N"])
+    rp = _module(N, int(g["d"]), L, float(g["lam"]), float(g["t0"]), P0=g["P0"], use_matrix=bool(g["use_matrix"]),
+                 exact=exact)
+    nb = len(g["src"]) // B
+    for b in range(nb):
+        s = slice(b * B, (b + 1) * B)
+        rp.update(src_node_ids=g["src"][s], dst_node_ids=g["dst"][s], node_interact_times=g["t"][s])
+        _assert_state(_layers(rp), g[f"P_after_{b}"], 5e-6 if exact else 1e-4, f"{name} batch {b}")
+        assert float(rp.now_time.item()) == float(g[f"now_after_{b}"])
+
+
+@pytest.mark.parametrize("name", ["g3g4_readout_d16_L3.npz", "g3g4_readout_d128_L3.npz",
+                                  "g3g4_readout_d140_L1.npz"])
+def test_golden_readout(golden_dir, name):
+    _need_gpu()
+    g = np.load(os.path.join(golden_dir, name))
+    L, N, d = int(g["L"]), int(g["N"]), int(g["d"])
+    now = float(g["now_time"])
+    rp = _module(N, d, L, float(g["lam"]), now, P0=g["P"][0])
+    # load the reference's state the way its callers do: reload_random_projections (TPNet.py:149-157)
+    rp.reload_random_projections((torch.tensor(now, dtype=torch.float64, device=DEV),
+                                  [torch.from_numpy(g["P"][i]).to(DEV) for i in range(1, L + 1)]))
+    u, v = g["u"], g["v"]
+    got = rp.pair_gram(u, v).cpu().numpy()
+    np.testing.assert_allclose(got, g["gram_scaled"], rtol=1e-4, atol=1e-5)
+    rp.not_scale = True
+    raw = rp.pair_gram(u, v).cpu().numpy()
+    assert np.all(np.abs(raw - g["gram_raw"]) <= _gram_bound(g["P"], u, v, L, 1e-5))
+    rp.not_scale = False
+    sd = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("mlp.")}
+    rp.mlp.load_state_dict(sd)
+    feat = rp.get_pair_wise_feature(src_node_ids=u, dst_node_ids=v)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), g["feat_mlp_scaled"], rtol=1e-4, atol=1e-5)
+    rows = rp.get_random_projections(u)
+    assert len(rows) == L + 1
+    np.testing.assert_array_equal(np.stack([r.cpu().numpy() for r in rows]), g["rows_u"])
+    # gradient reaches the mlp only
+    feat.sum().backward()
+    assert rp.mlp[0].weight.grad is not None and all(p.grad is None for p in rp.random_projections)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_golden_backup_reload_reset(golden_dir, exact):
+    _need_gpu()
+    g = np.load(os.path.join(golden_dir, "g5_backup_reload.npz"))
+    L, B, N = int(g["L"]), int(g["B"]), int(g["N"])
+    rp = _module(N, int(g["d"]), L, float(g["lam"]), float(g["t0"]), P0=g["P0"], exact=exact)
+    upd = lambda b: rp.update(g["src"][b * B:(b + 1) * B], g["dst"][b * B:(b + 1) * B], g["t"][b * B:(b + 1) * B])
+    rtol = 5e-6 if exact else 1e-4
+    for b in range(3):
+        upd(b)
+    bk = rp.backup_random_projections()
+    assert float(bk[0].item()) == float(g["bk_now"]) and len(bk[1]) == L
+    _assert_state(np.stack([x.cpu().numpy() for x in bk[1]]), g["bk_P"], rtol, "backup")
+    for b in range(3, 6):
+        upd(b)
+    _assert_state(_layers(rp), g["P_after_6"], rtol, "after 6")
+    rp.reload_random_projections(bk)
+    _assert_state(_layers(rp), g["P_after_reload"], rtol, "after reload")
+    assert float(rp.now_time.item()) == float(g["now_after_reload"])
+    upd(3)
+    _assert_state(_layers(rp), g["P_after_reload_update"], rtol, "after reload+update")
+    p0_before = rp.random_projections[0].detach().clone()
+    rp.reset_random_projections()
+    assert float(rp.now_time.item()) == float(g["now_after_reset"])
+    assert np.all(_layers(rp) == 0)
+    assert not torch.equal(p0_before, rp.random_projections[0])       # P[0] is redrawn (TPNet.py:138-139)
+    # and the module keeps working after a reset
+    upd(0)
+    assert np.abs(_layers(rp)[0]).max() > 0
+    # state-dict round trip through a fresh module (checkpoint save / load, utils/EarlyStopping.py:64-87)
+    sd = {k: v.clone() for k, v in rp.state_dict().items()}
+    rp2 = _module(N, int(g["d"]), L, float(g["lam"]), 0.0, exact=exact)
+    rp2.load_state_dict(sd)
+    upd(1)
+    rp2.update(g["src"][B:2 * B], g["dst"][B:2 * B], g["t"][B:2 * B])
+    np.testing.assert_allclose(_layers(rp2), _layers(rp), rtol=1e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (2) seeded random inputs against the oracle: geometries, layer counts, hubs, duplicates, ragged tail
+# ---------------------------------------------------------------------------------------------------------
+def _random_stream(rng, N, E, span, hub_frac=0.2):
+    src = rng.randint(1, N, E).astype(np.int64)
+    dst = rng.randint(1, N, E).astype(np.int64)
+    src[rng.rand(E) < hub_frac] = 1 + rng.randint(0, 3)          # hubs: long contribution lists
+    dst[rng.rand(E) < hub_frac / 2] = 7
+    dst[::17] = src[::17]                                         # self pairs
+    t = np.sort(rng.uniform(1.0e6, 1.0e6 + span, E))
+    neg = rng.randint(0, N, E).astype(np.int64)                   # includes the padding row 0
+    return src, dst, neg, t
+
+
+@pytest.mark.parametrize("d,L,N,B", [(64, 3, 300, 50), (128, 3, 500, 128), (256, 3, 200, 96), (512, 2, 150, 64),
+                                     (120, 3, 260, 40), (140, 1, 90, 33), (30, 4, 64, 20), (1024, 1, 80, 16),
+                                     (128, 4, 333, 77), (64, 2, 1000, 500)])
+@pytest.mark.parametrize("exact", [True, False])
+def test_stream_matches_oracle(d, L, N, B, exact):
+    """run_stream (fused readout + update per batch, ragged last batch) == oracle loop readout, readout, update."""
+    _need_gpu()
+    rng = np.random.RandomState(d * 7 + L)
+    E = 4 * B + B // 3 + 1
+    lam = 2e-6
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    rp = _module(N, d, L, lam, t[0], P0=P0, exact=exact)
+    st = O.OracleState(P0, L, lam, t[0])
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    fp, fn = rp.run_stream(dev(src), dev(dst), dev(neg), dev(t), B)
+    fp = fp.cpu().numpy(); fn = fn.cpu().numpy()
+    for b in range(0, E, B):
+        s = slice(b, min(b + B, E))
+        want_p = O.pair_gram(st, src[s], dst[s]); want_n = O.pair_gram(st, src[s], neg[s])
+        np.testing.assert_allclose(fp[s], want_p, rtol=1e-4, atol=1e-5, err_msg=f"pos batch {b // B}")
+        np.testing.assert_allclose(fn[s], want_n, rtol=1e-4, atol=1e-5, err_msg=f"neg batch {b // B}")
+        O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 5e-6 if exact else 1e-4, "final state")
+    assert float(rp.now_time.item()) == float(t[-1])
+    rp.check_device_errors()
+
+
+def test_exact_mode_is_bit_exact_when_times_are_batch_constant():
+    """With one timestamp per batch every time weight is exp(0) = 1 and the decay factor comes from the host in
+    f64 (as in the reference), so the exact mode must reproduce the oracle's f32 sums BIT FOR BIT: same products,
+    same index-ordered additions (src side then dst side), no fused multiply-add."""
+    _need_gpu()
+    rng = np.random.RandomState(11)
+    N, d, L, B, nb = 120, 128, 3, 64, 6
+    src, dst, _, _ = _random_stream(rng, N, B * nb, 1.0)
+    t = np.repeat(1000.0 * np.arange(1, nb + 1), B)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    rp = _module(N, d, L, 1e-4, 0.0, P0=P0, exact=True)
+    st = O.OracleState(P0, L, 1e-4, 0.0)
+    for b in range(nb):
+        s = slice(b * B, (b + 1) * B)
+        rp.update(src[s], dst[s], t[s])
+        O.update(st, src[s], dst[s], t[s])
+        np.testing.assert_array_equal(_layers(rp), np.stack(st.P[1:]))
+
+
+def test_module_calls_interleave_like_the_training_loop():
+    """Caller order of train_link_prediction.py:325-373: readouts (big and small), then update, per batch; plus
+    encoder-style index patterns (np.tile / np.repeat, padding id 0: models/TPNet.py:313-316)."""
+    _need_gpu()
+    rng = np.random.RandomState(2)
+    N, d, L, B, K = 400, 128, 3, 40, 5
+    lam = 1e-6
+    src, dst, neg, t = _random_stream(rng, N, 6 * B, 3.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    rp = _module(N, d, L, lam, t[0], P0=P0)
+    st = O.OracleState(P0, L, lam, t[0])
+    for b in range(6):
+        s = slice(b * B, (b + 1) * B)
+        neigh = rng.randint(0, N, (2 * B, K))
+        neigh[rng.rand(2 * B, K) < 0.3] = 0
+        big_u = np.tile(neigh.reshape(-1), 2)
+        big_v = np.concatenate([np.repeat(src[s], K), np.repeat(dst[s], K), np.repeat(src[s], K), np.repeat(dst[s], K)])
+        for (u, v) in ((big_u, big_v), (src[s], dst[s]), (src[s], neg[s])):
+            got = rp.pair_gram(u, v).cpu().numpy()
+            np.testing.assert_allclose(got, O.pair_gram(st, u, v), rtol=1e-4, atol=1e-5)
+        rp.update(src[s], dst[s], t[s])
+        O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4)
+
+
+def test_edge_cases_and_errors():
+    _need_gpu()
+    N, d, L = 50, 64, 3
+    rp = _module(N, d, L, 1e-6, 0.0)
+    ids = np.array([1, 2, 3])
+    with pytest.raises(IndexError):
+        rp.update(np.array([], dtype=np.int64), np.array([], dtype=np.int64), np.array([]))
+    with pytest.raises(IndexError):
+        rp.update(np.array([N]), np.array([1]), np.array([1.0]))
+    with pytest.raises(IndexError):
+        rp.get_pair_wise_feature(np.array([1]), np.array([-N - 1]))
+    with pytest.raises(ValueError):
+        rp.update(ids, ids[:2], np.array([1.0, 2.0, 3.0]))
+    assert rp.pair_gram(np.array([], dtype=np.int64), np.array([], dtype=np.int64)).shape == (0, 64)
+    # a single edge, a self pair, the padding row
+    rp.update(np.array([4]), np.array([4]), np.array([10.0]))
+    P0 = rp.random_projections[0].detach().cpu().numpy()
+    np.testing.assert_allclose(rp.random_projections[1][4].cpu().numpy(), 2 * P0[4], rtol=1e-6)
+    g = rp.pair_gram(np.array([0]), np.array([0])).cpu().numpy().reshape(8, 8)
+    assert np.isfinite(g).all() and g[0, 0] > 0 and g[1, 1] == 0
+    # device-side id check of the stream path: bad ids are skipped and reported, never dereferenced
+    src = torch.tensor([1, 2, N + 5, 3], dtype=torch.int64, device=DEV)
+    dst = torch.tensor([2, 3, 4, -1], dtype=torch.int64, device=DEV)
+    t = torch.tensor([11.0, 12.0, 13.0, 14.0], dtype=torch.float64, device=DEV)
+    rp.run_stream(src, dst, None, t, 2, want_neg=False)
+    with pytest.raises(IndexError):
+        rp.check_device_errors()
+    rp.check_device_errors()     # cleared
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (3) BASELINE.json's config C2 at full size: oracle on the whole stream + size-independent properties
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2():
+    from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+    c = CONFIGS["C2"]
+    src, dst, t, N = synthetic_stream(c["U"], c["I"], c["E"], c["span"], 0)
+    neg = synthetic_negatives(c["U"], N, c["E"], c["B"], 1)
+    torch.manual_seed(0)
+    P0 = torch.normal(0, 1 / np.sqrt(c["d"]), (N, c["d"])).numpy()
+    return dict(c=c, src=src, dst=dst, neg=neg, t=t, N=N, P0=P0)
+
+
+def _run_c2(c2, P0, exact=False, E=None):
+    c = c2["c"]
+    E = E or c["E"]
+    rp = _module(c2["N"], c["d"], 3, c["lam"], 0.0, P0=P0, exact=exact, E=c["E"])
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x[:E])).to(DEV)
+    fp, fn = rp.run_stream(dev(c2["src"]), dev(c2["dst"]), dev(c2["neg"]), dev(c2["t"]), c["B"],
+                           t_end=float(c2["t"][E - 1]))
+    return rp, fp, fn
+
+
+def test_c2_full_stream_against_oracle(c2):
+    """Wikipedia-shaped stream (157 474 edges, d=128, B=1000, 158 batches incl. a ragged tail): every readout of
+    every batch and the final state, lazy-decay mode, against the oracle's eager arithmetic."""
+    _need_gpu()
+    c = c2["c"]
+    rp, fp, fn = _run_c2(c2, c2["P0"])
+    fp = fp.cpu().numpy(); fn = fn.cpu().numpy()
+    st = O.OracleState(c2["P0"], 3, c["lam"], 0.0)
+    E, B = c["E"], c["B"]
+    worst = 0.0
+    for b in range(0, E, B):
+        s = slice(b, min(b + B, E))
+        for got, v in ((fp[s], c2["dst"][s]), (fn[s], c2["neg"][s])):
+            want = O.pair_gram(st, c2["src"][s], v)
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+            worst = max(worst, float(np.abs(got - want).max()))
+        O.update(st, c2["src"][s], c2["dst"][s], c2["t"][s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "C2 final state")
+    rp.check_device_errors()
+    print(f"C2 full stream: worst |feature delta| = {worst:.3e}")
+
+
+def test_c2_properties(c2):
+    """Size-independent properties on the full stream: (a) run-to-run determinism, bit for bit; (b) linearity in
+    P[0]: scaling P[0] by 2 scales every layer by exactly 2 (power-of-two scaling commutes with f32 rounding) and
+    shifts nothing else; (c) chunked == unchunked: the stream in two run_stream calls equals one call."""
+    _need_gpu()
+    c = c2["c"]
+    E = 40 * c["B"] + 123
+    rp1, fp1, fn1 = _run_c2(c2, c2["P0"], E=E)
+    rp2, fp2, fn2 = _run_c2(c2, c2["P0"], E=E)
+    assert torch.equal(fp1, fp2) and torch.equal(fn1, fn2)
+    np.testing.assert_array_equal(_layers(rp1), _layers(rp2))
+    rp3, _, _ = _run_c2(c2, 2.0 * c2["P0"], E=E)
+    np.testing.assert_array_equal(_layers(rp3), 2.0 * _layers(rp1))
+    # two calls
+    rp4 = _module(c2["N"], c["d"], 3, c["lam"], 0.0, P0=c2["P0"], E=c["E"])
+    dev = lambda x, a, b: torch.from_numpy(np.ascontiguousarray(x[a:b])).to(DEV)
+    cut = 17 * c["B"]
+    outs = []
+    for a, b in ((0, cut), (cut, E)):
+        outs.append(rp4.run_stream(dev(c2["src"], a, b), dev(c2["dst"], a, b), dev(c2["neg"], a, b),
+                                   dev(c2["t"], a, b), c["B"]))
+    assert torch.equal(torch.cat([outs[0][0], outs[1][0]]), fp1)
+    np.testing.assert_array_equal(_layers(rp4), _layers(rp1))

@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI in include/tpnet_hip.h (tpnet_amd/libtpnet_hip.so).
+
+There is NO CPU fallback: if the HIP library is missing, or no GPU is present when a compute entry point is
+called, the product path raises.  PyTorch is used only as plumbing (device memory, streams).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtpnet_hip.so")
+
+TPNET_MAX_LAYERS = 4
+FLAG_NOT_SCALE = 1
+FLAG_EAGER_DECAY = 2
+FLAG_SEQUENTIAL = 4
+
+ERR_INDEX = -4
+
+
+class NodeMeta(C.Structure):
+    _fields_ = [("ver", C.c_uint32), ("pad0", C.c_uint32), ("tref", C.c_double * 2), ("pad1", C.c_uint64)]
+
+
+class State(C.Structure):
+    _fields_ = [("p0", C.c_void_p), ("q", C.c_void_p), ("meta", C.c_void_p), ("N", C.c_int64), ("d", C.c_int32),
+                ("L", C.c_int32), ("err", C.c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol include/tpnet_hip.h declares (tests check this)
+_P = C.c_void_p
+_SP = C.POINTER(State)
+SIGNATURES = {
+    "tpnet_strerror": (C.c_char_p, [C.c_int]),
+    "tpnet_abi_version": (C.c_int, []),
+    "tpnet_last_hip_error": (C.c_int, []),
+    "tpnet_device_count": (C.c_int, []),
+    "tpnet_q_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "tpnet_meta_bytes": (C.c_size_t, [C.c_int64]),
+    "tpnet_state_init": (C.c_int, [_SP, C.c_double, _P]),
+    "tpnet_import_layers": (C.c_int, [_SP, C.POINTER(_P), C.c_double, _P]),
+    "tpnet_export_layers": (C.c_int, [_SP, C.POINTER(_P), C.c_double, C.c_double, _P]),
+    "tpnet_decay": (C.c_int, [_SP, C.POINTER(C.c_float), C.c_double, _P]),
+    "tpnet_gather_rows": (C.c_int, [_SP, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
+    "tpnet_pair_gram": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P]),
+    "tpnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_uint32,
+                               C.c_uint32, _P, C.c_size_t, _P]),
+    "tpnet_run_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
+                                   C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(C.c_double), _P]),
+    "tpnet_check_errors": (C.c_int, [_SP, _P]),
+    "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
+                                    C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), _P]),
+}
+
+_lib = None
+
+
+class TPNetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtpnet_hip.so (built by __graft_entry__.build() / tpnet_amd/csrc/Makefile).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TPNetHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). tpnet_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc == 0:
+        return
+    lib = load()
+    msg = lib.tpnet_strerror(rc).decode()
+    if rc == ERR_INDEX:
+        raise IndexError(f"tpnet_hip {what}: {msg}")
+    extra = f" (hipError_t {lib.tpnet_last_hip_error()})" if rc == -3 else ""
+    raise TPNetHipError(f"tpnet_hip {what}: {msg}{extra}")

@@ -1,0 +1,264 @@
+// C ABI (include/tpnet_hip.h): argument checks, workspace carving, launch sequencing.  No allocation, no implicit
+// synchronisation; everything is enqueued on the caller's stream.
+#include "tpnet_common.h"
+
+#include <vector>
+
+namespace tpnet {
+thread_local int g_last_hip_error = 0;
+
+static int check_state(const tpnet_state* st) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err) return TPNET_ERR_BAD_ARG;
+    if (st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS) return TPNET_ERR_BAD_ARG;
+    if (st->N >= (1ll << 31)) return TPNET_ERR_BAD_ARG;
+    return TPNET_OK;
+}
+
+// largest chunk (multiple of `batch`, at most E) whose plan fits the workspace
+static int64_t max_chunk(size_t ws_bytes, int64_t E, int64_t batch) {
+    if (plan_bytes(E, batch) <= ws_bytes) return E;
+    int64_t lo = 0, hi = (E + batch - 1) / batch;  // in batches; lo fits (0), hi does not
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) / 2;
+        if (plan_bytes(mid * batch, batch) <= ws_bytes) lo = mid; else hi = mid;
+    }
+    return lo * batch;
+}
+
+struct StepTimer {
+    hipEvent_t* ev = nullptr;  // 2 per launch when per-kernel timing is requested
+    int64_t n = 0, cap = 0;
+};
+
+static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                           const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                           uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* ws,
+                           size_t ws_bytes, hipStream_t s, StepTimer* timer) {
+    if (E == 0) return TPNET_OK;
+    const int64_t chunk = max_chunk(ws_bytes, E, batch);
+    if (chunk < 1) return TPNET_ERR_WORKSPACE;
+    const int NG = (2 * st.L + 2) * (2 * st.L + 2);
+    uint32_t lid = launch_id_base;
+    for (int64_t c0 = 0; c0 < E; c0 += chunk) {
+        const int64_t Ec = (E - c0 < chunk) ? (E - c0) : chunk;
+        Plan p{};
+        int rc = plan_carve(ws, ws_bytes, Ec, batch, &p);
+        if (rc) return rc;
+        // the clock before a later chunk is t[c0-1], read on device (no host copy of the timestamps is needed)
+        rc = plan_build(st, p, src + c0, dst + c0, t + c0, Ec, batch, now_time, c0 > 0 ? t + c0 - 1 : nullptr, lambda,
+                        flags, s);
+        if (rc) return rc;
+        StreamArgs a;
+        a.src = src + c0;
+        a.dst = dst + c0;
+        a.neg = neg ? neg + c0 : nullptr;
+        a.t = t + c0;
+        a.out_pos = out_pos ? out_pos + c0 * NG : nullptr;
+        a.out_neg = out_neg ? out_neg + c0 * NG : nullptr;
+        const int64_t nb = (Ec + batch - 1) / batch;
+        const bool have_readout = a.out_pos || a.out_neg;
+        for (int64_t b = 0; b < nb; ++b, ++lid) {
+            const int32_t ne = (int32_t)((Ec - b * batch < batch) ? (Ec - b * batch) : batch);
+            if (flags & TPNET_FLAG_EAGER_DECAY) {
+                // reference order: readout on the pre-batch state, THEN decay + scatter-add (TPNet.py:83-96)
+                if (have_readout) {
+                    rc = launch_step(st, a, p, b, ne, lambda, lid, flags | ROLE_READOUT, s);
+                    if (rc) return rc;
+                }
+                rc = launch_decay_desc(st, p, b, s);
+                if (rc) return rc;
+                rc = launch_step(st, a, p, b, ne, lambda, lid, flags | ROLE_UPDATE, s);
+                if (rc) return rc;
+            } else {
+                if (timer && timer->n < timer->cap) (void)hipEventRecord(timer->ev[2 * timer->n], s);
+                rc = launch_step(st, a, p, b, ne, lambda, lid, flags | ROLE_UPDATE | (have_readout ? ROLE_READOUT : 0u),
+                                 s);
+                if (rc) return rc;
+                if (timer && timer->n < timer->cap) {
+                    (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);
+                    ++timer->n;
+                }
+            }
+        }
+    }
+    return TPNET_OK;
+}
+
+}  // namespace tpnet
+
+using namespace tpnet;
+
+extern "C" {
+
+const char* tpnet_strerror(int status) {
+    switch (status) {
+        case TPNET_OK: return "ok";
+        case TPNET_ERR_BAD_ARG: return "bad argument";
+        case TPNET_ERR_WORKSPACE: return "workspace missing or too small";
+        case TPNET_ERR_HIP: return "HIP runtime error";
+        case TPNET_ERR_INDEX: return "node id out of range";
+        case TPNET_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+int tpnet_abi_version(void) { return TPNET_ABI_VERSION; }
+int tpnet_last_hip_error(void) { return g_last_hip_error; }
+
+int tpnet_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t tpnet_q_bytes(int64_t N, int32_t d, int32_t L) { return (size_t)2 * (size_t)N * (size_t)L * (size_t)d * sizeof(float); }
+size_t tpnet_meta_bytes(int64_t N) { return (size_t)N * sizeof(tpnet_node_meta); }
+
+int tpnet_state_init(const tpnet_state* st, double t0, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    return launch_state_init(*st, t0, (hipStream_t)stream);
+}
+
+int tpnet_import_layers(const tpnet_state* st, const float* const* layers, double now_time, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (!layers) return TPNET_ERR_BAD_ARG;
+    for (int i = 0; i < st->L; ++i)
+        if (!layers[i]) return TPNET_ERR_BAD_ARG;
+    return launch_import(*st, layers, now_time, (hipStream_t)stream);
+}
+
+int tpnet_export_layers(const tpnet_state* st, float* const* layers, double now_time, double lambda, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (!layers) return TPNET_ERR_BAD_ARG;
+    for (int i = 0; i < st->L; ++i)
+        if (!layers[i]) return TPNET_ERR_BAD_ARG;
+    return launch_export(*st, layers, now_time, lambda, (hipStream_t)stream);
+}
+
+int tpnet_decay(const tpnet_state* st, const float* factors, double t_new, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (!factors) return TPNET_ERR_BAD_ARG;
+    return launch_decay(*st, factors, t_new, (hipStream_t)stream);
+}
+
+int tpnet_gather_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out,
+                      void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!ids || !out))) return TPNET_ERR_BAD_ARG;
+    return launch_gather_rows(*st, ids, n, now_time, lambda, out, (hipStream_t)stream);
+}
+
+int tpnet_pair_gram(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
+                    double lambda, uint32_t flags, float* out, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!u || !v || !out))) return TPNET_ERR_BAD_ARG;
+    return launch_pair_gram(*st, u, v, n, now_time, lambda, flags, out, (hipStream_t)stream);
+}
+
+size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
+
+int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
+                 double t_last, double now_time, double lambda, uint32_t launch_id, uint32_t flags, void* workspace,
+                 size_t ws_bytes, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (B < 1 || !src || !dst || !t) return TPNET_ERR_BAD_ARG;  // the reference raises on an empty batch (t[-1])
+    if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
+    (void)t_last;
+    if (plan_bytes(B, B) > ws_bytes) return TPNET_ERR_WORKSPACE;
+    return run_stream_impl(*st, src, dst, nullptr, t, B, B, now_time, lambda, launch_id, flags, nullptr, nullptr,
+                           workspace, ws_bytes, (hipStream_t)stream, nullptr);
+}
+
+int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                     const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                     uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* workspace,
+                     size_t ws_bytes, double* t_end_out, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (E < 0 || batch < 1 || (E > 0 && (!src || !dst || !t))) return TPNET_ERR_BAD_ARG;
+    if (out_neg && !neg) return TPNET_ERR_BAD_ARG;
+    const int64_t nb = (E + batch - 1) / batch;
+    if (launch_id_base == 0 || (uint64_t)launch_id_base + (uint64_t)nb >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
+    rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos, out_neg,
+                         workspace, ws_bytes, (hipStream_t)stream, nullptr);
+    if (rc) return rc;
+    if (t_end_out && E > 0) {
+        TPNET_HIP_TRY(hipMemcpyAsync(t_end_out, t + E - 1, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        TPNET_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return TPNET_OK;
+}
+
+int tpnet_check_errors(const tpnet_state* st, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    uint32_t h[4] = {0, 0, 0, 0};
+    TPNET_HIP_TRY(hipMemcpyAsync(h, st->err, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    TPNET_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (h[0] != 0) {
+        TPNET_HIP_TRY(hipMemsetAsync(st->err, 0, sizeof(h), (hipStream_t)stream));
+        return TPNET_ERR_INDEX;
+    }
+    return TPNET_OK;
+}
+
+int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                      const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                      uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* workspace,
+                      size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (reps < 1 || E < 1 || batch < 1) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nb = (E + batch - 1) / batch;
+    if ((uint64_t)launch_id_base + (uint64_t)nb * (uint64_t)(reps + 1) >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
+    hipEvent_t e0, e1;
+    TPNET_HIP_TRY(hipEventCreate(&e0));
+    TPNET_HIP_TRY(hipEventCreate(&e1));
+    uint32_t lid = launch_id_base;
+    TPNET_HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) {
+        rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, lid, flags, out_pos, out_neg, workspace,
+                             ws_bytes, s, nullptr);
+        if (rc) return rc;
+        lid += (uint32_t)nb;
+    }
+    TPNET_HIP_TRY(hipEventRecord(e1, s));
+    TPNET_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TPNET_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (total_ms_out) *total_ms_out = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+
+    if (kernel_ms_out) {
+        // one extra pass with an event pair around every step launch (up to 512 launches): per-kernel durations
+        StepTimer tm;
+        tm.cap = nb < 512 ? nb : 512;
+        std::vector<hipEvent_t> evs((size_t)(2 * tm.cap));
+        for (auto& e : evs) TPNET_HIP_TRY(hipEventCreate(&e));
+        tm.ev = evs.data();
+        rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, lid, flags, out_pos, out_neg, workspace,
+                             ws_bytes, s, &tm);
+        if (rc) return rc;
+        TPNET_HIP_TRY(hipStreamSynchronize(s));
+        double sum = 0.0;
+        for (int64_t i = 0; i < tm.n; ++i) {
+            float k = 0.f;
+            TPNET_HIP_TRY(hipEventElapsedTime(&k, evs[2 * i], evs[2 * i + 1]));
+            sum += k;
+        }
+        *kernel_ms_out = tm.n ? (float)(sum / (double)tm.n) : 0.f;
+        for (auto& e : evs) (void)hipEventDestroy(e);
+    }
+    return TPNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,603 @@
+// gfx950 kernels of the temporal-walk-matrix hot path: pairwise Gram readout, batched scatter-add update, the
+// fused per-batch "step", and the dense state passes (init / import / export / decay / row gather).
+//
+// Reference semantics restated by these kernels: models/TPNet.py:67-99 (update), :101-110 (row gather),
+// :112-128 (pairwise readout before self.mlp), :131-157 (reset / backup / reload).
+//
+// Geometry: LPP lanes of a 64-wide wavefront cooperate on one row (one pair, or one target node); each lane owns
+// VPL vectors of W floats per column chunk, so a wave-level load instruction fetches whole rows with 16-byte lanes:
+//   d = 64 -> 4 rows per instruction, d = 128 -> 2, d = 256 -> 1, d = 512 -> one row per two instructions.
+// Compiled with -ffp-contract=off: the update path must not fuse (row*w)+acc, so that the eager/sequential mode
+// reproduces the reference's rounding; the Gram uses explicit fmaf.
+#include "tpnet_common.h"
+
+namespace tpnet {
+
+static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (ver >> 1)
+static constexpr int BLOCK = 256;
+
+// ---------------------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void ldv(const float* __restrict__ row, int vi, float* dst) {
+    if constexpr (W == 4) {
+        const float4 x = reinterpret_cast<const float4*>(row)[vi];
+        dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+    } else {
+        dst[0] = row[vi];
+    }
+}
+template <int W>
+__device__ __forceinline__ void stv(float* __restrict__ row, int vi, const float* src) {
+    if constexpr (W == 4) {
+        reinterpret_cast<float4*>(row)[vi] = make_float4(src[0], src[1], src[2], src[3]);
+    } else {
+        row[vi] = src[0];
+    }
+}
+
+struct MetaView {
+    int copy;  // copy holding the pre-launch bundle
+    float g;   // exp(-lambda * (now - tref[copy])): pending decay of layer 1 (layer i: g^i)
+};
+
+__device__ __forceinline__ MetaView read_meta(const NodeMeta* __restrict__ meta, int64_t n, uint32_t bid, double now,
+                                              double lambda) {
+    const uint4* p = reinterpret_cast<const uint4*>(meta + n);
+    const uint4 a = p[0];
+    const uint4 b = p[1];
+    int c = (int)(a.x & 1u);
+    if ((a.x >> 1) == bid) c ^= 1;  // rewritten by a concurrent group of THIS launch: the pre-batch copy is the other one
+    const double t0 = __hiloint2double((int)a.w, (int)a.z);
+    const double t1 = __hiloint2double((int)b.y, (int)b.x);
+    const double tr = c ? t1 : t0;
+    const float x = (float)(-lambda * (now - tr));
+    MetaView m;
+    m.copy = c;
+    m.g = (x == 0.0f) ? 1.0f : expf(x);
+    return m;
+}
+
+// Recursive halving: MP partial sums per lane over a group of 2*M lanes -> lane gl ends with the MP/(2M) complete sums
+// of indices [gl*MP/(2M), ...).  63 shuffles for 64 values over 64 lanes instead of 6*64 for a butterfly all-reduce.
+template <int C, int M>
+struct Halve {
+    static __device__ __forceinline__ void run(float* v, int gl) {
+        const bool upper = (gl & M) != 0;
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) {
+            const float keep = upper ? v[i + C / 2] : v[i];
+            const float send = upper ? v[i] : v[i + C / 2];
+            v[i] = keep + __shfl_xor(send, M, 64);
+        }
+        Halve<C / 2, M / 2>::run(v, gl);
+    }
+};
+template <int C>
+struct Halve<C, 0> {
+    static __device__ __forceinline__ void run(float*, int) {}
+};
+
+template <int LPP, int L>
+struct GramCfg {
+    static constexpr int NR = L + 1;
+    static constexpr int NN = 2 * NR;
+    static constexpr int NG = NN * NN;
+    static constexpr int MP = ((NG + LPP - 1) / LPP) * LPP;
+    static constexpr int PER = MP / LPP;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairwise readout of ONE pair by one group of LPP lanes (models/TPNet.py:119-128)
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int VPL, int W, int L>
+__device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
+                                          double now, double lambda, bool do_scale, float* __restrict__ out, int gl) {
+    using C = GramCfg<LPP, L>;
+    constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
+    const int d = S.d;
+    const int nvec = d / W;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+
+    bool idok = valid && (uint64_t)u < (uint64_t)S.N && (uint64_t)v < (uint64_t)S.N;
+    if (valid && !idok && gl == 0) atomicAdd(S.err, 1u);
+    if (!idok) { u = 0; v = 0; }
+
+    const float* rowp[NN];
+    float rs[NN];
+    {
+        const int64_t ids[2] = {u, v};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const MetaView m = read_meta(meta, ids[s], bid, now, lambda);
+            rowp[s * NR] = S.p0 + ids[s] * (int64_t)d;
+            rs[s * NR] = 1.0f;
+            const float* qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
+            float g = 1.0f;
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+                g *= m.g;
+                rowp[s * NR + i] = qb + (int64_t)(i - 1) * d;
+                rs[s * NR + i] = g;
+            }
+        }
+    }
+
+    float acc[C::MP];
+#pragma unroll
+    for (int i = 0; i < C::MP; ++i) acc[i] = 0.0f;
+
+    for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
+        float f[NN][F];
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int vi = c0 + j * LPP + gl;
+                if (vi < nvec) {
+                    ldv<W>(rowp[a], vi, &f[a][j * W]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) f[a][j * W + k] = 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+            if (a % NR != 0) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) f[a][k] *= rs[a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+#pragma unroll
+            for (int b = a; b < NN; ++b) {
+                float s = acc[a * NN + b];
+#pragma unroll
+                for (int k = 0; k < F; ++k) s = fmaf(f[a][k], f[b][k], s);
+                acc[a * NN + b] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 1; a < NN; ++a) {
+#pragma unroll
+        for (int b = 0; b < a; ++b) acc[a * NN + b] = acc[b * NN + a];
+    }
+
+    Halve<C::MP, LPP / 2>::run(acc, gl);
+
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < C::PER; ++k) {
+            const int idx = gl * C::PER + k;
+            if (idx < C::NG) {
+                float x = acc[k];
+                if (do_scale) {
+                    x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (:127)
+                    x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
+                }
+                if (!idok) x = __builtin_nanf("");
+                out[idx] = x;
+            }
+        }
+    }
+}
+
+template <int LPP, int VPL, int W, int L>
+__global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_t* __restrict__ u,
+                                                     const int64_t* __restrict__ v, int64_t n, double now,
+                                                     double lambda, uint32_t flags, float* __restrict__ out) {
+    constexpr int GPB = BLOCK / LPP;
+    constexpr int NG = GramCfg<LPP, L>::NG;
+    const int gl = threadIdx.x % LPP;
+    const int g = threadIdx.x / LPP;
+    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
+        const int64_t p = base + g;
+        const bool valid = p < n;
+        const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
+        gram_pair<LPP, VPL, W, L>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * NG, gl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// update of ONE target node by one group of LPP lanes (models/TPNet.py:90-96, all layers at once):
+//   new[i][u] = old[i][u] * g_u^i  +  sum_j  w_j * ( P[i-1][partner_j] * g_partner^(i-1) ),   i = 1..L
+// contributions are summed in sorted order = the reference's index order (src-side edges, then dst-side edges).
+// All reads hit pre-launch copies; the result goes to the other copy.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int VPL, int W, int L>
+__device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t* __restrict__ s_partner,
+                                            const float* __restrict__ s_coef, int32_t u, uint32_t j0, uint32_t cnt,
+                                            bool valid, uint32_t bid, double t_last, double lambda, int gl) {
+    constexpr int F = VPL * W;
+    constexpr int U = 4;  // contributions in flight per group
+    const int d = S.d;
+    const int nvec = d / W;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    if (!valid) { u = 0; cnt = 0; }
+
+    const MetaView mu = read_meta(meta, u, bid, t_last, lambda);
+    const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
+    float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
+    float gu[L];
+    gu[0] = mu.g;
+#pragma unroll
+    for (int i = 1; i < L; ++i) gu[i] = gu[i - 1] * mu.g;
+
+    for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
+        float acc[L][F];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int vi = c0 + j * LPP + gl;
+                if (valid && vi < nvec) {
+                    ldv<W>(qold + (int64_t)i * d, vi, &acc[i][j * W]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) acc[i][j * W + k] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < F; ++k) acc[i][k] *= gu[i];
+        }
+
+        for (uint32_t jj = 0; jj < cnt; jj += U) {
+            int32_t pv[U];
+            float w[U];
+            bool ok[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                ok[k] = jj + k < cnt;
+                pv[k] = ok[k] ? s_partner[j0 + jj + k] : 0;
+                w[k] = ok[k] ? s_coef[j0 + jj + k] : 0.0f;
+            }
+            MetaView mv[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) mv[k] = read_meta(meta, pv[k], bid, t_last, lambda);
+            float r[U][L][F];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float* r0 = S.p0 + (int64_t)pv[k] * d;
+                const float* rq = S.q + ((int64_t)mv[k].copy * S.N + pv[k]) * ((int64_t)L * d);
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const float* rp = (i == 0) ? r0 : rq + (int64_t)(i - 1) * d;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        const int vi = c0 + j * LPP + gl;
+                        if (ok[k] && vi < nvec) {
+                            ldv<W>(rp, vi, &r[k][i][j * W]);
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < W; ++x) r[k][i][j * W + x] = 0.0f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (ok[k]) {
+                    float gi = 1.0f;
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+#pragma unroll
+                        for (int x = 0; x < F; ++x) {
+                            const float m = (r[k][i][x] * gi) * w[k];  // (P[i-1][partner] decayed) * time weight (:91-92)
+                            acc[i][x] = acc[i][x] + m;                 // scatter-add, in index order (:93-96)
+                        }
+                        gi *= mv[k].g;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int vi = c0 + j * LPP + gl;
+                if (valid && vi < nvec) stv<W>(qnew + (int64_t)i * d, vi, &acc[i][j * W]);
+            }
+        }
+    }
+    if (valid && gl == 0) {
+        meta[u].tref[mu.copy ^ 1] = t_last;
+        meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused per-batch step: readout (src,dst) and (src,neg) on the pre-batch state + update, ONE launch.
+// Work index space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the
+// batch's update items.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int VPL, int W, int L>
+__global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, double lambda,
+                                                uint32_t bid, uint32_t flags) {
+    constexpr int GPB = BLOCK / LPP;
+    constexpr int GPW = 64 / LPP;
+    constexpr int NG = GramCfg<LPP, L>::NG;
+    const BatchDesc D = p.desc[b];
+    const int gl = threadIdx.x % LPP;
+    const int g = threadIdx.x / LPP;
+    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    const int64_t ne = D.ne;
+    const int64_t npos = ((flags & ROLE_READOUT) && a.out_pos) ? ne : 0;
+    const int64_t nneg = ((flags & ROLE_READOUT) && a.out_neg) ? ne : 0;
+    const int64_t npairs = npos + nneg;
+    const int64_t RP = (npairs + GPW - 1) / GPW * GPW;
+    const int64_t nitems = (flags & ROLE_UPDATE) ? (int64_t)D.n_light : 0;
+    const int64_t total = RP + nitems;
+    const Item* items = p.light + 2 * D.e0;
+
+    for (int64_t base = (int64_t)blockIdx.x * GPB; base < total; base += (int64_t)gridDim.x * GPB) {
+        const int64_t w = base + g;
+        const int64_t wave0 = base + (g / GPW) * GPW;  // first work index of this wave: decides the wave's role
+        if (wave0 < RP) {
+            const bool valid = w < npairs;
+            int64_t e = 0, u = 0, v = 0;
+            float* out = nullptr;
+            if (valid) {
+                if (w < npos) {
+                    e = D.e0 + w;
+                    v = a.dst[e];
+                    out = a.out_pos + e * NG;
+                } else {
+                    e = D.e0 + (w - npos);
+                    v = a.neg[e];
+                    out = a.out_neg + e * NG;
+                }
+                u = a.src[e];
+            }
+            gram_pair<LPP, VPL, W, L>(S, u, v, valid, bid, D.now, lambda, do_scale, out, gl);
+        } else {
+            const int64_t it = w - RP;
+            const bool valid = it < nitems;
+            Item I;
+            I.j0 = 0; I.cnt = 0;
+            int32_t u = 0;
+            if (valid) {
+                I = items[it];
+                u = p.s_target[I.j0];
+            }
+            update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, u, I.j0, I.cnt, valid, bid, D.t_last, lambda, gl);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dense passes
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_state_init(tpnet_state S, double t0) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nq = 2 * S.N * (int64_t)S.L * S.d;
+    for (int64_t i = tid; i < nq; i += stride) S.q[i] = 0.0f;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    for (int64_t n = tid; n < S.N; n += stride) {
+        NodeMeta m;
+        m.ver = 0; m.pad0 = 0; m.tref[0] = t0; m.tref[1] = t0; m.pad1 = 0;
+        meta[n] = m;
+    }
+    if (tid < 4) S.err[tid] = 0;
+}
+
+struct LayerPtrs {
+    float* p[TPNET_MAX_LAYERS];
+};
+
+// layers (row-major [N][d] each) -> copy 0 bundles; meta = {0, now}
+__global__ void k_import(tpnet_state S, LayerPtrs lp, double now) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t d = S.d, L = S.L;
+    const int64_t tot = S.N * L * d;
+    for (int64_t x = tid; x < tot; x += stride) {
+        const int64_t n = x / (L * d);
+        const int64_t r = x - n * (L * d);
+        const int64_t i = r / d, k = r - i * d;
+        S.q[x] = lp.p[i][n * d + k];
+    }
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    for (int64_t n = tid; n < S.N; n += stride) {
+        NodeMeta m;
+        m.ver = 0; m.pad0 = 0; m.tref[0] = now; m.tref[1] = now; m.pad1 = 0;
+        meta[n] = m;
+    }
+}
+
+// current bundles with the pending decay applied -> layers
+__global__ void k_export(tpnet_state S, LayerPtrs lp, double now, double lambda) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t d = S.d, L = S.L;
+    const int64_t tot = S.N * L * d;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    for (int64_t x = tid; x < tot; x += stride) {
+        const int64_t n = x / (L * d);
+        const int64_t r = x - n * (L * d);
+        const int64_t i = r / d, k = r - i * d;
+        const MetaView m = read_meta(meta, n, READER_BID, now, lambda);
+        float g = m.g;
+        for (int64_t z = 0; z < i; ++z) g *= m.g;
+        lp.p[i][n * d + k] = S.q[((int64_t)m.copy * S.N) * (L * d) + x] * g;
+    }
+}
+
+struct DecayFactors {
+    float f[TPNET_MAX_LAYERS];
+};
+
+// eager dense decay (models/TPNet.py:83-85): current copy of every row *= f[i]; tref = t_new.
+// One block-stride loop over nodes; LPP-agnostic (one thread per element of the bundle).
+__global__ void k_decay(tpnet_state S, DecayFactors df, double t_new) {
+    const int64_t d = S.d, L = S.L;
+    const int64_t per = L * d;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    for (int64_t n = blockIdx.x; n < S.N; n += gridDim.x) {
+        const uint32_t ver = meta[n].ver;
+        const int c = ver & 1;
+        float* qb = S.q + ((int64_t)c * S.N + n) * per;
+        for (int64_t r = threadIdx.x; r < per; r += blockDim.x) {
+            const int64_t i = r / d;
+            qb[r] = qb[r] * df.f[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) meta[n].tref[c] = t_new;
+    }
+}
+
+__global__ void k_decay_desc(tpnet_state S, const BatchDesc* __restrict__ desc, int64_t b) {
+    const int64_t d = S.d, L = S.L;
+    const int64_t per = L * d;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    const float* __restrict__ decay = desc[b].decay;  // indexed from memory (a private copy would be demoted to LDS)
+    const double t_last = desc[b].t_last;
+    for (int64_t n = blockIdx.x; n < S.N; n += gridDim.x) {
+        const uint32_t ver = meta[n].ver;
+        const int c = ver & 1;
+        float* qb = S.q + ((int64_t)c * S.N + n) * per;
+        for (int64_t r = threadIdx.x; r < per; r += blockDim.x) {
+            const int64_t i = r / d;
+            qb[r] = qb[r] * decay[i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) meta[n].tref[c] = t_last;
+    }
+}
+
+// get_random_projections (models/TPNet.py:101-110): out[(i*n + k)*d + :] = P[i][ids[k]]
+__global__ void k_gather_rows(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now, double lambda,
+                              float* __restrict__ out) {
+    const int64_t d = S.d, L = S.L;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        int64_t id = ids[k];
+        const bool ok = (uint64_t)id < (uint64_t)S.N;
+        if (!ok) {
+            if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+            id = 0;
+        }
+        const MetaView m = read_meta(meta, id, READER_BID, now, lambda);
+        const float* qb = S.q + ((int64_t)m.copy * S.N + id) * (L * d);
+        for (int64_t r = threadIdx.x; r < (L + 1) * d; r += blockDim.x) {
+            const int64_t i = r / d, c = r - i * d;
+            float x;
+            if (i == 0) {
+                x = S.p0[id * d + c];
+            } else {
+                float g = m.g;
+                for (int64_t z = 1; z < i; ++z) g *= m.g;
+                x = qb[(i - 1) * d + c] * g;
+            }
+            out[(i * n + k) * d + c] = ok ? x : __builtin_nanf("");
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t work_items, int per_block, int cap) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+int launch_state_init(const tpnet_state& st, double t0, hipStream_t s) {
+    const int64_t nq = 2 * st.N * (int64_t)st.L * st.d;
+    hipLaunchKernelGGL(k_state_init, dim3(grid_for(nq, 256 * 4, 4096)), dim3(256), 0, s, st, t0);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_import(const tpnet_state& st, const float* const* layers, double now, hipStream_t s) {
+    LayerPtrs lp{};
+    for (int i = 0; i < st.L; ++i) lp.p[i] = const_cast<float*>(layers[i]);
+    hipLaunchKernelGGL(k_import, dim3(grid_for(st.N * (int64_t)st.L * st.d, 256 * 4, 4096)), dim3(256), 0, s, st, lp,
+                       now);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_export(const tpnet_state& st, float* const* layers, double now, double lambda, hipStream_t s) {
+    LayerPtrs lp{};
+    for (int i = 0; i < st.L; ++i) lp.p[i] = layers[i];
+    hipLaunchKernelGGL(k_export, dim3(grid_for(st.N * (int64_t)st.L * st.d, 256 * 4, 4096)), dim3(256), 0, s, st, lp,
+                       now, lambda);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_decay(const tpnet_state& st, const float* factors_host, double t_new, hipStream_t s) {
+    DecayFactors df{};
+    for (int i = 0; i < st.L; ++i) df.f[i] = factors_host[i];
+    hipLaunchKernelGGL(k_decay, dim3(grid_for(st.N, 1, 8192)), dim3(256), 0, s, st, df, t_new);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_decay_desc(const tpnet_state& st, const Plan& p, int64_t b, hipStream_t s) {
+    hipLaunchKernelGGL(k_decay_desc, dim3(grid_for(st.N, 1, 8192)), dim3(256), 0, s, st, p.desc, b);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
+                       hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n, 1, 8192)), dim3(256), 0, s, st, ids, n, now, lambda, out);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+// dispatch over (geometry, L)
+#define TPNET_DISPATCH_L(LPP_, VPL_, W_, CALL)                                  \
+    switch (st.L) {                                                             \
+        case 1: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 1; CALL; } break; \
+        case 2: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 2; CALL; } break; \
+        case 3: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 3; CALL; } break; \
+        case 4: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 4; CALL; } break; \
+        default: return TPNET_ERR_BAD_ARG;                                      \
+    }
+#define TPNET_DISPATCH(CALL)                                                    \
+    do {                                                                        \
+        const Geom gm = pick_geom(st.d);                                        \
+        if (gm.w == 1) { TPNET_DISPATCH_L(64, 1, 1, CALL) }                     \
+        else if (gm.lpp == 16) { TPNET_DISPATCH_L(16, 1, 4, CALL) }             \
+        else if (gm.lpp == 32) { TPNET_DISPATCH_L(32, 1, 4, CALL) }             \
+        else if (gm.vpl == 1) { TPNET_DISPATCH_L(64, 1, 4, CALL) }              \
+        else { TPNET_DISPATCH_L(64, 2, 4, CALL) }                               \
+    } while (0)
+
+int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
+                     uint32_t flags, float* out, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    TPNET_DISPATCH(({
+        const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
+        hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, u, v, n, now, lambda,
+                           flags, out);
+    }));
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int32_t ne, double lambda,
+                uint32_t launch_id, uint32_t flags, hipStream_t s) {
+    // upper bound of the work indices: 2*ne readout pairs + at most 2*ne distinct targets
+    const int64_t work = 4 * (int64_t)ne + 8;
+    TPNET_DISPATCH(({
+        const int grid = grid_for(work, BLOCK / LPP, 256 * 8);
+        hipLaunchKernelGGL((k_step<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b, lambda, launch_id,
+                           flags);
+    }));
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+}  // namespace tpnet

@@ -1,0 +1,206 @@
+// Batch planning for the update: group the 2*B (target <- partner) contributions of every batch by target node,
+// keeping the reference's summation order inside a target (models/TPNet.py:93-96: all src-side scatter-adds in edge
+// order, then all dst-side ones).  Done for a whole chunk of the stream at once (one stable device radix sort over
+// (batch, target) keys), so the per-batch step kernels find ready-made item lists and the cost is amortised.
+#include "tpnet_common.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace tpnet {
+
+static constexpr uint32_t HEAVY_THRESHOLD = 0xFFFFFFFFu;  // contributions per target above which an item is "heavy"
+
+static inline int ceil_log2_u64(uint64_t x) {
+    int b = 0;
+    while (b < 63 && (1ull << b) < x) ++b;
+    return b;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t sort_tmp_bytes(size_t n) {
+    size_t bytes = 0;
+    uint64_t* kn = nullptr;
+    uint32_t* vn = nullptr;
+    // size query only: no kernel is launched
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, n, 0, 64, (hipStream_t)0, false);
+    return bytes;
+}
+
+size_t plan_bytes(int64_t max_edges, int64_t batch) {
+    if (max_edges < 1) max_edges = 1;
+    if (batch < 1) batch = 1;
+    const size_t nc = 2 * (size_t)max_edges;
+    const size_t nb = (size_t)((max_edges + batch - 1) / batch);
+    size_t tot = 0;
+    tot += align_up(nc * sizeof(uint64_t), 256) * 2;   // keys in/out
+    tot += align_up(nc * sizeof(uint32_t), 256) * 2;   // vals in/out
+    tot += align_up(nc * sizeof(int32_t), 256) * 2;    // s_partner, s_target
+    tot += align_up(nc * sizeof(float), 256);          // s_coef
+    tot += align_up(nc * sizeof(Item), 256) * 2;       // light, heavy
+    tot += align_up(nb * sizeof(BatchDesc), 256);
+    tot += align_up(sort_tmp_bytes(nc), 256) + 256;
+    return tot;
+}
+
+int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out) {
+    if (!ws) return TPNET_ERR_WORKSPACE;
+    const size_t nc = 2 * (size_t)Ec;
+    const size_t nb = (size_t)((Ec + batch - 1) / batch);
+    char* p = reinterpret_cast<char*>(ws);
+    char* const end = p + ws_bytes;
+    p = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(p), 256));
+    auto take = [&](size_t bytes) -> void* {
+        void* r = p;
+        p += align_up(bytes, 256);
+        return r;
+    };
+    out->keys_in = (uint64_t*)take(nc * sizeof(uint64_t));
+    out->keys_out = (uint64_t*)take(nc * sizeof(uint64_t));
+    out->vals_in = (uint32_t*)take(nc * sizeof(uint32_t));
+    out->vals_out = (uint32_t*)take(nc * sizeof(uint32_t));
+    out->s_partner = (int32_t*)take(nc * sizeof(int32_t));
+    out->s_target = (int32_t*)take(nc * sizeof(int32_t));
+    out->s_coef = (float*)take(nc * sizeof(float));
+    out->light = (Item*)take(nc * sizeof(Item));
+    out->heavy = (Item*)take(nc * sizeof(Item));
+    out->desc = (BatchDesc*)take(nb * sizeof(BatchDesc));
+    out->sort_tmp_bytes = sort_tmp_bytes(nc);
+    out->sort_tmp = take(out->sort_tmp_bytes);
+    if (p > end) return TPNET_ERR_WORKSPACE;
+    return TPNET_OK;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------
+__global__ void k_batch_desc(BatchDesc* __restrict__ desc, const double* __restrict__ t, int64_t Ec, int64_t B,
+                             int64_t nb, double now_time, const double* __restrict__ t_prev, double lambda, int L) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    BatchDesc D;
+    D.e0 = b * B;
+    const int64_t ne = (Ec - D.e0 < B) ? (Ec - D.e0) : B;
+    D.ne = (int32_t)ne;
+    D.pad = 0;
+    D.t_last = t[D.e0 + ne - 1];                       // next_time = node_interact_times[-1]   (TPNet.py:76)
+    D.now = (b == 0) ? (t_prev ? *t_prev : now_time) : t[D.e0 - 1];         // clock left by the previous batch       (TPNet.py:99)
+    D.n_light = 0;
+    D.n_heavy = 0;
+    const double g = exp(-lambda * (D.t_last - D.now));  // TPNet.py:84-85, f64 then rounded to f32 once
+    double gi = 1.0;
+    for (int i = 0; i < TPNET_MAX_LAYERS; ++i) {
+        gi *= g;
+        D.decay[i] = (i < L) ? (float)gi : 1.0f;
+    }
+    desc[b] = D;
+}
+
+// contribution j of the chunk: batch b = j / (2B); inside the batch the first ne are the src-side scatter-adds
+// (target src[e] <- partner dst[e]), the next ne the dst-side ones.
+__device__ __forceinline__ void decode(int64_t j, int64_t B, int64_t Ec, int64_t& b, int& side, int64_t& e) {
+    b = j / (2 * B);
+    const int64_t e0 = b * B;
+    const int64_t ne = (Ec - e0 < B) ? (Ec - e0) : B;
+    const int64_t r = j - 2 * e0;
+    side = (r >= ne) ? 1 : 0;
+    e = e0 + (side ? r - ne : r);
+}
+
+__global__ void k_make_keys(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                            const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t Ec, int64_t B,
+                            int64_t N, int node_bits, uint32_t* err) {
+    const int64_t nc = 2 * Ec;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b, e;
+        int side;
+        decode(j, B, Ec, b, side, e);
+        int64_t tgt = side ? dst[e] : src[e];
+        if ((uint64_t)tgt >= (uint64_t)N) tgt = 0;  // counted (once per edge) in k_finish
+        keys[j] = ((uint64_t)b << node_bits) | (uint64_t)tgt;
+        vals[j] = (uint32_t)j;
+    }
+}
+
+__global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                         const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N, int node_bits, double lambda,
+                         uint32_t heavy_threshold, uint32_t* err) {
+    const int64_t nc = 2 * Ec;
+    const uint64_t node_mask = (1ull << node_bits) - 1;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = p.keys_out[j];
+        const uint32_t val = p.vals_out[j];
+        int64_t b, e;
+        int side;
+        decode((int64_t)val, B, Ec, b, side, e);
+        const int64_t s = src[e], dd = dst[e];
+        const bool ok = (uint64_t)s < (uint64_t)N && (uint64_t)dd < (uint64_t)N;
+        if (!ok && side == 0) atomicAdd(err, 1u);
+        const int64_t partner = side ? s : dd;
+        const double t_last = p.desc[b].t_last;
+        // time weight, with the reference's casts: absolute times rounded to f32 BEFORE the subtraction, f32 lambda
+        // (models/TPNet.py:77-78)
+        const float x = (float)t_last - (float)t[e];
+        const float w = expf((float)(-lambda) * x);
+        p.s_partner[j] = ok ? (int32_t)partner : 0;
+        p.s_coef[j] = ok ? w : 0.0f;
+        p.s_target[j] = (int32_t)(key & node_mask);
+
+        const int64_t c0 = 2 * b * B;
+        const int64_t ne = (Ec - b * B < B) ? (Ec - b * B) : B;
+        const int64_t cend = c0 + 2 * ne;
+        const bool head = (j == c0) || (p.keys_out[j - 1] != key);
+        if (head) {
+            // run length by galloping + binary search on the sorted keys
+            int64_t lo = j, hi, step = 1;
+            for (;;) {
+                const int64_t nx = lo + step;
+                if (nx >= cend) { hi = cend; break; }
+                if (p.keys_out[nx] != key) { hi = nx; break; }
+                lo = nx;
+                step <<= 1;
+            }
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (p.keys_out[mid] == key) lo = mid; else hi = mid;
+            }
+            Item it;
+            it.j0 = (uint32_t)j;
+            it.cnt = (uint32_t)(hi - j);
+            if (it.cnt > heavy_threshold) {
+                const uint32_t idx = atomicAdd(&p.desc[b].n_heavy, 1u);
+                p.heavy[c0 + idx] = it;
+            } else {
+                const uint32_t idx = atomicAdd(&p.desc[b].n_light, 1u);
+                p.light[c0 + idx] = it;
+            }
+        }
+    }
+}
+
+int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t,
+               int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda, uint32_t flags,
+               hipStream_t s) {
+    const int64_t nb = (Ec + batch - 1) / batch;
+    const int64_t nc = 2 * Ec;
+    const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
+    const int batch_bits = ceil_log2_u64((uint64_t)nb) < 1 ? 1 : ceil_log2_u64((uint64_t)nb);
+    if (node_bits + batch_bits > 64) return TPNET_ERR_BAD_ARG;
+
+    hipLaunchKernelGGL(k_batch_desc, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, p.desc, t, Ec, batch, nb,
+                       now_time, t_prev_dev, lambda, (int)st.L);
+    int grid = (int)((nc + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_make_keys, dim3(grid), dim3(256), 0, s, p.keys_in, p.vals_in, src, dst, Ec, batch, st.N,
+                       node_bits, st.err);
+    TPNET_HIP_TRY(hipGetLastError());
+    size_t tmp = p.sort_tmp_bytes;
+    TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
+                                            (size_t)nc, 0u, (unsigned)(node_bits + batch_bits), s, false));
+    const uint32_t thr = (flags & TPNET_FLAG_SEQUENTIAL) ? 0xFFFFFFFFu : HEAVY_THRESHOLD;
+    hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, s, p, src, dst, t, Ec, batch, st.N, node_bits, lambda, thr,
+                       st.err);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+}  // namespace tpnet

@@ -1,0 +1,111 @@
+// Shared declarations of the gfx950 implementation (internal; the public ABI is include/tpnet_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tpnet_hip.h"
+
+namespace tpnet {
+
+// ---- per-node record, 32 bytes: {ver, pad, tref[2], pad} ---------------------------------------------------
+// tref is kept PER COPY: a launch that rewrites node n writes tref[new copy] and ver only, so a concurrent reader
+// of the same launch (which must see the pre-batch row) finds tref[old copy] untouched whatever ver it observes.
+struct NodeMeta {
+    uint32_t ver;   // (launch_id << 1) | current copy
+    uint32_t pad0;
+    double tref[2];
+    uint64_t pad1;
+};
+static_assert(sizeof(NodeMeta) == 32, "NodeMeta must be 32 bytes");
+
+// Per-batch descriptor written by the plan kernels, read by the step kernel.
+struct BatchDesc {
+    int64_t e0;        // first edge of the batch
+    int32_t ne;        // edges in the batch
+    int32_t pad;
+    double now;        // module clock before this batch's update (readout time)
+    double t_last;     // t[e0+ne-1]: clock after the update (models/TPNet.py:76,99)
+    uint32_t n_light;  // number of light items (targets whose contributions one wave group sums)
+    uint32_t n_heavy;  // number of heavy items (one workgroup each)
+    float decay[TPNET_MAX_LAYERS];  // eager mode: f32(exp(-lambda*(t_last-now))^i), i = 1..L
+};
+
+// One update item: a distinct target node of the batch and its run of contributions in the sorted arrays.
+struct Item {
+    uint32_t j0;   // first contribution (index into the sorted arrays)
+    uint32_t cnt;  // number of contributions
+};
+
+// Views into the caller's workspace for one chunk of the stream.
+struct Plan {
+    uint64_t* keys_in;
+    uint64_t* keys_out;
+    uint32_t* vals_in;
+    uint32_t* vals_out;
+    int32_t* s_partner;   // [2*Ec] partner node of each contribution, sorted by (batch, target, side, edge)
+    float* s_coef;        // [2*Ec] time weight w_e = exp(-lambda (t_last - t_e))  (models/TPNet.py:78)
+    int32_t* s_target;    // [2*Ec]
+    Item* light;          // [2*Ec] batch b owns [2*e0(b), 2*e0(b)+n_light)
+    Item* heavy;          // [2*Ec]
+    BatchDesc* desc;      // [nb]
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+};
+
+struct StreamArgs {
+    const int64_t* src;
+    const int64_t* dst;
+    const int64_t* neg;
+    const double* t;
+    float* out_pos;
+    float* out_neg;
+};
+
+// Launch geometry of the fast paths: LPP lanes cooperate on one row (one pair / one target), each lane owning VPL
+// vectors of W floats per column chunk.
+struct Geom {
+    int lpp, vpl, w;
+};
+inline Geom pick_geom(int d) {
+    if (d % 4 != 0) return {64, 1, 1};
+    const int nvec = d / 4;
+    if (nvec <= 16) return {16, 1, 4};
+    if (nvec <= 32) return {32, 1, 4};
+    if (nvec <= 64) return {64, 1, 4};
+    return {64, 2, 4};
+}
+
+// host-side launchers implemented in kernels.hip / plan.hip
+int launch_state_init(const tpnet_state& st, double t0, hipStream_t s);
+int launch_import(const tpnet_state& st, const float* const* layers_dev, double now, hipStream_t s);
+int launch_export(const tpnet_state& st, float* const* layers_dev, double now, double lambda, hipStream_t s);
+int launch_decay(const tpnet_state& st, const float* factors_host, double t_new, hipStream_t s);
+int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
+                       hipStream_t s);
+int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
+                     uint32_t flags, float* out, hipStream_t s);
+// One launch: readout of batch b (if out_pos/out_neg) on the pre-batch state + update of batch b.
+int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int32_t ne, double lambda,
+                uint32_t launch_id, uint32_t flags, hipStream_t s);
+int launch_decay_desc(const tpnet_state& st, const Plan& p, int64_t b, hipStream_t s);
+
+size_t plan_bytes(int64_t max_edges, int64_t batch);
+int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out);
+int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t,
+               int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda, uint32_t flags,
+               hipStream_t s);
+
+// internal flag bits of launch_step (above the public TPNET_FLAG_* bits)
+static constexpr uint32_t ROLE_READOUT = 1u << 16;
+static constexpr uint32_t ROLE_UPDATE = 1u << 17;
+
+extern thread_local int g_last_hip_error;
+#define TPNET_HIP_TRY(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) {                               \
+            tpnet::g_last_hip_error = (int)_e;                \
+            return TPNET_ERR_HIP;                             \
+        }                                                     \
+    } while (0)
+
+}  // namespace tpnet

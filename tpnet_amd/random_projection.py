@@ -1,0 +1,357 @@
+"""Drop-in `RandomProjectionModule` backed by the gfx950 HIP kernels (C ABI: include/tpnet_hip.h).
+
+Mirrors the reference operator interface of /root/reference/models/TPNet.py:9-157 -- same constructor
+arguments, method names, argument meaning, attributes and state-dict keys -- so that the reference's callers
+(train_link_prediction.py:137-145,248,372,403-494; evaluate_models_utils.py:183; models/TPNet.py:313;
+models/modules.py:112) work unchanged.  There is no CPU fallback: every compute method needs the HIP library
+and a GPU-resident module, and raises otherwise.
+
+How the state is held:
+  * `random_projections[0]` (P[0]) IS the kernels' layer-0 buffer (no copy).
+  * layers 1..L live in the engine's own layout (`_q`: ping-pong per-node bundles + `_meta`), where the
+    reference's dense per-batch decay (TPNet.py:83-85) is carried lazily per row.  The `random_projections[1..L]`
+    Parameters are materialised from it (one export pass, decay applied) whenever somebody looks at them
+    (attribute access, state_dict(), backup, .to()), and imported back when somebody writes them
+    (reload, load_state_dict, .to(), direct `.data` assignment -- detected through data_ptr/_version).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_MAX_LAUNCH_ID = 0x7FFFFFFF - (1 << 24)
+
+
+class RandomProjectionModule(nn.Module):
+    def __init__(self, node_num: int, edge_num: int, dim_factor: int, num_layer: int, time_decay_weight: float,
+                 device: str, use_matrix: bool, beginning_time: np.float64, not_scale: bool, enforce_dim: int,
+                 exact: bool = False):
+        """Arguments as in the reference (models/TPNet.py:10-26).  `exact=True` (extension, default off) selects
+        the reference's literal arithmetic: an eager dense decay of every row per update (TPNet.py:83-85) and
+        strictly index-ordered sums -- used by the parity tests; the default carries the decay lazily per row."""
+        super().__init__()
+        if not 1 <= num_layer <= _lib.TPNET_MAX_LAYERS:
+            raise ValueError(f"num_layer must be in 1..{_lib.TPNET_MAX_LAYERS} (got {num_layer})")
+        self.node_num = node_num
+        self.edge_num = edge_num
+        if enforce_dim != -1:
+            self.dim = enforce_dim
+        else:
+            self.dim = min(int(math.log(self.edge_num * 2)) * dim_factor, node_num)
+        self.num_layer = num_layer
+        self.time_decay_weight = time_decay_weight
+        self.begging_time = nn.Parameter(torch.tensor(beginning_time), requires_grad=False)
+        self.now_time = nn.Parameter(torch.tensor(beginning_time), requires_grad=False)
+        self.device = device
+        self.random_projections = nn.ParameterList()
+        self.use_matrix = use_matrix
+        self.node_feature_dim = 128
+        self.not_scale = not_scale
+        self.exact = bool(exact)
+        if self.use_matrix:
+            self.dim = self.node_num
+            for i in range(self.num_layer + 1):
+                if i == 0:
+                    self.random_projections.append(nn.Parameter(torch.eye(self.node_num), requires_grad=False))
+                else:
+                    self.random_projections.append(
+                        nn.Parameter(torch.zeros_like(self.random_projections[i - 1]), requires_grad=False))
+        else:
+            for i in range(self.num_layer + 1):
+                if i == 0:
+                    self.random_projections.append(
+                        nn.Parameter(torch.normal(0, 1 / math.sqrt(self.dim), (self.node_num, self.dim)),
+                                     requires_grad=False))
+                else:
+                    self.random_projections.append(
+                        nn.Parameter(torch.zeros_like(self.random_projections[i - 1]), requires_grad=False))
+        self.pair_wise_feature_dim = (2 * self.num_layer + 2) ** 2
+        self.mlp = nn.Sequential(nn.Linear(self.pair_wise_feature_dim, self.pair_wise_feature_dim * 4), nn.ReLU(),
+                                 nn.Linear(self.pair_wise_feature_dim * 4, self.pair_wise_feature_dim))
+        # ---- engine side (plain attributes: not parameters/buffers, so the state-dict keys match the reference)
+        self._eng = None                      # dict of device tensors, allocated on first use
+        self._engine_valid = False            # engine holds the truth for layers 1..L
+        self._params_valid = True             # the Parameters hold the truth for layers 1..L
+        self._param_sig = None                # (data_ptr, _version) of the layer Parameters at the last sync
+        self._now_host = float(beginning_time)
+        self._launch_id = 1
+
+    # ------------------------------------------------------------------------------------------------------
+    # plumbing
+    # ------------------------------------------------------------------------------------------------------
+    def _plist(self):
+        return self._modules["random_projections"]
+
+    def __getattr__(self, name):
+        # external readers of `random_projections` / `now_time` see the reference's eager values
+        if name == "random_projections" and "_modules" in self.__dict__ and not self.__dict__.get("_params_valid", True):
+            self._materialize()
+        return super().__getattr__(name)
+
+    def _sig(self):
+        return tuple((p.data_ptr(), p._version, p.device) for p in self._plist())
+
+    def _dev(self) -> torch.device:
+        dev = self._plist()[0].device
+        if dev.type != "cuda":
+            raise _lib.TPNetHipError(
+                "RandomProjectionModule (tpnet_amd) computes only on a GPU: move the module to a cuda device "
+                "first (the reference script does this in utils/utils.py:43); there is no CPU fallback")
+        return dev
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self._dev()).cuda_stream)
+
+    def _engine(self):
+        """Allocate the engine buffers on the Parameters' device (once per device) and return them."""
+        dev = self._dev()
+        lib = _lib.load()
+        if self._eng is None or self._eng["dev"] != dev:
+            N, d, L = self.node_num, self.dim, self.num_layer
+            with torch.cuda.device(dev):
+                q = torch.empty(lib.tpnet_q_bytes(N, d, L) // 4, dtype=torch.float32, device=dev)
+                meta = torch.empty(lib.tpnet_meta_bytes(N), dtype=torch.uint8, device=dev)
+                err = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._eng = dict(dev=dev, q=q, meta=meta, err=err, ws=None)
+            self._engine_valid = False
+        return self._eng
+
+    def _state(self) -> _lib.State:
+        eng = self._engine()
+        p0 = self._plist()[0]
+        if not p0.is_contiguous() or p0.dtype != torch.float32:
+            raise _lib.TPNetHipError("random_projections[0] must be a contiguous float32 tensor")
+        return _lib.State(p0=p0.data_ptr(), q=eng["q"].data_ptr(), meta=eng["meta"].data_ptr(), N=self.node_num,
+                          d=self.dim, L=self.num_layer, err=eng["err"].data_ptr())
+
+    def _workspace(self, max_edges: int, batch: int):
+        eng = self._engine()
+        need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
+        if eng["ws"] is None or eng["ws"].numel() < need:
+            eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
+        return eng["ws"]
+
+    def _layer_ptrs(self):
+        arr = (C.c_void_p * self.num_layer)()
+        for i in range(1, self.num_layer + 1):
+            p = self._plist()[i]
+            if not p.is_contiguous() or p.dtype != torch.float32 or p.device != self._dev():
+                raise _lib.TPNetHipError(f"random_projections[{i}] must be a contiguous float32 tensor on the GPU")
+            arr[i - 1] = p.data_ptr()
+        return arr
+
+    def _ensure_engine(self):
+        """Make the engine state current: import the Parameters if somebody wrote them since the last sync."""
+        self._engine()
+        if self._engine_valid and self._params_valid and self._param_sig != self._sig():
+            self._engine_valid = False          # Parameters were written behind our back (.data = ..., copy_, ...)
+        if not self._engine_valid:
+            if not self._params_valid:
+                raise _lib.TPNetHipError("internal error: neither the engine nor the Parameters hold the state")
+            self._now_host = float(self._parameters["now_time"].item())   # the Parameters are the truth here
+            st = self._state()
+            _lib.check(_lib.load().tpnet_import_layers(C.byref(st), self._layer_ptrs(), self._now_host, self._stream()),
+                       "import_layers")
+            self._engine_valid = True
+            self._param_sig = self._sig()
+            self._launch_id = 1
+
+    def _materialize(self):
+        """Write the eager matrices P[1..L] (decay applied) into the Parameters (in place)."""
+        if self._params_valid:
+            return
+        st = self._state()
+        _lib.check(_lib.load().tpnet_export_layers(C.byref(st), self._layer_ptrs(), self._now_host,
+                                                   float(self.time_decay_weight), self._stream()), "export_layers")
+        self._params_valid = True
+        self._param_sig = self._sig()
+
+    def _next_launch_ids(self, n: int) -> int:
+        if self._launch_id + n >= _MAX_LAUNCH_ID:       # consolidate: export + import resets every node's version
+            self._materialize()
+            self._engine_valid = False
+            self._ensure_engine()
+        first = self._launch_id
+        self._launch_id += n
+        return first
+
+    def _ids_to_device(self, ids, what):
+        ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int64)
+        if ids.ndim != 1:
+            raise ValueError(f"{what} must be one-dimensional")
+        if ids.size and (ids.min() < -self.node_num or ids.max() >= self.node_num):
+            raise IndexError(f"{what}: index out of range for {self.node_num} nodes")
+        if ids.size and ids.min() < 0:
+            ids = np.where(ids < 0, ids + self.node_num, ids)     # python-style negative ids, as ATen indexing
+        return torch.from_numpy(ids).to(self._dev())
+
+    # nn.Module hooks that read or write the Parameters wholesale ---------------------------------------------
+    def state_dict(self, *args, **kwargs):
+        self._materialize()
+        return super().state_dict(*args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._params_valid = True
+        self._engine_valid = False
+
+    def _apply(self, fn, *args, **kwargs):
+        if self._eng is not None and not self._params_valid:
+            self._materialize()
+        out = super()._apply(fn, *args, **kwargs)
+        self._params_valid = True
+        self._engine_valid = False
+        return out
+
+    # ------------------------------------------------------------------------------------------------------
+    # reference interface
+    # ------------------------------------------------------------------------------------------------------
+    def update(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, node_interact_times: np.ndarray):
+        """models/TPNet.py:67-99: decay to t[-1], then P[i][src] += w*P[i-1][dst]; P[i][dst] += w*P[i-1][src]
+        for i = L..1 on pre-batch values; now_time <- t[-1]."""
+        t = np.ascontiguousarray(np.asarray(node_interact_times), dtype=np.float64)
+        if t.size == 0:
+            raise IndexError("update() with an empty batch (the reference indexes node_interact_times[-1])")
+        if not (len(src_node_ids) == len(dst_node_ids) == len(t)):
+            raise ValueError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
+        self._ensure_engine()
+        lib = _lib.load()
+        src = self._ids_to_device(src_node_ids, "src_node_ids")
+        dst = self._ids_to_device(dst_node_ids, "dst_node_ids")
+        next_time = float(t[-1])
+        t_dev = torch.from_numpy(t).to(self._dev())
+        B = int(t.size)
+        st = self._state()
+        lam = float(self.time_decay_weight)
+        flags = 0
+        if self.exact:
+            # the factor exactly as the reference forms it: f64 numpy, rounded to f32 once (TPNet.py:84-85)
+            g = np.exp(-self.time_decay_weight * (np.float64(next_time) - np.float64(self._now_host)))
+            fac = (C.c_float * self.num_layer)(*[np.float32(np.power(g, i)) for i in range(1, self.num_layer + 1)])
+            _lib.check(lib.tpnet_decay(C.byref(st), fac, next_time, self._stream()), "decay")
+            flags |= _lib.FLAG_SEQUENTIAL
+        ws = self._workspace(B, B)
+        lid = self._next_launch_ids(1)
+        _lib.check(lib.tpnet_update(C.byref(st), src.data_ptr(), dst.data_ptr(), t_dev.data_ptr(), B, next_time,
+                                    self._now_host, lam, lid, flags, ws.data_ptr(), ws.numel(), self._stream()),
+                   "update")
+        self._now_host = next_time
+        self._params_valid = False
+        self._parameters["now_time"].data.fill_(next_time)
+
+    def get_random_projections(self, node_ids: np.ndarray):
+        """models/TPNet.py:101-110: [P[i][node_ids] for i in 0..L]."""
+        self._ensure_engine()
+        ids = self._ids_to_device(node_ids, "node_ids")
+        n = ids.numel()
+        out = torch.empty((self.num_layer + 1, n, self.dim), dtype=torch.float32, device=self._dev())
+        st = self._state()
+        _lib.check(_lib.load().tpnet_gather_rows(C.byref(st), ids.data_ptr(), n, self._now_host,
+                                                 float(self.time_decay_weight), out.data_ptr(), self._stream()),
+                   "gather_rows")
+        return [out[i] for i in range(self.num_layer + 1)]
+
+    def pair_gram(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray) -> torch.Tensor:
+        """The pairwise feature BEFORE self.mlp (models/TPNet.py:119-128): [n, (2L+2)^2] on the GPU."""
+        self._ensure_engine()
+        if len(src_node_ids) != len(dst_node_ids):
+            raise ValueError("src_node_ids and dst_node_ids must have the same length")
+        u = self._ids_to_device(src_node_ids, "src_node_ids")
+        v = self._ids_to_device(dst_node_ids, "dst_node_ids")
+        n = u.numel()
+        out = torch.empty((n, self.pair_wise_feature_dim), dtype=torch.float32, device=self._dev())
+        st = self._state()
+        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        _lib.check(_lib.load().tpnet_pair_gram(C.byref(st), u.data_ptr(), v.data_ptr(), n, self._now_host,
+                                               float(self.time_decay_weight), flags, out.data_ptr(), self._stream()),
+                   "pair_gram")
+        return out
+
+    def get_pair_wise_feature(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray):
+        """models/TPNet.py:112-129.  No gradient flows into the projections (requires_grad=False in the
+        reference, :49-62); self.mlp stays a trainable torch module."""
+        return self.mlp(self.pair_gram(src_node_ids, dst_node_ids))
+
+    def reset_random_projections(self):
+        """models/TPNet.py:131-139."""
+        for i in range(1, self.num_layer + 1):
+            nn.init.zeros_(self._plist()[i])
+        self._parameters["now_time"].data = self._parameters["begging_time"].clone()
+        if not self.use_matrix:
+            nn.init.normal_(self._plist()[0], mean=0, std=1 / math.sqrt(self.dim))
+        self._now_host = float(self._parameters["begging_time"].item())
+        self._params_valid = True
+        if self._plist()[0].device.type == "cuda":
+            st = self._state()
+            _lib.check(_lib.load().tpnet_state_init(C.byref(st), self._now_host, self._stream()), "state_init")
+            self._engine_valid = True
+            self._param_sig = self._sig()
+            self._launch_id = 1
+        else:
+            self._engine_valid = False
+
+    def backup_random_projections(self):
+        """models/TPNet.py:141-147: (now_time.clone(), [P[1..L] clones])."""
+        self._materialize()
+        return self._parameters["now_time"].clone(), [self._plist()[i].clone() for i in range(1, self.num_layer + 1)]
+
+    def reload_random_projections(self, random_projections):
+        """models/TPNet.py:149-157."""
+        now_time, layers = random_projections
+        self._parameters["now_time"].data = now_time.clone()
+        for i in range(1, self.num_layer + 1):
+            self._plist()[i].data = layers[i - 1].clone()
+        self._params_valid = True
+        self._engine_valid = False
+
+    # ------------------------------------------------------------------------------------------------------
+    # extension: device-resident edge stream (the reference's batch loop, train_link_prediction.py:253-373)
+    # ------------------------------------------------------------------------------------------------------
+    def run_stream(self, src: torch.Tensor, dst: torch.Tensor, neg, t: torch.Tensor, batch_size: int,
+                   want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None):
+        """For each chronological batch: pre-mlp pairwise features of (src,dst) and (src,neg) on the pre-batch
+        state, then update().  src/dst/neg: int64 [E] on the GPU, t: float64 [E] on the GPU.  Returns
+        (feat_pos, feat_neg) of shape [E, (2L+2)^2] (None where not requested).  `t_end` = t[-1] if the caller
+        already has it on the host (avoids one 8-byte device->host copy)."""
+        self._ensure_engine()
+        dev = self._dev()
+        E = int(src.numel())
+        for name, x, dt in (("src", src, torch.int64), ("dst", dst, torch.int64), ("t", t, torch.float64)):
+            if x.device != dev or x.dtype != dt or not x.is_contiguous() or x.numel() != E:
+                raise ValueError(f"run_stream: {name} must be a contiguous {dt} tensor of {E} elements on {dev}")
+        if neg is not None and (neg.device != dev or neg.dtype != torch.int64 or neg.numel() != E):
+            raise ValueError("run_stream: neg must be an int64 tensor of the same length on the same device")
+        want_neg = want_neg and neg is not None
+        NG = self.pair_wise_feature_dim
+        if want_pos and out_pos is None:
+            out_pos = torch.empty((E, NG), dtype=torch.float32, device=dev)
+        if want_neg and out_neg is None:
+            out_neg = torch.empty((E, NG), dtype=torch.float32, device=dev)
+        if E == 0:
+            return out_pos, out_neg
+        ws = self._workspace(E, batch_size)
+        st = self._state()
+        nb = (E + batch_size - 1) // batch_size
+        lid = self._next_launch_ids(nb)
+        flags = (_lib.FLAG_NOT_SCALE if self.not_scale else 0)
+        if self.exact:
+            flags |= _lib.FLAG_EAGER_DECAY | _lib.FLAG_SEQUENTIAL
+        t_out = C.c_double(0.0)
+        _lib.check(_lib.load().tpnet_run_stream(
+            C.byref(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
+            E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
+            out_pos.data_ptr() if want_pos else None, out_neg.data_ptr() if want_neg else None,
+            ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream()), "run_stream")
+        self._now_host = float(t_end) if t_end is not None else float(t_out.value)
+        self._params_valid = False
+        self._parameters["now_time"].data.fill_(self._now_host)
+        return (out_pos if want_pos else None), (out_neg if want_neg else None)
+
+    def check_device_errors(self):
+        """Raise IndexError if a kernel met a node id outside [0, node_num) since the last check."""
+        st = self._state()
+        _lib.check(_lib.load().tpnet_check_errors(C.byref(st), self._stream()), "check_errors")
