@@ -15,6 +15,7 @@ namespace tpnet {
 
 static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (ver >> 1)
 static constexpr int BLOCK = 256;
+static constexpr int HEAVY_BLOCKS = 32;   // workgroups of a step launch reserved for heavy update items
 
 // ---------------------------------------------------------------------------------------------------------------
 // helpers
@@ -204,17 +205,93 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// update of ONE target node by one group of LPP lanes (models/TPNet.py:90-96, all layers at once):
+// update (models/TPNet.py:90-96, all layers at once) of ONE target node u:
 //   new[i][u] = old[i][u] * g_u^i  +  sum_j  w_j * ( P[i-1][partner_j] * g_partner^(i-1) ),   i = 1..L
-// contributions are summed in sorted order = the reference's index order (src-side edges, then dst-side edges).
+// Contributions are summed in sorted order = the reference's index order (src-side edges, then dst-side edges).
 // All reads hit pre-launch copies; the result goes to the other copy.
+//
+// accumulate_range: one group of LPP lanes adds the contributions [jb, je) into acc.  Dependent memory round trips
+// are what bounds a small batch, so: (1) the (partner, weight) pairs and the partners' meta records of up to LPP
+// contributions are fetched lane-parallel (one per lane, two round trips in all) and handed round by shuffles;
+// (2) U contributions' rows (U*L vectors per lane) are in flight at once.  All loops are wave-uniform (__any), the
+// per-group bounds only predicate the loads, because the groups of one wave may own different targets.
 // ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int VPL, int W, int L>
+__device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int32_t* __restrict__ s_partner,
+                                                 const float* __restrict__ s_coef, uint32_t jb, uint32_t je,
+                                                 uint32_t bid, double t_last, double lambda, int gl, int c0,
+                                                 float (&acc)[L][VPL * W]) {
+    constexpr int F = VPL * W;
+    constexpr int U = 4;
+    const int d = S.d;
+    const int nvec = d / W;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    for (uint32_t r0 = jb; __any(r0 < je); r0 += LPP) {
+        const uint32_t jm = r0 + (uint32_t)gl;
+        const bool mine = jm < je;
+        const int32_t my_pv = mine ? s_partner[jm] : 0;
+        const float my_w = mine ? s_coef[jm] : 0.0f;
+        const MetaView my_m = read_meta(meta, my_pv, bid, t_last, lambda);
+        const uint32_t n_here = (r0 < je) ? ((je - r0 < (uint32_t)LPP) ? je - r0 : (uint32_t)LPP) : 0u;
+        for (uint32_t k0 = 0; __any(k0 < n_here); k0 += U) {
+            int32_t pv[U];
+            float w[U], g[U];
+            int cp[U];
+            bool ok[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int sl = (int)k0 + k;
+                ok[k] = (uint32_t)sl < n_here;
+                pv[k] = __shfl(my_pv, sl, LPP);
+                w[k] = __shfl(my_w, sl, LPP);
+                g[k] = __shfl(my_m.g, sl, LPP);
+                cp[k] = __shfl(my_m.copy, sl, LPP);
+            }
+            float r[U][L][F];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float* r0p = S.p0 + (int64_t)pv[k] * d;
+                const float* rq = S.q + ((int64_t)cp[k] * S.N + pv[k]) * ((int64_t)L * d);
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const float* rp = (i == 0) ? r0p : rq + (int64_t)(i - 1) * d;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        const int vi = c0 + j * LPP + gl;
+                        if (ok[k] && vi < nvec) {
+                            ldv<W>(rp, vi, &r[k][i][j * W]);
+                        } else {
+#pragma unroll
+                            for (int x = 0; x < W; ++x) r[k][i][j * W + x] = 0.0f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (ok[k]) {
+                    float gi = 1.0f;
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+#pragma unroll
+                        for (int x = 0; x < F; ++x) {
+                            const float m = (r[k][i][x] * gi) * w[k];  // (P[i-1][partner], decayed) * time weight (:91-92)
+                            acc[i][x] = acc[i][x] + m;                 // scatter-add, in index order (:93-96)
+                        }
+                        gi *= g[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// light item: one group owns the target
 template <int LPP, int VPL, int W, int L>
 __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                             const float* __restrict__ s_coef, int32_t u, uint32_t j0, uint32_t cnt,
                                             bool valid, uint32_t bid, double t_last, double lambda, int gl) {
     constexpr int F = VPL * W;
-    constexpr int U = 4;  // contributions in flight per group
     const int d = S.d;
     const int nvec = d / W;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
@@ -245,56 +322,7 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
 #pragma unroll
             for (int k = 0; k < F; ++k) acc[i][k] *= gu[i];
         }
-
-        for (uint32_t jj = 0; jj < cnt; jj += U) {
-            int32_t pv[U];
-            float w[U];
-            bool ok[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                ok[k] = jj + k < cnt;
-                pv[k] = ok[k] ? s_partner[j0 + jj + k] : 0;
-                w[k] = ok[k] ? s_coef[j0 + jj + k] : 0.0f;
-            }
-            MetaView mv[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) mv[k] = read_meta(meta, pv[k], bid, t_last, lambda);
-            float r[U][L][F];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const float* r0 = S.p0 + (int64_t)pv[k] * d;
-                const float* rq = S.q + ((int64_t)mv[k].copy * S.N + pv[k]) * ((int64_t)L * d);
-#pragma unroll
-                for (int i = 0; i < L; ++i) {
-                    const float* rp = (i == 0) ? r0 : rq + (int64_t)(i - 1) * d;
-#pragma unroll
-                    for (int j = 0; j < VPL; ++j) {
-                        const int vi = c0 + j * LPP + gl;
-                        if (ok[k] && vi < nvec) {
-                            ldv<W>(rp, vi, &r[k][i][j * W]);
-                        } else {
-#pragma unroll
-                            for (int x = 0; x < W; ++x) r[k][i][j * W + x] = 0.0f;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (ok[k]) {
-                    float gi = 1.0f;
-#pragma unroll
-                    for (int i = 0; i < L; ++i) {
-#pragma unroll
-                        for (int x = 0; x < F; ++x) {
-                            const float m = (r[k][i][x] * gi) * w[k];  // (P[i-1][partner] decayed) * time weight (:91-92)
-                            acc[i][x] = acc[i][x] + m;                 // scatter-add, in index order (:93-96)
-                        }
-                        gi *= mv[k].g;
-                    }
-                }
-            }
-        }
+        accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, j0, j0 + cnt, bid, t_last, lambda, gl, c0, acc);
 #pragma unroll
         for (int i = 0; i < L; ++i) {
 #pragma unroll
@@ -310,10 +338,82 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
     }
 }
 
+// heavy item: the whole workgroup owns the target.  Group g sums the g-th slice of the contribution list; the slices'
+// partial sums are added in slice order through LDS (fixed order: results are reproducible run to run, but the
+// association differs from the strictly sequential sum -- TPNET_FLAG_SEQUENTIAL turns heavy items off).
+template <int LPP, int VPL, int W, int L>
+__device__ __forceinline__ void update_item_block(const tpnet_state& S, const int32_t* __restrict__ s_partner,
+                                                  const float* __restrict__ s_coef, int32_t u, uint32_t j0,
+                                                  uint32_t cnt, uint32_t bid, double t_last, double lambda,
+                                                  float* __restrict__ part /* LDS [L*F][BLOCK] */) {
+    constexpr int F = VPL * W;
+    constexpr int G = BLOCK / LPP;
+    const int d = S.d;
+    const int nvec = d / W;
+    const int gl = threadIdx.x % LPP;
+    const int g = threadIdx.x / LPP;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    const uint32_t per = (cnt + G - 1) / G;
+    const uint32_t lo = (uint32_t)g * per < cnt ? (uint32_t)g * per : cnt;
+    const uint32_t hi = lo + per < cnt ? lo + per : cnt;
+
+    const MetaView mu = read_meta(meta, u, bid, t_last, lambda);
+    const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
+    float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
+
+    for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
+        float acc[L][F];
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int k = 0; k < F; ++k) acc[i][k] = 0.0f;
+        accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, j0 + lo, j0 + hi, bid, t_last, lambda, gl, c0, acc);
+#pragma unroll
+        for (int i = 0; i < L; ++i)
+#pragma unroll
+            for (int k = 0; k < F; ++k) part[(i * F + k) * BLOCK + threadIdx.x] = acc[i][k];
+        __syncthreads();
+        if (g == 0) {
+            float gi = 1.0f;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                gi *= mu.g;
+                float tot[F];
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const int vi = c0 + j * LPP + gl;
+                    if (vi < nvec) {
+                        ldv<W>(qold + (int64_t)i * d, vi, &tot[j * W]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) tot[j * W + k] = 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < F; ++k) tot[k] *= gi;
+                for (int gg = 0; gg < G; ++gg) {
+#pragma unroll
+                    for (int k = 0; k < F; ++k) tot[k] = tot[k] + part[(i * F + k) * BLOCK + gg * LPP + gl];
+                }
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const int vi = c0 + j * LPP + gl;
+                    if (vi < nvec) stv<W>(qnew + (int64_t)i * d, vi, &tot[j * W]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        meta[u].tref[mu.copy ^ 1] = t_last;
+        meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fused per-batch step: readout (src,dst) and (src,neg) on the pre-batch state + update, ONE launch.
-// Work index space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the
-// batch's update items.
+// Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target); the others walk a work index
+// space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, int W, int L>
 __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, double lambda,
@@ -321,7 +421,19 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
     constexpr int GPB = BLOCK / LPP;
     constexpr int GPW = 64 / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
+    __shared__ float part[L * VPL * W * BLOCK];
     const BatchDesc D = p.desc[b];
+    if (blockIdx.x < HEAVY_BLOCKS) {
+        if (flags & ROLE_UPDATE) {
+            const Item* heavy = p.heavy + 2 * D.e0;
+            for (uint32_t h = blockIdx.x; h < D.n_heavy; h += HEAVY_BLOCKS) {
+                const Item I = heavy[h];
+                update_item_block<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, bid, D.t_last,
+                                                  lambda, part);
+            }
+        }
+        return;
+    }
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
@@ -333,8 +445,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
     const int64_t nitems = (flags & ROLE_UPDATE) ? (int64_t)D.n_light : 0;
     const int64_t total = RP + nitems;
     const Item* items = p.light + 2 * D.e0;
+    const int64_t nblk = (int64_t)gridDim.x - HEAVY_BLOCKS;
 
-    for (int64_t base = (int64_t)blockIdx.x * GPB; base < total; base += (int64_t)gridDim.x * GPB) {
+    for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total; base += nblk * GPB) {
         const int64_t w = base + g;
         const int64_t wave0 = base + (g / GPW) * GPW;  // first work index of this wave: decides the wave's role
         if (wave0 < RP) {
@@ -358,13 +471,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             const int64_t it = w - RP;
             const bool valid = it < nitems;
             Item I;
-            I.j0 = 0; I.cnt = 0;
-            int32_t u = 0;
-            if (valid) {
-                I = items[it];
-                u = p.s_target[I.j0];
-            }
-            update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, u, I.j0, I.cnt, valid, bid, D.t_last, lambda, gl);
+            I.j0 = 0; I.cnt = 0; I.target = 0; I.pad = 0;
+            if (valid) I = items[it];
+            update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, valid, bid, D.t_last, lambda,
+                                        gl);
         }
     }
 }
@@ -592,7 +702,7 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
     // upper bound of the work indices: 2*ne readout pairs + at most 2*ne distinct targets
     const int64_t work = 4 * (int64_t)ne + 8;
     TPNET_DISPATCH(({
-        const int grid = grid_for(work, BLOCK / LPP, 256 * 8);
+        const int grid = HEAVY_BLOCKS + grid_for(work, BLOCK / LPP, 256 * 8);
         hipLaunchKernelGGL((k_step<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b, lambda, launch_id,
                            flags);
     }));

@@ -9,7 +9,7 @@
 
 namespace tpnet {
 
-static constexpr uint32_t HEAVY_THRESHOLD = 0xFFFFFFFFu;  // contributions per target above which an item is "heavy"
+static constexpr uint32_t HEAVY_THRESHOLD = 8u;  // contributions per target above which an item is "heavy"
 
 static inline int ceil_log2_u64(uint64_t x) {
     int b = 0;
@@ -166,6 +166,8 @@ __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t*
             Item it;
             it.j0 = (uint32_t)j;
             it.cnt = (uint32_t)(hi - j);
+            it.target = (int32_t)(key & node_mask);
+            it.pad = 0;
             if (it.cnt > heavy_threshold) {
                 const uint32_t idx = atomicAdd(&p.desc[b].n_heavy, 1u);
                 p.heavy[c0 + idx] = it;

@@ -31,8 +31,10 @@ struct BatchDesc {
 
 // One update item: a distinct target node of the batch and its run of contributions in the sorted arrays.
 struct Item {
-    uint32_t j0;   // first contribution (index into the sorted arrays)
-    uint32_t cnt;  // number of contributions
+    uint32_t j0;     // first contribution (index into the sorted arrays)
+    uint32_t cnt;    // number of contributions
+    int32_t target;  // the node
+    uint32_t pad;
 };
 
 // Views into the caller's workspace for one chunk of the stream.
