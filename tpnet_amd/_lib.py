@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtpnet_hip.so")
+LIB_PATH = os.environ.get("TPNET_DEV_LIB") or os.path.join(_HERE, "libtpnet_hip.so")   # TPNET_DEV_LIB: diagnostic builds
 
 TPNET_MAX_LAYERS = 4
 FLAG_NOT_SCALE = 1

@@ -2,6 +2,7 @@
 // synchronisation; everything is enqueued on the caller's stream.
 #include "tpnet_common.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace tpnet {
@@ -23,6 +24,12 @@ static int64_t max_chunk(size_t ws_bytes, int64_t E, int64_t batch) {
         if (plan_bytes(mid * batch, batch) <= ws_bytes) lo = mid; else hi = mid;
     }
     return lo * batch;
+}
+
+// developer knobs for kernel experiments (never set in tests or bench.py)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 struct StepTimer {
@@ -62,17 +69,19 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
             if (flags & TPNET_FLAG_EAGER_DECAY) {
                 // reference order: readout on the pre-batch state, THEN decay + scatter-add (TPNet.py:83-96)
                 if (have_readout) {
-                    rc = launch_step(st, a, p, b, ne, lambda, lid, flags | ROLE_READOUT, s);
+                    rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | ROLE_READOUT, s);
                     if (rc) return rc;
                 }
                 rc = launch_decay_desc(st, p, b, s);
                 if (rc) return rc;
-                rc = launch_step(st, a, p, b, ne, lambda, lid, flags | ROLE_UPDATE, s);
+                rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | ROLE_UPDATE, s);
                 if (rc) return rc;
             } else {
                 if (timer && timer->n < timer->cap) (void)hipEventRecord(timer->ev[2 * timer->n], s);
-                rc = launch_step(st, a, p, b, ne, lambda, lid, flags | ROLE_UPDATE | (have_readout ? ROLE_READOUT : 0u),
-                                 s);
+                static const int role_mask = env_int("TPNET_DEV_ROLE_MASK", 3);
+                const uint32_t roles = ((role_mask & 2) ? ROLE_UPDATE : 0u) |
+                                       ((have_readout && (role_mask & 1)) ? ROLE_READOUT : 0u);
+                rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | roles, s);
                 if (rc) return rc;
                 if (timer && timer->n < timer->cap) {
                     (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);

@@ -13,8 +13,27 @@
 
 namespace tpnet {
 
+#ifdef TPNET_STAMPS
+// diagnostic build only: lane 0 of every wave records (shader clock, 100 MHz wall clock) at phase boundaries
+#define STAMP(slot)                                                                                        \
+    do {                                                                                                   \
+        if (dbg && (threadIdx.x & 63) == 0) {                                                              \
+            const size_t wv = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));                    \
+            if (wv < 4000) {                                                                               \
+                dbg[(wv * 8 + (slot)) * 2 + 0] = __builtin_amdgcn_s_memtime();                             \
+                dbg[(wv * 8 + (slot)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                         \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (ver >> 1)
-static constexpr int BLOCK = 256;
+#ifndef TPNET_BLOCK
+#define TPNET_BLOCK 512
+#endif
+static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the pair/step kernels
 static constexpr int HEAVY_BLOCKS = 32;   // workgroups of a step launch reserved for heavy update items
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -28,6 +47,13 @@ __device__ __forceinline__ void ldv(const float* __restrict__ row, int vi, float
     } else {
         dst[0] = row[vi];
     }
+}
+// predicated load without a branch: out-of-range lanes read vector 0 of the (always valid) row and are zeroed
+template <int W>
+__device__ __forceinline__ void ldv_pred(const float* __restrict__ row, int vi, bool ok, float* dst) {
+    ldv<W>(row, ok ? vi : 0, dst);
+#pragma unroll
+    for (int k = 0; k < W; ++k) dst[k] = ok ? dst[k] : 0.0f;
 }
 template <int W>
 __device__ __forceinline__ void stv(float* __restrict__ row, int vi, const float* src) {
@@ -61,16 +87,45 @@ __device__ __forceinline__ MetaView read_meta(const NodeMeta* __restrict__ meta,
 }
 
 // Recursive halving: MP partial sums per lane over a group of 2*M lanes -> lane gl ends with the MP/(2M) complete sums
-// of indices [gl*MP/(2M), ...).  63 shuffles for 64 values over 64 lanes instead of 6*64 for a butterfly all-reduce.
+// of indices [gl*MP/(2M), ...).  63 exchanges for 64 values over 64 lanes instead of 6*64 for a butterfly all-reduce.
+// Exchanges never touch LDS: v_permlane32_swap / v_permlane16_swap (gfx950) trade the two halves in one instruction
+// (then one add, no select); inside a 16-lane row the partner comes through DPP (row_ror:8, row_half_mirror,
+// quad_perm) fused into v_add_f32_dpp.  Any involution works as the pairing as long as the partners differ in the
+// lane bit M that decides which half a lane keeps.
+template <int M>
+__device__ __forceinline__ float pair_sum(float a) {
+    static_assert(M == 8 || M == 4 || M == 2 || M == 1, "row-level DPP pairing");
+    constexpr int ctrl = (M == 8) ? 0x128 /* row_ror:8 */ : (M == 4) ? 0x141 /* row_half_mirror */
+                       : (M == 2) ? 0x4E /* quad_perm [2,3,0,1] */ : 0xB1 /* quad_perm [1,0,3,2] */;
+    const float p = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), ctrl, 0xF, 0xF, false));
+    return a + p;
+}
+
 template <int C, int M>
 struct Halve {
     static __device__ __forceinline__ void run(float* v, int gl) {
-        const bool upper = (gl & M) != 0;
+        if constexpr (M == 32) {
 #pragma unroll
-        for (int i = 0; i < C / 2; ++i) {
-            const float keep = upper ? v[i + C / 2] : v[i];
-            const float send = upper ? v[i] : v[i + C / 2];
-            v[i] = keep + __shfl_xor(send, M, 64);
+            for (int i = 0; i < C / 2; ++i) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + C / 2]),
+                                                                false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+        } else if constexpr (M == 16) {
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + C / 2]),
+                                                                false, false);
+                v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+        } else {
+            const bool upper = (gl & M) != 0;
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) {
+                const float x = pair_sum<M>(v[i]);
+                const float y = pair_sum<M>(v[i + C / 2]);
+                v[i] = upper ? y : x;
+            }
         }
         Halve<C / 2, M / 2>::run(v, gl);
     }
@@ -94,7 +149,8 @@ struct GramCfg {
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, int W, int L>
 __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
-                                          double now, double lambda, bool do_scale, float* __restrict__ out, int gl) {
+                                          double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
+                                          unsigned long long* dbg = nullptr) {
     using C = GramCfg<LPP, L>;
     constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
     const int d = S.d;
@@ -105,6 +161,7 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
     if (valid && !idok && gl == 0) atomicAdd(S.err, 1u);
     if (!idok) { u = 0; v = 0; }
 
+    STAMP(1);
     const float* rowp[NN];
     float rs[NN];
     {
@@ -128,6 +185,7 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
     float acc[C::MP];
 #pragma unroll
     for (int i = 0; i < C::MP; ++i) acc[i] = 0.0f;
+    STAMP(2);
 
     for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
         float f[NN][F];
@@ -136,12 +194,7 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                if (vi < nvec) {
-                    ldv<W>(rowp[a], vi, &f[a][j * W]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < W; ++k) f[a][j * W + k] = 0.0f;
-                }
+                ldv_pred<W>(rowp[a], vi, vi < nvec, &f[a][j * W]);
             }
         }
 #pragma unroll
@@ -168,7 +221,9 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
         for (int b = 0; b < a; ++b) acc[a * NN + b] = acc[b * NN + a];
     }
 
+    STAMP(3);
     Halve<C::MP, LPP / 2>::run(acc, gl);
+    STAMP(4);
 
     if (valid) {
 #pragma unroll
@@ -258,12 +313,7 @@ __device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) {
                         const int vi = c0 + j * LPP + gl;
-                        if (ok[k] && vi < nvec) {
-                            ldv<W>(rp, vi, &r[k][i][j * W]);
-                        } else {
-#pragma unroll
-                            for (int x = 0; x < W; ++x) r[k][i][j * W + x] = 0.0f;
-                        }
+                        ldv_pred<W>(rp, vi, ok[k] && vi < nvec, &r[k][i][j * W]);
                     }
                 }
             }
@@ -286,18 +336,25 @@ __device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int
     }
 }
 
-// light item: one group owns the target
+// light item: one group owns the target.  Its first two contributions come inside the item record, so the target's
+// meta record and both partners' are fetched together, then all their rows together: three dependent round trips
+// (item -> metas -> rows) for the typical target.
 template <int LPP, int VPL, int W, int L>
 __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t* __restrict__ s_partner,
-                                            const float* __restrict__ s_coef, int32_t u, uint32_t j0, uint32_t cnt,
-                                            bool valid, uint32_t bid, double t_last, double lambda, int gl) {
+                                            const float* __restrict__ s_coef, Item I, bool valid, uint32_t bid,
+                                            double t_last, double lambda, int gl) {
     constexpr int F = VPL * W;
     const int d = S.d;
     const int nvec = d / W;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
-    if (!valid) { u = 0; cnt = 0; }
+    if (!valid) { I.target = 0; I.cnt = 0; I.p0 = 0; I.p1 = 0; I.j0 = 0; }
+    const int32_t u = I.target;
+    const bool has0 = I.cnt >= 1, has1 = I.cnt >= 2;
+    const int32_t pv[2] = {I.p0, has1 ? I.p1 : 0};
+    const float pw[2] = {I.w0, I.w1};
 
     const MetaView mu = read_meta(meta, u, bid, t_last, lambda);
+    const MetaView mp[2] = {read_meta(meta, pv[0], bid, t_last, lambda), read_meta(meta, pv[1], bid, t_last, lambda)};
     const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
     float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
     float gu[L];
@@ -307,22 +364,55 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
 
     for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
         float acc[L][F];
+        float r[2][L][F];
 #pragma unroll
         for (int i = 0; i < L; ++i) {
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                if (valid && vi < nvec) {
-                    ldv<W>(qold + (int64_t)i * d, vi, &acc[i][j * W]);
-                } else {
+                ldv_pred<W>(qold + (int64_t)i * d, vi, valid && vi < nvec, &acc[i][j * W]);
+            }
+        }
 #pragma unroll
-                    for (int k = 0; k < W; ++k) acc[i][j * W + k] = 0.0f;
+        for (int k = 0; k < 2; ++k) {
+            const bool okk = (k == 0) ? has0 : has1;
+            const float* r0p = S.p0 + (int64_t)pv[k] * d;
+            const float* rq = S.q + ((int64_t)mp[k].copy * S.N + pv[k]) * ((int64_t)L * d);
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const float* rp = (i == 0) ? r0p : rq + (int64_t)(i - 1) * d;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const int vi = c0 + j * LPP + gl;
+                    ldv_pred<W>(rp, vi, okk && vi < nvec, &r[k][i][j * W]);
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
 #pragma unroll
             for (int k = 0; k < F; ++k) acc[i][k] *= gu[i];
         }
-        accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, j0, j0 + cnt, bid, t_last, lambda, gl, c0, acc);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool okk = (k == 0) ? has0 : has1;
+            if (okk) {
+                float gi = 1.0f;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+#pragma unroll
+                    for (int x = 0; x < F; ++x) {
+                        const float m = (r[k][i][x] * gi) * pw[k];  // (P[i-1][partner], decayed) * time weight (:91-92)
+                        acc[i][x] = acc[i][x] + m;                  // scatter-add, in index order (:93-96)
+                    }
+                    gi *= mp[k].g;
+                }
+            }
+        }
+        if (__any(I.cnt > 2)) {
+            const uint32_t jb = I.j0 + 2, je = (I.cnt > 2) ? I.j0 + I.cnt : I.j0 + 2;
+            accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, jb, je, bid, t_last, lambda, gl, c0, acc);
+        }
 #pragma unroll
         for (int i = 0; i < L; ++i) {
 #pragma unroll
@@ -363,10 +453,17 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 
     for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
         float acc[L][F];
+        float old[L][F];   // the target's pre-batch rows: fetched up front by group 0, consumed after the barrier
 #pragma unroll
-        for (int i = 0; i < L; ++i)
+        for (int i = 0; i < L; ++i) {
 #pragma unroll
             for (int k = 0; k < F; ++k) acc[i][k] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int vi = c0 + j * LPP + gl;
+                ldv_pred<W>(qold + (int64_t)i * d, vi, g == 0 && vi < nvec, &old[i][j * W]);
+            }
+        }
         accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, j0 + lo, j0 + hi, bid, t_last, lambda, gl, c0, acc);
 #pragma unroll
         for (int i = 0; i < L; ++i)
@@ -380,17 +477,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
                 gi *= mu.g;
                 float tot[F];
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const int vi = c0 + j * LPP + gl;
-                    if (vi < nvec) {
-                        ldv<W>(qold + (int64_t)i * d, vi, &tot[j * W]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < W; ++k) tot[j * W + k] = 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < F; ++k) tot[k] *= gi;
+                for (int k = 0; k < F; ++k) tot[k] = old[i][k] * gi;
                 for (int gg = 0; gg < G; ++gg) {
 #pragma unroll
                     for (int k = 0; k < F; ++k) tot[k] = tot[k] + part[(i * F + k) * BLOCK + gg * LPP + gl];
@@ -416,20 +503,28 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, int W, int L>
-__global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, double lambda,
-                                                uint32_t bid, uint32_t flags) {
+__global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, int64_t e0, int32_t ne_,
+                                                double lambda, uint32_t bid, uint32_t flags) {
     constexpr int GPB = BLOCK / LPP;
     constexpr int GPW = 64 / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
     __shared__ float part[L * VPL * W * BLOCK];
+    unsigned long long* dbg = p.dbg;
+    (void)dbg;
+    STAMP(0);
+    // e0/ne come with the launch and the item records are fetched speculatively (their slots always exist), so neither
+    // the id loads nor the item loads wait for the descriptor (clocks, item counts): both are in flight together.
     const BatchDesc D = p.desc[b];
     if (blockIdx.x < HEAVY_BLOCKS) {
         if (flags & ROLE_UPDATE) {
-            const Item* heavy = p.heavy + 2 * D.e0;
-            for (uint32_t h = blockIdx.x; h < D.n_heavy; h += HEAVY_BLOCKS) {
+            const Item* heavy = p.heavy + 2 * e0;
+            const uint32_t cap = 2u * (uint32_t)ne_;
+            for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
                 const Item I = heavy[h];
+                if (h >= D.n_heavy) break;
                 update_item_block<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, bid, D.t_last,
                                                   lambda, part);
+                STAMP(7);
             }
         }
         return;
@@ -437,14 +532,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
-    const int64_t ne = D.ne;
+    const int64_t ne = ne_;
     const int64_t npos = ((flags & ROLE_READOUT) && a.out_pos) ? ne : 0;
     const int64_t nneg = ((flags & ROLE_READOUT) && a.out_neg) ? ne : 0;
     const int64_t npairs = npos + nneg;
     const int64_t RP = (npairs + GPW - 1) / GPW * GPW;
-    const int64_t nitems = (flags & ROLE_UPDATE) ? (int64_t)D.n_light : 0;
-    const int64_t total = RP + nitems;
-    const Item* items = p.light + 2 * D.e0;
+    const int64_t cap_items = (flags & ROLE_UPDATE) ? 2 * ne : 0;   // upper bound of the light items (slots exist)
+    const int64_t total = RP + cap_items;
+    const Item* items = p.light + 2 * e0;
     const int64_t nblk = (int64_t)gridDim.x - HEAVY_BLOCKS;
 
     for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total; base += nblk * GPB) {
@@ -456,25 +551,25 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             float* out = nullptr;
             if (valid) {
                 if (w < npos) {
-                    e = D.e0 + w;
+                    e = e0 + w;
                     v = a.dst[e];
                     out = a.out_pos + e * NG;
                 } else {
-                    e = D.e0 + (w - npos);
+                    e = e0 + (w - npos);
                     v = a.neg[e];
                     out = a.out_neg + e * NG;
                 }
                 u = a.src[e];
             }
-            gram_pair<LPP, VPL, W, L>(S, u, v, valid, bid, D.now, lambda, do_scale, out, gl);
+            gram_pair<LPP, VPL, W, L>(S, u, v, valid, bid, D.now, lambda, do_scale, out, gl, p.dbg);
+            STAMP(5);
         } else {
             const int64_t it = w - RP;
-            const bool valid = it < nitems;
-            Item I;
-            I.j0 = 0; I.cnt = 0; I.target = 0; I.pad = 0;
-            if (valid) I = items[it];
-            update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, valid, bid, D.t_last, lambda,
-                                        gl);
+            Item I = items[it < cap_items ? it : 0];
+            if (wave0 - RP >= (int64_t)D.n_light) break;   // wave-uniform: no item of this wave exists (and none later)
+            const bool valid = it < (int64_t)D.n_light;
+            update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I, valid, bid, D.t_last, lambda, gl);
+            STAMP(6);
         }
     }
 }
@@ -697,14 +792,14 @@ int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, 
     return TPNET_OK;
 }
 
-int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int32_t ne, double lambda,
-                uint32_t launch_id, uint32_t flags, hipStream_t s) {
+int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
+                double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
     // upper bound of the work indices: 2*ne readout pairs + at most 2*ne distinct targets
     const int64_t work = 4 * (int64_t)ne + 8;
     TPNET_DISPATCH(({
         const int grid = HEAVY_BLOCKS + grid_for(work, BLOCK / LPP, 256 * 8);
-        hipLaunchKernelGGL((k_step<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b, lambda, launch_id,
-                           flags);
+        hipLaunchKernelGGL((k_step<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b,
+                           b * batch, ne, lambda, launch_id, flags);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;

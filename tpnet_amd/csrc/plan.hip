@@ -4,6 +4,7 @@
 // (batch, target) keys), so the per-batch step kernels find ready-made item lists and the cost is amortised.
 #include "tpnet_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -33,7 +34,7 @@ size_t plan_bytes(int64_t max_edges, int64_t batch) {
     if (batch < 1) batch = 1;
     const size_t nc = 2 * (size_t)max_edges;
     const size_t nb = (size_t)((max_edges + batch - 1) / batch);
-    size_t tot = 0;
+    size_t tot = TPNET_DBG_BYTES;
     tot += align_up(nc * sizeof(uint64_t), 256) * 2;   // keys in/out
     tot += align_up(nc * sizeof(uint32_t), 256) * 2;   // vals in/out
     tot += align_up(nc * sizeof(int32_t), 256) * 2;    // s_partner, s_target
@@ -56,6 +57,7 @@ int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out) 
         p += align_up(bytes, 256);
         return r;
     };
+    out->dbg = (unsigned long long*)take(TPNET_DBG_BYTES);
     out->keys_in = (uint64_t*)take(nc * sizeof(uint64_t));
     out->keys_out = (uint64_t*)take(nc * sizeof(uint64_t));
     out->vals_in = (uint32_t*)take(nc * sizeof(uint32_t));
@@ -121,6 +123,25 @@ __global__ void k_make_keys(uint64_t* __restrict__ keys, uint32_t* __restrict__ 
     }
 }
 
+// partner and time weight of the contribution whose pre-sort index is `val`
+__device__ __forceinline__ void contribution(const Plan& p, const int64_t* __restrict__ src,
+                                             const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t Ec,
+                                             int64_t B, int64_t N, double lambda, uint32_t val, int32_t& partner,
+                                             float& w, uint32_t* err) {
+    int64_t b, e;
+    int side;
+    decode((int64_t)val, B, Ec, b, side, e);
+    const int64_t s = src[e], dd = dst[e];
+    const bool ok = (uint64_t)s < (uint64_t)N && (uint64_t)dd < (uint64_t)N;
+    if (err && !ok && side == 0) atomicAdd(err, 1u);   // once per bad edge
+    const double t_last = p.desc[b].t_last;
+    // time weight, with the reference's casts: absolute times rounded to f32 BEFORE the subtraction, f32 lambda
+    // (models/TPNet.py:77-78)
+    const float x = (float)t_last - (float)t[e];
+    w = ok ? expf((float)(-lambda) * x) : 0.0f;
+    partner = ok ? (int32_t)(side ? s : dd) : 0;
+}
+
 __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                          const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N, int node_bits, double lambda,
                          uint32_t heavy_threshold, uint32_t* err) {
@@ -129,20 +150,12 @@ __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t*
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t key = p.keys_out[j];
         const uint32_t val = p.vals_out[j];
-        int64_t b, e;
-        int side;
-        decode((int64_t)val, B, Ec, b, side, e);
-        const int64_t s = src[e], dd = dst[e];
-        const bool ok = (uint64_t)s < (uint64_t)N && (uint64_t)dd < (uint64_t)N;
-        if (!ok && side == 0) atomicAdd(err, 1u);
-        const int64_t partner = side ? s : dd;
-        const double t_last = p.desc[b].t_last;
-        // time weight, with the reference's casts: absolute times rounded to f32 BEFORE the subtraction, f32 lambda
-        // (models/TPNet.py:77-78)
-        const float x = (float)t_last - (float)t[e];
-        const float w = expf((float)(-lambda) * x);
-        p.s_partner[j] = ok ? (int32_t)partner : 0;
-        p.s_coef[j] = ok ? w : 0.0f;
+        const int64_t b = (int64_t)(key >> node_bits);
+        int32_t partner;
+        float w;
+        contribution(p, src, dst, t, Ec, B, N, lambda, val, partner, w, err);
+        p.s_partner[j] = partner;
+        p.s_coef[j] = w;
         p.s_target[j] = (int32_t)(key & node_mask);
 
         const int64_t c0 = 2 * b * B;
@@ -167,6 +180,11 @@ __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t*
             it.j0 = (uint32_t)j;
             it.cnt = (uint32_t)(hi - j);
             it.target = (int32_t)(key & node_mask);
+            it.p0 = partner;
+            it.w0 = w;
+            it.p1 = 0;
+            it.w1 = 0.0f;
+            if (it.cnt >= 2) contribution(p, src, dst, t, Ec, B, N, lambda, p.vals_out[j + 1], it.p1, it.w1, nullptr);
             it.pad = 0;
             if (it.cnt > heavy_threshold) {
                 const uint32_t idx = atomicAdd(&p.desc[b].n_heavy, 1u);
@@ -198,7 +216,8 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     size_t tmp = p.sort_tmp_bytes;
     TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
                                             (size_t)nc, 0u, (unsigned)(node_bits + batch_bits), s, false));
-    const uint32_t thr = (flags & TPNET_FLAG_SEQUENTIAL) ? 0xFFFFFFFFu : HEAVY_THRESHOLD;
+    static const char* thr_env = getenv("TPNET_DEV_HEAVY_THRESHOLD");
+    const uint32_t thr = (flags & TPNET_FLAG_SEQUENTIAL) ? 0xFFFFFFFFu : (thr_env ? (uint32_t)atoi(thr_env) : HEAVY_THRESHOLD);
     hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, s, p, src, dst, t, Ec, batch, st.N, node_bits, lambda, thr,
                        st.err);
     TPNET_HIP_TRY(hipGetLastError());

@@ -29,13 +29,20 @@ struct BatchDesc {
     float decay[TPNET_MAX_LAYERS];  // eager mode: f32(exp(-lambda*(t_last-now))^i), i = 1..L
 };
 
-// One update item: a distinct target node of the batch and its run of contributions in the sorted arrays.
+// One update item: a distinct target node of the batch and its run of contributions in the sorted arrays.  The first
+// two contributions ride in the record itself, so that a typical target (1-2 contributions) needs no further
+// dependent load before its rows can be fetched.
 struct Item {
     uint32_t j0;     // first contribution (index into the sorted arrays)
-    uint32_t cnt;    // number of contributions
+    uint32_t cnt;    // number of contributions (0 = empty slot)
     int32_t target;  // the node
+    int32_t p0;      // partner / weight of contribution j0
+    float w0;
+    int32_t p1;      // partner / weight of contribution j0+1 (if cnt >= 2)
+    float w1;
     uint32_t pad;
 };
+static_assert(sizeof(Item) == 32, "Item must be 32 bytes");
 
 // Views into the caller's workspace for one chunk of the stream.
 struct Plan {
@@ -51,7 +58,9 @@ struct Plan {
     BatchDesc* desc;      // [nb]
     void* sort_tmp;
     size_t sort_tmp_bytes;
+    unsigned long long* dbg;  // first TPNET_DBG_BYTES of the workspace: in-kernel stamps of diagnostic builds (-DTPNET_STAMPS)
 };
+static constexpr size_t TPNET_DBG_BYTES = 1u << 20;
 
 struct StreamArgs {
     const int64_t* src;
@@ -86,8 +95,8 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
 int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                      uint32_t flags, float* out, hipStream_t s);
 // One launch: readout of batch b (if out_pos/out_neg) on the pre-batch state + update of batch b.
-int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int32_t ne, double lambda,
-                uint32_t launch_id, uint32_t flags, hipStream_t s);
+int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
+                double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s);
 int launch_decay_desc(const tpnet_state& st, const Plan& p, int64_t b, hipStream_t s);
 
 size_t plan_bytes(int64_t max_edges, int64_t batch);
