@@ -129,6 +129,31 @@ int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* d
                      uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
                      void* workspace, size_t ws_bytes, double* t_end_out, void* stream);
 
+/* ---- row-sharded multi-GPU building blocks (one process per GPU; the exchange itself is the caller's RCCL call) ----
+ * Rows are owned cyclically: owner(n) = n % G.  Every rank holds the full stream; per batch it (1) packs the
+ * touched rows it owns, (2) all-gathers them over RCCL, (3) unpacks the other ranks' rows into its local table,
+ * (4) runs the fused step restricted to the targets / pairs it owns.  See tpnet_amd/sharded.py. */
+
+/* Plan the update of a whole device-resident stream once (the per-batch item lists tpnet_step_batch consumes).
+ * The workspace must hold the whole stream: tpnet_workspace_bytes(E, batch). */
+int tpnet_plan_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t E,
+                      int64_t batch, double now_time, double lambda, uint32_t flags, void* workspace, size_t ws_bytes,
+                      void* stream);
+
+/* One fused launch for batch b of a planned stream: readout of the pairs whose src node this rank owns (other
+ * output rows are left untouched) + update of the targets it owns (id % own_mod == own_rem; own_mod = 1: all). */
+int tpnet_step_batch(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                     const double* t, int64_t E, int64_t batch, int64_t b, double lambda, uint32_t launch_id,
+                     uint32_t flags, int32_t own_mod, int32_t own_rem, float* out_pos, float* out_neg,
+                     void* workspace, size_t ws_bytes, void* stream);
+
+/* out[k][i][:] = P[i+1][ids[k]] at now_time (i = 0..L-1; layer 0 is static and replicated, never exchanged). */
+int tpnet_pack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out,
+                    void* stream);
+/* Local copy of row ids[k] <- in[k] (expressed at now_time).  Only for rows owned by another rank. */
+int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* in,
+                      void* stream);
+
 /* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
  * the last call (and clears the words), TPNET_OK otherwise. */
 int tpnet_check_errors(const tpnet_state* st, void* stream);

@@ -62,6 +62,8 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
         a.t = t + c0;
         a.out_pos = out_pos ? out_pos + c0 * NG : nullptr;
         a.out_neg = out_neg ? out_neg + c0 * NG : nullptr;
+        a.own_mod = 1;
+        a.own_rem = 0;
         const int64_t nb = (Ec + batch - 1) / batch;
         const bool have_readout = a.out_pos || a.out_neg;
         for (int64_t b = 0; b < nb; ++b, ++lid) {
@@ -203,6 +205,60 @@ int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* d
         TPNET_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     }
     return TPNET_OK;
+}
+
+int tpnet_plan_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t E,
+                      int64_t batch, double now_time, double lambda, uint32_t flags, void* workspace, size_t ws_bytes,
+                      void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (E < 1 || batch < 1 || !src || !dst || !t) return TPNET_ERR_BAD_ARG;
+    if (plan_bytes(E, batch) > ws_bytes) return TPNET_ERR_WORKSPACE;
+    Plan p{};
+    rc = plan_carve(workspace, ws_bytes, E, batch, &p);
+    if (rc) return rc;
+    return plan_build(*st, p, src, dst, t, E, batch, now_time, nullptr, lambda, flags, (hipStream_t)stream);
+}
+
+int tpnet_step_batch(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                     const double* t, int64_t E, int64_t batch, int64_t b, double lambda, uint32_t launch_id,
+                     uint32_t flags, int32_t own_mod, int32_t own_rem, float* out_pos, float* out_neg,
+                     void* workspace, size_t ws_bytes, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    const int64_t nb = (E + batch - 1) / batch;
+    if (E < 1 || batch < 1 || b < 0 || b >= nb || !src || !dst || !t) return TPNET_ERR_BAD_ARG;
+    if (own_mod < 1 || own_rem < 0 || own_rem >= own_mod) return TPNET_ERR_BAD_ARG;
+    if (out_neg && !neg) return TPNET_ERR_BAD_ARG;
+    if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
+    if (flags & TPNET_FLAG_EAGER_DECAY) return TPNET_ERR_BAD_ARG;   // the sharded path carries the decay lazily
+    Plan p{};
+    rc = plan_carve(workspace, ws_bytes, E, batch, &p);
+    if (rc) return rc;
+    StreamArgs a;
+    a.src = src; a.dst = dst; a.neg = neg; a.t = t;
+    a.out_pos = out_pos; a.out_neg = out_neg;
+    a.own_mod = own_mod; a.own_rem = own_rem;
+    const int32_t ne = (int32_t)((E - b * batch < batch) ? (E - b * batch) : batch);
+    const bool have_readout = out_pos || out_neg;
+    return launch_step(*st, a, p, b, batch, ne, lambda, launch_id,
+                       flags | ROLE_UPDATE | (have_readout ? ROLE_READOUT : 0u), (hipStream_t)stream);
+}
+
+int tpnet_pack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out,
+                    void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!ids || !out))) return TPNET_ERR_BAD_ARG;
+    return launch_pack_rows(*st, ids, n, now_time, lambda, out, (hipStream_t)stream);
+}
+
+int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* in,
+                      void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!ids || !in))) return TPNET_ERR_BAD_ARG;
+    return launch_unpack_rows(*st, ids, n, now_time, in, (hipStream_t)stream);
 }
 
 int tpnet_check_errors(const tpnet_state* st, void* stream) {

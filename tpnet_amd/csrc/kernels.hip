@@ -39,6 +39,13 @@ static constexpr int HEAVY_BLOCKS = 32;   // workgroups of a step launch reserve
 // ---------------------------------------------------------------------------------------------------------------
 // helpers
 // ---------------------------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t work_items, int per_block, int cap) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
 template <int W>
 __device__ __forceinline__ void ldv(const float* __restrict__ row, int vi, float* dst) {
     if constexpr (W == 4) {
@@ -522,6 +529,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
                 const Item I = heavy[h];
                 if (h >= D.n_heavy) break;
+                if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
                 update_item_block<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, bid, D.t_last,
                                                   lambda, part);
                 STAMP(7);
@@ -561,13 +569,17 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
                 }
                 u = a.src[e];
             }
-            gram_pair<LPP, VPL, W, L>(S, u, v, valid, bid, D.now, lambda, do_scale, out, gl, p.dbg);
+            // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
+            const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
+            if (!__any(mine)) continue;
+            gram_pair<LPP, VPL, W, L>(S, u, v, mine, bid, D.now, lambda, do_scale, out, gl, p.dbg);
             STAMP(5);
         } else {
             const int64_t it = w - RP;
             Item I = items[it < cap_items ? it : 0];
             if (wave0 - RP >= (int64_t)D.n_light) break;   // wave-uniform: no item of this wave exists (and none later)
-            const bool valid = it < (int64_t)D.n_light;
+            const bool valid = it < (int64_t)D.n_light &&
+                               (a.own_mod <= 1 || (I.target % a.own_mod) == a.own_rem);   // targets belong to their owner
             update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I, valid, bid, D.t_last, lambda, gl);
             STAMP(6);
         }
@@ -704,14 +716,63 @@ __global__ void k_gather_rows(tpnet_state S, const int64_t* __restrict__ ids, in
     }
 }
 
+// row exchange of the sharded state: out[k][i][:] = P[i+1][ids[k]] at `now` (decay applied), i = 0..L-1
+__global__ void k_pack_rows(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now, double lambda,
+                            float* __restrict__ out) {
+    const int64_t d = S.d, L = S.L;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        int64_t id = ids[k];
+        if ((uint64_t)id >= (uint64_t)S.N) {
+            if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+            id = 0;
+        }
+        const MetaView m = read_meta(meta, id, READER_BID, now, lambda);
+        const float* qb = S.q + ((int64_t)m.copy * S.N + id) * (L * d);
+        for (int64_t r = threadIdx.x; r < L * d; r += blockDim.x) {
+            const int64_t i = r / d;
+            float g = m.g;
+            for (int64_t z = 0; z < i; ++z) g *= m.g;
+            out[k * L * d + r] = qb[r] * g;
+        }
+    }
+}
+
+// the inverse: the current copy of row ids[k] <- in[k], expressed at `now` (rows owned by another rank: never the
+// target of a local update, so no launch of this rank rewrites them concurrently)
+__global__ void k_unpack_rows(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now,
+                              const float* __restrict__ in) {
+    const int64_t d = S.d, L = S.L;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const int64_t id = ids[k];
+        if ((uint64_t)id >= (uint64_t)S.N) {
+            if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+            continue;
+        }
+        const int c = (int)(meta[id].ver & 1u);
+        float* qb = S.q + ((int64_t)c * S.N + id) * (L * d);
+        for (int64_t r = threadIdx.x; r < L * d; r += blockDim.x) qb[r] = in[k * L * d + r];
+        if (threadIdx.x == 0) meta[id].tref[c] = now;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
-static inline int grid_for(int64_t work_items, int per_block, int cap) {
-    int64_t g = (work_items + per_block - 1) / per_block;
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    return (int)g;
+int launch_pack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
+                     hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(n, 1, 8192)), dim3(256), 0, s, st, ids, n, now, lambda, out);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_unpack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* in, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(n, 1, 8192)), dim3(256), 0, s, st, ids, n, now, in);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
 }
 
 int launch_state_init(const tpnet_state& st, double t0, hipStream_t s) {

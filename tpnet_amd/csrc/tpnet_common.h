@@ -69,6 +69,8 @@ struct StreamArgs {
     const double* t;
     float* out_pos;
     float* out_neg;
+    int32_t own_mod;   // row sharding: this rank computes targets / pairs (by their src node) with id % own_mod == own_rem
+    int32_t own_rem;   // (own_mod = 1: everything)
 };
 
 // Launch geometry of the fast paths: LPP lanes cooperate on one row (one pair / one target), each lane owning VPL
@@ -98,6 +100,9 @@ int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, 
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s);
 int launch_decay_desc(const tpnet_state& st, const Plan& p, int64_t b, hipStream_t s);
+int launch_pack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
+                     hipStream_t s);
+int launch_unpack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* in, hipStream_t s);
 
 size_t plan_bytes(int64_t max_edges, int64_t batch);
 int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out);
