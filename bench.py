@@ -77,12 +77,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TPNET_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU (development only)
+    backend = os.environ.get("TPNET_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev if backend != "nccl" else local_rank)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import tpnet_amd
     from tpnet_amd import _lib
@@ -91,7 +97,12 @@ def main():
     B, d, L = cfg["B"], cfg["d"], 3
     K, W = args.steps, args.warmup
 
-    src, dst, neg, t, N = make_workload(cfg, W + K, rank)
+    # N = 1: configs[1] as is.  N > 1: the SAME graph row-sharded over the ranks (owner(n) = n % N), weak scaling:
+    # the global batch is N*B edges per step (B per GPU), every rank holds the whole stream, one RCCL all-gather of
+    # the touched rows per step (tpnet_amd/sharded.py).
+    Bg = B * world
+    cfg_run = dict(cfg, B=Bg)
+    src, dst, neg, t, N = make_workload(cfg_run, W + K, 0)
     torch.manual_seed(0)
     P0 = torch.normal(0, 1 / np.sqrt(d), (N, d))
     rp = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=cfg["E"], dim_factor=10, num_layer=L,
@@ -102,24 +113,38 @@ def main():
     to_dev = lambda x: torch.from_numpy(x).to(dev)
     d_src, d_dst, d_neg, d_t = to_dev(src), to_dev(dst), to_dev(neg), to_dev(t)
     NG = rp.pair_wise_feature_dim
-    out_pos = torch.empty((K * B, NG), dtype=torch.float32, device=dev)
-    out_neg = torch.empty((K * B, NG), dtype=torch.float32, device=dev)
+    runner = None
+    if world > 1:
+        from tpnet_amd.sharded import ShardedStreamRunner
+        runner = ShardedStreamRunner(rp)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run(a, b_):
+        sl_ = slice(a * Bg, b_ * Bg)
+        if runner is None:
+            rp.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, out_pos=out_pos[:(b_ - a) * Bg],
+                          out_neg=out_neg[:(b_ - a) * Bg], t_end=float(t[b_ * Bg - 1]))
+        else:
+            t_last = t[np.minimum(np.arange(a + 1, b_ + 1) * Bg, len(t)) - 1]
+            runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last)
+
+    out_pos = out_neg = None
+    if runner is None:
+        out_pos = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
+        out_neg = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
     # warm-up: W untimed steps (also sizes the workspace for the timed call)
-    rp._workspace(K * B, B)
+    rp._workspace(K * Bg, Bg)
     if W > 0:
-        rp.run_stream(d_src[:W * B], d_dst[:W * B], d_neg[:W * B], d_t[:W * B], B, out_pos=out_pos[:W * B],
-                      out_neg=out_neg[:W * B], t_end=float(t[W * B - 1]))
-    sl = slice(W * B, (W + K) * B)
+        run(0, W)
+    sl = slice(W * Bg, (W + K) * Bg)
     a_src, a_dst, a_neg, a_t = d_src[sl], d_dst[sl], d_neg[sl], d_t[sl]
     barrier()
     t0 = time.perf_counter()
-    rp.run_stream(a_src, a_dst, a_neg, a_t, B, out_pos=out_pos, out_neg=out_neg, t_end=float(t[(W + K) * B - 1]))
+    run(W, W + K)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -131,7 +156,7 @@ def main():
     # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side), one extra
     # pass over the same K batches (state keeps advancing; throughput above is not affected)
     roof = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         lib = _lib.load()
         st = rp._state()
         ws = rp._workspace(K * B, B)
@@ -151,18 +176,20 @@ def main():
 
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(cfg, src, dst, neg, t, N, P0.numpy())
-        total_edges = K * B * world
+        total_edges = K * Bg
         line = {
             "metric": "temporal edges/sec (proj-update + pairwise readout)",
             "value": total_edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['desc']}, L=3, synthetic S({cfg['U']},{cfg['I']},E,span) "
-                                   f"stream of {(W + K) * B} edges, decoder-level unit (2 readouts + update per edge)",
-                       "batch": B, "dim": d, "num_layer": L, "nodes": N,
-                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (one stream each)"},
+                                   f"stream of {(W + K) * Bg} edges, decoder-level unit (2 readouts + update per edge)",
+                       "batch": Bg, "dim": d, "num_layer": L, "nodes": N,
+                       "parallelism": "single GPU" if world == 1 else
+                       f"rows sharded over {world} GPUs (owner = id % {world}), global batch {Bg} = {B} per GPU, "
+                       f"one RCCL all-gather of touched rows per step"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
