@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc_<CFG>/{trace,fetch,write} (tools/pmc.sh) into profiles/<name>.md:
+per-kernel durations from the kernel trace, HBM-side traffic of k_step from the PMC passes
+(FETCH_SIZE doubled for gfx950 wide reads as MI355X_MICROARCH.md §HBM prescribes; both counters are in KiB)."""
+import csv, glob, os, sys, statistics as st
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tpnet_amd.stream import CONFIGS, bytes_per_edge
+
+def one(path):
+    f = glob.glob(path)
+    return f[0] if f else None
+
+def main(cfg, tag):
+    base = os.path.join(ROOT, "gpurun_out", f"pmc_{cfg}")
+    c = CONFIGS[cfg]
+    lines = [f"# rocprofv3 summary, {cfg} ({c['desc']}, L=3), {tag}", ""]
+    ks = one(f"{base}/trace/*/*_kernel_stats.csv")
+    lines += ["## kernel-trace --stats (top kernels)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
+    for r in list(csv.DictReader(open(ks)))[:8]:
+        lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
+    tr = [r for r in csv.DictReader(open(one(f"{base}/trace/*/*_kernel_trace.csv"))) if "k_step" in r["Kernel_Name"]]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
+    avg = st.mean(dur)
+    bpl = bytes_per_edge(c["d"], 3) * c["B"]
+    lines += ["", f"k_step: {len(dur)} launches, avg {avg:.0f} ns, median {st.median(dur):.0f} ns; grid {tr[0]['Grid_Size_X']} x {tr[0]['Workgroup_Size_X']}, "
+              f"VGPR {tr[0]['VGPR_Count']}+{tr[0]['Accum_VGPR_Count']}, LDS {tr[0]['LDS_Block_Size']} B",
+              f"algorithmic bytes per launch = {bytes_per_edge(c['d'], 3)} B/edge x {c['B']} = {bpl / 1e6:.2f} MB -> "
+              f"achieved {bpl / avg:.1f} GB/s = {bpl / avg / 8000 * 100:.1f} % of 8 TB/s", ""]
+    res = {}
+    for name in ("fetch", "write"):
+        f = one(f"{base}/{name}/*/*_counter_collection.csv")
+        if not f:
+            continue
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
+        if vals:
+            res[name] = st.mean(vals)
+    if res:
+        fetch_b = res.get("fetch", 0) * 1024 * 2        # gfx950: FETCH_SIZE reads 1/2 of wide coalesced reads
+        write_b = res.get("write", 0) * 1024
+        lines += ["## PMC (separate passes)", "",
+                  f"FETCH_SIZE avg per k_step launch = {res.get('fetch', 0):.1f} KiB (x2 gfx950 correction -> {fetch_b / 1e6:.2f} MB); "
+                  f"WRITE_SIZE avg = {res.get('write', 0):.1f} KiB ({write_b / 1e6:.2f} MB)",
+                  f"memory-side traffic per launch ~ {(fetch_b + write_b) / 1e6:.2f} MB vs algorithmic {bpl / 1e6:.2f} MB "
+                  f"(ratio {(fetch_b + write_b) / bpl:.2f}; the whole state fits the 256 MB Infinity Cache, whose hits are counted)", ""]
+    out = os.path.join(ROOT, "profiles", f"{tag}_{cfg}.md")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    return res, avg
+
+if __name__ == "__main__":
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    for cfg in sys.argv[2:] or ["C2"]:
+        main(cfg, tag)

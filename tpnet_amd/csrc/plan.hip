@@ -142,58 +142,82 @@ __device__ __forceinline__ void contribution(const Plan& p, const int64_t* __res
     partner = ok ? (int32_t)(side ? s : dd) : 0;
 }
 
+// Wave-aggregated append: the lanes with `pred` that share a batch take consecutive slots of that batch's list with
+// ONE atomic per (wave, batch) instead of one per item (a batch's counter is a single hot address otherwise).
+__device__ __forceinline__ uint32_t agg_append(BatchDesc* __restrict__ desc, int64_t b, bool pred, bool heavy) {
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t idx = 0;
+    unsigned long long todo = __ballot(pred);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int64_t bsel = __shfl(b, leader, 64);
+        const unsigned long long grp = __ballot(pred && b == bsel);
+        uint32_t base = 0;
+        if (lane == leader)
+            base = atomicAdd(heavy ? &desc[bsel].n_heavy : &desc[bsel].n_light, (uint32_t)__popcll(grp));
+        base = __shfl(base, leader, 64);
+        if (pred && b == bsel) idx = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
+        todo &= ~grp;
+    }
+    return idx;
+}
+
 __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                          const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N, int node_bits, double lambda,
                          uint32_t heavy_threshold, uint32_t* err) {
     const int64_t nc = 2 * Ec;
     const uint64_t node_mask = (1ull << node_bits) - 1;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = p.keys_out[j];
-        const uint32_t val = p.vals_out[j];
-        const int64_t b = (int64_t)(key >> node_bits);
-        int32_t partner;
-        float w;
-        contribution(p, src, dst, t, Ec, B, N, lambda, val, partner, w, err);
-        p.s_partner[j] = partner;
-        p.s_coef[j] = w;
-        p.s_target[j] = (int32_t)(key & node_mask);
+    for (int64_t jb = (int64_t)blockIdx.x * blockDim.x; jb < nc; jb += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = jb + threadIdx.x;
+        const bool active = j < nc;
+        bool head = false;
+        int64_t b = 0, c0 = 0;
+        Item it;
+        it.j0 = 0; it.cnt = 0; it.target = 0; it.p0 = 0; it.w0 = 0.f; it.p1 = 0; it.w1 = 0.f; it.pad = 0;
+        if (active) {
+            const uint64_t key = p.keys_out[j];
+            const uint32_t val = p.vals_out[j];
+            b = (int64_t)(key >> node_bits);
+            int32_t partner;
+            float w;
+            contribution(p, src, dst, t, Ec, B, N, lambda, val, partner, w, err);
+            p.s_partner[j] = partner;
+            p.s_coef[j] = w;
+            p.s_target[j] = (int32_t)(key & node_mask);
 
-        const int64_t c0 = 2 * b * B;
-        const int64_t ne = (Ec - b * B < B) ? (Ec - b * B) : B;
-        const int64_t cend = c0 + 2 * ne;
-        const bool head = (j == c0) || (p.keys_out[j - 1] != key);
-        if (head) {
-            // run length by galloping + binary search on the sorted keys
-            int64_t lo = j, hi, step = 1;
-            for (;;) {
-                const int64_t nx = lo + step;
-                if (nx >= cend) { hi = cend; break; }
-                if (p.keys_out[nx] != key) { hi = nx; break; }
-                lo = nx;
-                step <<= 1;
-            }
-            while (hi - lo > 1) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (p.keys_out[mid] == key) lo = mid; else hi = mid;
-            }
-            Item it;
-            it.j0 = (uint32_t)j;
-            it.cnt = (uint32_t)(hi - j);
-            it.target = (int32_t)(key & node_mask);
-            it.p0 = partner;
-            it.w0 = w;
-            it.p1 = 0;
-            it.w1 = 0.0f;
-            if (it.cnt >= 2) contribution(p, src, dst, t, Ec, B, N, lambda, p.vals_out[j + 1], it.p1, it.w1, nullptr);
-            it.pad = 0;
-            if (it.cnt > heavy_threshold) {
-                const uint32_t idx = atomicAdd(&p.desc[b].n_heavy, 1u);
-                p.heavy[c0 + idx] = it;
-            } else {
-                const uint32_t idx = atomicAdd(&p.desc[b].n_light, 1u);
-                p.light[c0 + idx] = it;
+            c0 = 2 * b * B;
+            const int64_t ne = (Ec - b * B < B) ? (Ec - b * B) : B;
+            const int64_t cend = c0 + 2 * ne;
+            head = (j == c0) || (p.keys_out[j - 1] != key);
+            if (head) {
+                // run length by galloping + binary search on the sorted keys
+                int64_t lo = j, hi, step = 1;
+                for (;;) {
+                    const int64_t nx = lo + step;
+                    if (nx >= cend) { hi = cend; break; }
+                    if (p.keys_out[nx] != key) { hi = nx; break; }
+                    lo = nx;
+                    step <<= 1;
+                }
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (p.keys_out[mid] == key) lo = mid; else hi = mid;
+                }
+                it.j0 = (uint32_t)j;
+                it.cnt = (uint32_t)(hi - j);
+                it.target = (int32_t)(key & node_mask);
+                it.p0 = partner;
+                it.w0 = w;
+                if (it.cnt >= 2)
+                    contribution(p, src, dst, t, Ec, B, N, lambda, p.vals_out[j + 1], it.p1, it.w1, nullptr);
             }
         }
+        const bool is_heavy = head && it.cnt > heavy_threshold;
+        const bool is_light = head && !is_heavy;
+        const uint32_t il = agg_append(p.desc, b, is_light, false);
+        const uint32_t ih = agg_append(p.desc, b, is_heavy, true);
+        if (is_light) p.light[c0 + il] = it;
+        if (is_heavy) p.heavy[c0 + ih] = it;
     }
 }
 
