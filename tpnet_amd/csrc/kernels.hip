@@ -25,18 +25,8 @@ namespace tpnet {
             }                                                                                              \
         }                                                                                                  \
     } while (0)
-// per-launch span: first wave start / last wave end of launch b (100 MHz wall clock), kept beyond the per-wave slots
-#define SPAN(which)                                                                                        \
-    do {                                                                                                   \
-        if (dbg && (threadIdx.x & 63) == 0 && b < 2048) {                                                  \
-            unsigned long long* sp = dbg + 4000 * 16 + 2 * b;                                              \
-            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                              \
-            if (which) atomicMax(sp + 1, now_); else atomicMin(sp, now_);                                  \
-        }                                                                                                  \
-    } while (0)
 #else
 #define STAMP(slot) do { } while (0)
-#define SPAN(which) do { } while (0)
 #endif
 
 static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (ver >> 1)
@@ -529,7 +519,6 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
     unsigned long long* dbg = p.dbg;
     (void)dbg;
     STAMP(0);
-    SPAN(0);
     // e0/ne come with the launch and the item records are fetched speculatively (their slots always exist), so neither
     // the id loads nor the item loads wait for the descriptor (clocks, item counts): both are in flight together.
     const BatchDesc D = p.desc[b];
@@ -546,7 +535,6 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
                 STAMP(7);
             }
         }
-        SPAN(1);
         return;
     }
     const int gl = threadIdx.x % LPP;
@@ -596,7 +584,6 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             STAMP(6);
         }
     }
-    SPAN(1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
