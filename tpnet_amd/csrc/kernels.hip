@@ -34,7 +34,7 @@ static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (v
 #define TPNET_BLOCK 512
 #endif
 static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the pair/step kernels
-static constexpr int HEAVY_BLOCKS = 32;   // workgroups of a step launch reserved for heavy update items
+static constexpr int HEAVY_BLOCKS = 24;   // workgroups of a step launch reserved for heavy update items
 
 // ---------------------------------------------------------------------------------------------------------------
 // helpers
@@ -151,10 +151,17 @@ struct GramCfg {
     static constexpr int PER = MP / LPP;
 };
 
+// FULL = the row is exactly one chunk (d == LPP*VPL*W): no tail predicate, no chunk loop; callers guarantee that an
+// inactive group points at row 0, so the load itself needs no guard either
+template <int W, bool FULL>
+__device__ __forceinline__ void ldv_maybe(const float* __restrict__ row, int vi, bool ok, float* dst) {
+    if constexpr (FULL) ldv<W>(row, vi, dst); else ldv_pred<W>(row, vi, ok, dst);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pairwise readout of ONE pair by one group of LPP lanes (models/TPNet.py:119-128)
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L>
+template <int LPP, int VPL, int W, int L, bool FULL>
 __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
                                           double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
                                           unsigned long long* dbg = nullptr) {
@@ -194,14 +201,14 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
     for (int i = 0; i < C::MP; ++i) acc[i] = 0.0f;
     STAMP(2);
 
-    for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
         float f[NN][F];
 #pragma unroll
         for (int a = 0; a < NN; ++a) {
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                ldv_pred<W>(rowp[a], vi, vi < nvec, &f[a][j * W]);
+                ldv_maybe<W, FULL>(rowp[a], vi, vi < nvec, &f[a][j * W]);
             }
         }
 #pragma unroll
@@ -249,7 +256,7 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
     }
 }
 
-template <int LPP, int VPL, int W, int L>
+template <int LPP, int VPL, int W, int L, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_t* __restrict__ u,
                                                      const int64_t* __restrict__ v, int64_t n, double now,
                                                      double lambda, uint32_t flags, float* __restrict__ out) {
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
         const int64_t p = base + g;
         const bool valid = p < n;
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
-        gram_pair<LPP, VPL, W, L>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * NG, gl);
+        gram_pair<LPP, VPL, W, L, FULL>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * NG, gl);
     }
 }
 
@@ -278,13 +285,12 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
 // (2) U contributions' rows (U*L vectors per lane) are in flight at once.  All loops are wave-uniform (__any), the
 // per-group bounds only predicate the loads, because the groups of one wave may own different targets.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L>
+template <int LPP, int VPL, int W, int L, int U, bool FULL>
 __device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                                  const float* __restrict__ s_coef, uint32_t jb, uint32_t je,
                                                  uint32_t bid, double t_last, double lambda, int gl, int c0,
                                                  float (&acc)[L][VPL * W]) {
     constexpr int F = VPL * W;
-    constexpr int U = 4;
     const int d = S.d;
     const int nvec = d / W;
     const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
@@ -320,7 +326,7 @@ __device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) {
                         const int vi = c0 + j * LPP + gl;
-                        ldv_pred<W>(rp, vi, ok[k] && vi < nvec, &r[k][i][j * W]);
+                        ldv_maybe<W, FULL>(rp, vi, ok[k] && vi < nvec, &r[k][i][j * W]);
                     }
                 }
             }
@@ -343,25 +349,35 @@ __device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int
     }
 }
 
-// light item: one group owns the target.  Its first two contributions come inside the item record, so the target's
-// meta record and both partners' are fetched together, then all their rows together: three dependent round trips
-// (item -> metas -> rows) for the typical target.
-template <int LPP, int VPL, int W, int L>
+// light item: one group owns the target (at most 2 + LPP contributions: the plan's heavy threshold is far below).
+// The chain of dependent memory round trips is what a small batch pays for, so the loads are staged explicitly:
+//   item record (carries the first two contributions)
+//   -> { meta of target, partner 0, partner 1 }  and  { (partner, weight) of the remaining contributions, one per lane }
+//   -> { rows of target, partner 0, partner 1 }   and  { meta of the remaining partners, one per lane }
+//   -> rows of the remaining partners, U at a time
+template <int LPP, int VPL, int W, int L, bool FULL>
 __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                             const float* __restrict__ s_coef, Item I, bool valid, uint32_t bid,
                                             double t_last, double lambda, int gl) {
     constexpr int F = VPL * W;
+    constexpr int U = 4;
     const int d = S.d;
     const int nvec = d / W;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
     if (!valid) { I.target = 0; I.cnt = 0; I.p0 = 0; I.p1 = 0; I.j0 = 0; }
     const int32_t u = I.target;
     const bool has0 = I.cnt >= 1, has1 = I.cnt >= 2;
-    const int32_t pv[2] = {I.p0, has1 ? I.p1 : 0};
-    const float pw[2] = {I.w0, I.w1};
+    const int32_t pv01[2] = {I.p0, has1 ? I.p1 : 0};
+    const float pw01[2] = {I.w0, I.w1};
+    const uint32_t n_tail = I.cnt > 2 ? I.cnt - 2 : 0;           // contributions j0+2 ..
 
+    // stage 1: metas of the first three nodes + the tail's (partner, weight), lane-parallel
     const MetaView mu = read_meta(meta, u, bid, t_last, lambda);
-    const MetaView mp[2] = {read_meta(meta, pv[0], bid, t_last, lambda), read_meta(meta, pv[1], bid, t_last, lambda)};
+    const MetaView mp[2] = {read_meta(meta, pv01[0], bid, t_last, lambda), read_meta(meta, pv01[1], bid, t_last, lambda)};
+    const bool mine = (uint32_t)gl < n_tail;
+    const int32_t my_pv = mine ? s_partner[I.j0 + 2 + gl] : 0;
+    const float my_w = mine ? s_coef[I.j0 + 2 + gl] : 0.0f;
+
     const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
     float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
     float gu[L];
@@ -369,7 +385,8 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
 #pragma unroll
     for (int i = 1; i < L; ++i) gu[i] = gu[i - 1] * mu.g;
 
-    for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
+        // stage 2: rows of the target and of the first two partners ...
         float acc[L][F];
         float r[2][L][F];
 #pragma unroll
@@ -377,24 +394,27 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                ldv_pred<W>(qold + (int64_t)i * d, vi, valid && vi < nvec, &acc[i][j * W]);
+                ldv_maybe<W, FULL>(qold + (int64_t)i * d, vi, valid && vi < nvec, &acc[i][j * W]);
             }
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const bool okk = (k == 0) ? has0 : has1;
-            const float* r0p = S.p0 + (int64_t)pv[k] * d;
-            const float* rq = S.q + ((int64_t)mp[k].copy * S.N + pv[k]) * ((int64_t)L * d);
+            const float* r0p = S.p0 + (int64_t)pv01[k] * d;
+            const float* rq = S.q + ((int64_t)mp[k].copy * S.N + pv01[k]) * ((int64_t)L * d);
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 const float* rp = (i == 0) ? r0p : rq + (int64_t)(i - 1) * d;
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
                     const int vi = c0 + j * LPP + gl;
-                    ldv_pred<W>(rp, vi, okk && vi < nvec, &r[k][i][j * W]);
+                    ldv_maybe<W, FULL>(rp, vi, okk && vi < nvec, &r[k][i][j * W]);
                 }
             }
         }
+        // ... and, in flight with them, the meta records of the remaining partners (one per lane)
+        const MetaView my_m = read_meta(meta, my_pv, bid, t_last, lambda);
+
 #pragma unroll
         for (int i = 0; i < L; ++i) {
 #pragma unroll
@@ -409,23 +429,70 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
                 for (int i = 0; i < L; ++i) {
 #pragma unroll
                     for (int x = 0; x < F; ++x) {
-                        const float m = (r[k][i][x] * gi) * pw[k];  // (P[i-1][partner], decayed) * time weight (:91-92)
-                        acc[i][x] = acc[i][x] + m;                  // scatter-add, in index order (:93-96)
+                        const float m = (r[k][i][x] * gi) * pw01[k];  // (P[i-1][partner], decayed) * time weight (:91-92)
+                        acc[i][x] = acc[i][x] + m;                    // scatter-add, in index order (:93-96)
                     }
                     gi *= mp[k].g;
                 }
             }
         }
-        if (__any(I.cnt > 2)) {
-            const uint32_t jb = I.j0 + 2, je = (I.cnt > 2) ? I.j0 + I.cnt : I.j0 + 2;
-            accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, jb, je, bid, t_last, lambda, gl, c0, acc);
+        // stage 3: the remaining contributions, U rows-sets at a time, in order
+        for (uint32_t k0 = 0; __any(k0 < n_tail); k0 += U) {
+            int32_t pv[U];
+            float w[U], g[U];
+            int cp[U];
+            bool ok[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int sl = (int)k0 + k;
+                ok[k] = (uint32_t)sl < n_tail && sl < LPP;
+                pv[k] = __shfl(my_pv, sl, LPP);
+                w[k] = __shfl(my_w, sl, LPP);
+                g[k] = __shfl(my_m.g, sl, LPP);
+                cp[k] = __shfl(my_m.copy, sl, LPP);
+            }
+            float rt[U][L][F];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float* r0p = S.p0 + (int64_t)pv[k] * d;
+                const float* rq = S.q + ((int64_t)cp[k] * S.N + pv[k]) * ((int64_t)L * d);
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const float* rp = (i == 0) ? r0p : rq + (int64_t)(i - 1) * d;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        const int vi = c0 + j * LPP + gl;
+                        ldv_maybe<W, FULL>(rp, vi, ok[k] && vi < nvec, &rt[k][i][j * W]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (ok[k]) {
+                    float gi = 1.0f;
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+#pragma unroll
+                        for (int x = 0; x < F; ++x) {
+                            const float m = (rt[k][i][x] * gi) * w[k];
+                            acc[i][x] = acc[i][x] + m;
+                        }
+                        gi *= g[k];
+                    }
+                }
+            }
+        }
+        // more than 2 + LPP contributions on a light item only happens with TPNET_FLAG_SEQUENTIAL (no heavy items)
+        if (__any(n_tail > (uint32_t)LPP)) {
+            const uint32_t jb = I.j0 + 2 + LPP, je = (n_tail > (uint32_t)LPP) ? I.j0 + I.cnt : jb;
+            accumulate_range<LPP, VPL, W, L, 4, FULL>(S, s_partner, s_coef, jb, je, bid, t_last, lambda, gl, c0, acc);
         }
 #pragma unroll
         for (int i = 0; i < L; ++i) {
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                if (valid && vi < nvec) stv<W>(qnew + (int64_t)i * d, vi, &acc[i][j * W]);
+                if (valid && (FULL || vi < nvec)) stv<W>(qnew + (int64_t)i * d, vi, &acc[i][j * W]);
             }
         }
     }
@@ -438,7 +505,7 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
 // heavy item: the whole workgroup owns the target.  Group g sums the g-th slice of the contribution list; the slices'
 // partial sums are added in slice order through LDS (fixed order: results are reproducible run to run, but the
 // association differs from the strictly sequential sum -- TPNET_FLAG_SEQUENTIAL turns heavy items off).
-template <int LPP, int VPL, int W, int L>
+template <int LPP, int VPL, int W, int L, bool FULL>
 __device__ __forceinline__ void update_item_block(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                                   const float* __restrict__ s_coef, int32_t u, uint32_t j0,
                                                   uint32_t cnt, uint32_t bid, double t_last, double lambda,
@@ -458,7 +525,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
     const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
     float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
 
-    for (int c0 = 0; c0 < nvec; c0 += LPP * VPL) {
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
         float acc[L][F];
         float old[L][F];   // the target's pre-batch rows: fetched up front by group 0, consumed after the barrier
 #pragma unroll
@@ -471,7 +538,9 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
                 ldv_pred<W>(qold + (int64_t)i * d, vi, g == 0 && vi < nvec, &old[i][j * W]);
             }
         }
-        accumulate_range<LPP, VPL, W, L>(S, s_partner, s_coef, j0 + lo, j0 + hi, bid, t_last, lambda, gl, c0, acc);
+        // heavy items keep twice as many rows in flight per group (U*L vectors per lane)
+        accumulate_range<LPP, VPL, W, L, 4, FULL>(S, s_partner, s_coef, j0 + lo, j0 + hi, bid, t_last, lambda, gl, c0,
+                                                  acc);
 #pragma unroll
         for (int i = 0; i < L; ++i)
 #pragma unroll
@@ -492,7 +561,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
                     const int vi = c0 + j * LPP + gl;
-                    if (vi < nvec) stv<W>(qnew + (int64_t)i * d, vi, &tot[j * W]);
+                    if (FULL || vi < nvec) stv<W>(qnew + (int64_t)i * d, vi, &tot[j * W]);
                 }
             }
         }
@@ -509,7 +578,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 // Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target); the others walk a work index
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L>
+template <int LPP, int VPL, int W, int L, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, int64_t e0, int32_t ne_,
                                                 double lambda, uint32_t bid, uint32_t flags) {
     constexpr int GPB = BLOCK / LPP;
@@ -530,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
                 const Item I = heavy[h];
                 if (h >= D.n_heavy) break;
                 if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
-                update_item_block<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, bid, D.t_last,
+                update_item_block<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, bid, D.t_last,
                                                   lambda, part);
                 STAMP(7);
             }
@@ -572,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
             const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
             if (!__any(mine)) continue;
-            gram_pair<LPP, VPL, W, L>(S, u, v, mine, bid, D.now, lambda, do_scale, out, gl, p.dbg);
+            gram_pair<LPP, VPL, W, L, FULL>(S, u, v, mine, bid, D.now, lambda, do_scale, out, gl, p.dbg);
             STAMP(5);
         } else {
             const int64_t it = w - RP;
@@ -580,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             if (wave0 - RP >= (int64_t)D.n_light) break;   // wave-uniform: no item of this wave exists (and none later)
             const bool valid = it < (int64_t)D.n_light &&
                                (a.own_mod <= 1 || (I.target % a.own_mod) == a.own_rem);   // targets belong to their owner
-            update_item<LPP, VPL, W, L>(S, p.s_partner, p.s_coef, I, valid, bid, D.t_last, lambda, gl);
+            update_item<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I, valid, bid, D.t_last, lambda, gl);
             STAMP(6);
         }
     }
@@ -822,23 +891,24 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
     return TPNET_OK;
 }
 
-// dispatch over (geometry, L)
-#define TPNET_DISPATCH_L(LPP_, VPL_, W_, CALL)                                  \
+// dispatch over (geometry, L, exact-fit)
+#define TPNET_DISPATCH_L(LPP_, VPL_, W_, FULL_, CALL)                           \
     switch (st.L) {                                                             \
-        case 1: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 1; CALL; } break; \
-        case 2: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 2; CALL; } break; \
-        case 3: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 3; CALL; } break; \
-        case 4: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 4; CALL; } break; \
+        case 1: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 1; constexpr bool FULL = FULL_; CALL; } break; \
+        case 2: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 2; constexpr bool FULL = FULL_; CALL; } break; \
+        case 3: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 3; constexpr bool FULL = FULL_; CALL; } break; \
+        case 4: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 4; constexpr bool FULL = FULL_; CALL; } break; \
         default: return TPNET_ERR_BAD_ARG;                                      \
     }
 #define TPNET_DISPATCH(CALL)                                                    \
     do {                                                                        \
         const Geom gm = pick_geom(st.d);                                        \
-        if (gm.w == 1) { TPNET_DISPATCH_L(64, 1, 1, CALL) }                     \
-        else if (gm.lpp == 16) { TPNET_DISPATCH_L(16, 1, 4, CALL) }             \
-        else if (gm.lpp == 32) { TPNET_DISPATCH_L(32, 1, 4, CALL) }             \
-        else if (gm.vpl == 1) { TPNET_DISPATCH_L(64, 1, 4, CALL) }              \
-        else { TPNET_DISPATCH_L(64, 2, 4, CALL) }                               \
+        const bool full = gm.w == 4 && st.d == gm.lpp * gm.vpl * 4;             \
+        if (gm.w == 1) { TPNET_DISPATCH_L(64, 1, 1, false, CALL) }              \
+        else if (gm.lpp == 16) { if (full) { TPNET_DISPATCH_L(16, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(16, 1, 4, false, CALL) } } \
+        else if (gm.lpp == 32) { if (full) { TPNET_DISPATCH_L(32, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 1, 4, false, CALL) } } \
+        else if (gm.vpl == 1) { if (full) { TPNET_DISPATCH_L(64, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(64, 1, 4, false, CALL) } }  \
+        else { if (full) { TPNET_DISPATCH_L(64, 2, 4, true, CALL) } else { TPNET_DISPATCH_L(64, 2, 4, false, CALL) } }                   \
     } while (0)
 
 int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
@@ -846,20 +916,42 @@ int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, 
     if (n == 0) return TPNET_OK;
     TPNET_DISPATCH(({
         const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
-        hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, u, v, n, now, lambda,
+        hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, u, v, n, now, lambda,
                            flags, out);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }
 
+// resident workgroups of a kernel on this device: occupancy (per CU, from the runtime) x CU count
+template <typename K>
+static int resident_blocks(K kernel) {
+    int dev = 0, cus = 256, per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    return cus * per_cu;
+}
+
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
-    // upper bound of the work indices: 2*ne readout pairs + at most 2*ne distinct targets
-    const int64_t work = 4 * (int64_t)ne + 8;
     TPNET_DISPATCH(({
-        const int grid = HEAVY_BLOCKS + grid_for(work, BLOCK / LPP, 256 * 8);
-        hipLaunchKernelGGL((k_step<LPP, VPL, W, L>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b,
+        constexpr int GPB = BLOCK / LPP;
+        static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL>);
+        // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
+        // chain of dependent memory round trips, so every workgroup should be resident at once (a workgroup that
+        // starts after another one has finished doubles the chain) -- the item slots give way first (a batch
+        // rarely has more than ne distinct light targets; the grid-stride loop covers the rest).
+        const int pair_blocks = grid_for(2 * (int64_t)ne, GPB, 1 << 20);
+        int item_blocks = grid_for(2 * (int64_t)ne, GPB, 1 << 20);
+        const int room = resident - HEAVY_BLOCKS - pair_blocks;
+        const int item_min = grid_for(((int64_t)ne * 3) / 4 + 1, GPB, 1 << 20);
+        if (item_blocks > room) item_blocks = room > item_min ? room : item_min;
+        int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
+        if (grid > HEAVY_BLOCKS + 256 * 8) grid = HEAVY_BLOCKS + 256 * 8;
+        hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b,
                            b * batch, ne, lambda, launch_id, flags);
     }));
     TPNET_HIP_TRY(hipGetLastError());
