@@ -169,9 +169,22 @@ def main():
                                          C.byref(total_ms), C.byref(kern_ms), stream), "time_stream")
         bpe = bytes_per_edge(d, L)
         achieved = bpe * B / (kern_ms.value * 1e-3) / 1e9 if kern_ms.value > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_step (fused readout + update of one batch)",
+        # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (tools/pmc.sh -> profiles/)
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{args.config}_pmc.json"))):
+            try:
+                pj = json.load(open(f))
+                if pj.get("traffic_bytes_per_launch"):
+                    traffic, traffic_src = pj["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+            except Exception:
+                pass
+        roof = {"bound": "hbm", "kernel": "k_step (fused readout + update of one batch; one launch per step)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": bpe * B, "avg_kernel_us": kern_ms.value * 1e3,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bpe * B, "avg_launch_period_us": kern_ms.value * 1e3,
+                "duration_note": "HIP events on the launch stream around the loop of step launches / launches: "
+                                 "kernel duration + inter-kernel boundary (rocprofv3 per-kernel average: profiles/)",
                 "stream_ms_events": total_ms.value}
 
     if rank == 0:

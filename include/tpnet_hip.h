@@ -160,8 +160,9 @@ int tpnet_check_errors(const tpnet_state* st, void* stream);
 
 /* Timing aid for bench.py: elapsed milliseconds of `reps` back-to-back tpnet_run_stream calls measured with
  * hipEvents recorded on `stream` (the stream the kernels run on).  The state is advanced `reps` times; the
- * caller resets it.  kernel_ms_out (may be NULL) receives the summed duration of the per-batch step kernels
- * only, from events around each launch of the LAST rep. */
+ * caller resets it.  kernel_ms_out (may be NULL) receives the average PERIOD of the per-batch step launches of
+ * the last rep: hipEvent pairs around each chunk's loop of step launches (planning kernels excluded) divided by
+ * the number of launches, i.e. kernel duration + the inter-kernel boundary (~1.7 us on MI355X). */
 int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                       const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                       uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,

@@ -8,8 +8,8 @@ sys.path.insert(0, ROOT)
 from tpnet_amd.stream import CONFIGS, bytes_per_edge
 
 def one(path):
-    f = glob.glob(path)
-    return f[0] if f else None
+    f = sorted(glob.glob(path), key=os.path.getmtime)      # several runs may have been merged: newest wins
+    return f[-1] if f else None
 
 def main(cfg, tag):
     base = os.path.join(ROOT, "gpurun_out", f"pmc_{cfg}")
@@ -43,6 +43,13 @@ def main(cfg, tag):
                   f"WRITE_SIZE avg = {res.get('write', 0):.1f} KiB ({write_b / 1e6:.2f} MB)",
                   f"memory-side traffic per launch ~ {(fetch_b + write_b) / 1e6:.2f} MB vs algorithmic {bpl / 1e6:.2f} MB "
                   f"(ratio {(fetch_b + write_b) / bpl:.2f}; the whole state fits the 256 MB Infinity Cache, whose hits are counted)", ""]
+    import json
+    js = {"config": cfg, "kernel": "k_step", "launches": len(dur), "avg_ns": avg, "median_ns": st.median(dur),
+          "algorithmic_bytes_per_launch": bpl,
+          "fetch_size_kib_avg": res.get("fetch"), "write_size_kib_avg": res.get("write"),
+          "traffic_bytes_per_launch": (res.get("fetch", 0) * 1024 * 2 + res.get("write", 0) * 1024) if res else None,
+          "note": "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section); separate --pmc passes"}
+    json.dump(js, open(os.path.join(ROOT, "profiles", f"{tag}_{cfg}_pmc.json"), "w"), indent=1)
     out = os.path.join(ROOT, "profiles", f"{tag}_{cfg}.md")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

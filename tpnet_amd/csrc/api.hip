@@ -33,8 +33,9 @@ static int env_int(const char* name, int dflt) {
 }
 
 struct StepTimer {
-    hipEvent_t* ev = nullptr;  // 2 per launch when per-kernel timing is requested
-    int64_t n = 0, cap = 0;
+    hipEvent_t* ev = nullptr;  // one pair per chunk, around its loop of step launches (plan kernels excluded)
+    int64_t n = 0, cap = 0;    // pairs recorded / available
+    int64_t launches = 0;      // step launches between the recorded pairs
 };
 
 static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int64_t* dst, const int64_t* neg,
@@ -66,6 +67,8 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
         a.own_rem = 0;
         const int64_t nb = (Ec + batch - 1) / batch;
         const bool have_readout = a.out_pos || a.out_neg;
+        const bool timed = timer && timer->n < timer->cap && !(flags & TPNET_FLAG_EAGER_DECAY);
+        if (timed) (void)hipEventRecord(timer->ev[2 * timer->n], s);
         for (int64_t b = 0; b < nb; ++b, ++lid) {
             const int32_t ne = (int32_t)((Ec - b * batch < batch) ? (Ec - b * batch) : batch);
             if (flags & TPNET_FLAG_EAGER_DECAY) {
@@ -79,17 +82,17 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
                 rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | ROLE_UPDATE, s);
                 if (rc) return rc;
             } else {
-                if (timer && timer->n < timer->cap) (void)hipEventRecord(timer->ev[2 * timer->n], s);
                 static const int role_mask = env_int("TPNET_DEV_ROLE_MASK", 3);
                 const uint32_t roles = ((role_mask & 2) ? ROLE_UPDATE : 0u) |
                                        ((have_readout && (role_mask & 1)) ? ROLE_READOUT : 0u);
                 rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | roles, s);
                 if (rc) return rc;
-                if (timer && timer->n < timer->cap) {
-                    (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);
-                    ++timer->n;
-                }
             }
+        }
+        if (timed) {
+            (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);
+            ++timer->n;
+            timer->launches += nb;
         }
     }
     return TPNET_OK;
@@ -287,11 +290,17 @@ int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
     hipEvent_t e0, e1;
     TPNET_HIP_TRY(hipEventCreate(&e0));
     TPNET_HIP_TRY(hipEventCreate(&e1));
+    // event pairs around the step-launch loop of every chunk of the LAST rep (at most 64 chunks)
+    StepTimer tm;
+    tm.cap = 64;
+    std::vector<hipEvent_t> evs((size_t)(2 * tm.cap));
+    for (auto& e : evs) TPNET_HIP_TRY(hipEventCreate(&e));
+    tm.ev = evs.data();
     uint32_t lid = launch_id_base;
     TPNET_HIP_TRY(hipEventRecord(e0, s));
     for (int r = 0; r < reps; ++r) {
         rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, lid, flags, out_pos, out_neg, workspace,
-                             ws_bytes, s, nullptr);
+                             ws_bytes, s, (kernel_ms_out && r == reps - 1) ? &tm : nullptr);
         if (rc) return rc;
         lid += (uint32_t)nb;
     }
@@ -300,29 +309,18 @@ int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
     float ms = 0.f;
     TPNET_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (total_ms_out) *total_ms_out = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-
     if (kernel_ms_out) {
-        // one extra pass with an event pair around every step launch (up to 512 launches): per-kernel durations
-        StepTimer tm;
-        tm.cap = nb < 512 ? nb : 512;
-        std::vector<hipEvent_t> evs((size_t)(2 * tm.cap));
-        for (auto& e : evs) TPNET_HIP_TRY(hipEventCreate(&e));
-        tm.ev = evs.data();
-        rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, lid, flags, out_pos, out_neg, workspace,
-                             ws_bytes, s, &tm);
-        if (rc) return rc;
-        TPNET_HIP_TRY(hipStreamSynchronize(s));
         double sum = 0.0;
         for (int64_t i = 0; i < tm.n; ++i) {
             float k = 0.f;
             TPNET_HIP_TRY(hipEventElapsedTime(&k, evs[2 * i], evs[2 * i + 1]));
             sum += k;
         }
-        *kernel_ms_out = tm.n ? (float)(sum / (double)tm.n) : 0.f;
-        for (auto& e : evs) (void)hipEventDestroy(e);
+        *kernel_ms_out = tm.launches ? (float)(sum / (double)tm.launches) : 0.f;
     }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (auto& e : evs) (void)hipEventDestroy(e);
     return TPNET_OK;
 }
 
