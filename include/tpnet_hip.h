@@ -154,6 +154,12 @@ int tpnet_pack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double
 int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* in,
                       void* stream);
 
+/* All peers' rows in one launch after the all-gather: ids = the batch's touched nodes ordered by (owner, node)
+ * (device int64[n]), recv = device float [G][maxc][L*d] as gathered, offs = device int64[G] start of each owner's
+ * run inside ids.  Rows owned by `me` are skipped. */
+int tpnet_unpack_gathered(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* recv,
+                          int64_t maxc, const int64_t* offs, int32_t G, int32_t me, void* stream);
+
 /* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
  * the last call (and clears the words), TPNET_OK otherwise. */
 int tpnet_check_errors(const tpnet_state* st, void* stream);

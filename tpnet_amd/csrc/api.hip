@@ -264,6 +264,14 @@ int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, doub
     return launch_unpack_rows(*st, ids, n, now_time, in, (hipStream_t)stream);
 }
 
+int tpnet_unpack_gathered(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* recv,
+                          int64_t maxc, const int64_t* offs, int32_t G, int32_t me, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || G < 1 || me < 0 || me >= G || maxc < 0 || (n > 0 && (!ids || !recv || !offs))) return TPNET_ERR_BAD_ARG;
+    return launch_unpack_gathered(*st, ids, n, now_time, recv, maxc, offs, G, me, (hipStream_t)stream);
+}
+
 int tpnet_check_errors(const tpnet_state* st, void* stream) {
     int rc = check_state(st);
     if (rc) return rc;

@@ -826,9 +826,42 @@ __global__ void k_unpack_rows(tpnet_state S, const int64_t* __restrict__ ids, in
     }
 }
 
+// all peers in one launch: ids = the batch's touched nodes ordered by (owner, node); recv = [G][maxc][L*d] as the
+// all-gather delivered it; offs[r] = start of owner r's run inside ids.  Rows owned by `me` are skipped.
+__global__ void k_unpack_gathered(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now,
+                                  const float* __restrict__ recv, int64_t maxc, const int64_t* __restrict__ offs, int G,
+                                  int me) {
+    const int64_t d = S.d, L = S.L;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const int64_t id = ids[k];
+        if ((uint64_t)id >= (uint64_t)S.N) {
+            if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+            continue;
+        }
+        const int r = (int)(id % G);
+        if (r == me) continue;
+        const int64_t slot = k - offs[r];
+        const float* in = recv + ((int64_t)r * maxc + slot) * (L * d);
+        const int c = (int)(meta[id].ver & 1u);
+        float* qb = S.q + ((int64_t)c * S.N + id) * (L * d);
+        for (int64_t x = threadIdx.x; x < L * d; x += blockDim.x) qb[x] = in[x];
+        if (threadIdx.x == 0) meta[id].tref[c] = now;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------
+int launch_unpack_gathered(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* recv,
+                           int64_t maxc, const int64_t* offs, int G, int me, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_unpack_gathered, dim3(grid_for(n, 1, 8192)), dim3(256), 0, s, st, ids, n, now, recv, maxc, offs,
+                       G, me);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 int launch_pack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
                      hipStream_t s) {
     if (n == 0) return TPNET_OK;

@@ -102,6 +102,8 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
 int launch_decay_desc(const tpnet_state& st, const Plan& p, int64_t b, hipStream_t s);
 int launch_pack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
                      hipStream_t s);
+int launch_unpack_gathered(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* recv,
+                           int64_t maxc, const int64_t* offs, int G, int me, hipStream_t s);
 int launch_unpack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* in, hipStream_t s);
 
 size_t plan_bytes(int64_t max_edges, int64_t batch);

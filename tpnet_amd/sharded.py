@@ -10,7 +10,7 @@ owner only.  Per batch:
               clock                                                                    (tpnet_pack_rows)
   2. exchange ONE all-gather of those row bundles (L*d floats per row; the lists are derived from the stream by
               every rank, so no request round is needed)                               (RCCL all_gather)
-  3. unpack   the other ranks' rows into the local table                               (tpnet_unpack_rows)
+  3. unpack   the other ranks' rows into the local table, one launch                    (tpnet_unpack_gathered)
   4. step     the fused kernel restricted to the targets this rank owns and the pairs whose src it owns: all its
               reads are pre-batch rows that are either owned or just refreshed         (tpnet_step_batch)
 
@@ -103,20 +103,27 @@ class ShardedStreamRunner:
         lid0 = rp._next_launch_ids(nb)
         maxc_all = int(counts.max()) if counts.size else 0
         send = torch.zeros((max(maxc_all, 1), row), dtype=torch.float32, device=dev)
+        recv_all = torch.empty((G, max(maxc_all, 1), row), dtype=torch.float32, device=dev)
+        offs_rel = torch.from_numpy(offsets - offsets[:, :1]).to(dev).contiguous()   # [nb, G] owner runs inside a batch
+        tot = counts.sum(axis=1)
         now = rp._now_host
+        nccl = G > 1 and dist.get_backend(self.group) == "nccl"
         for b in range(nb):
             maxc = int(counts[b].max())
             if G > 1 and maxc > 0:
-                c_me, o_me = int(counts[b, me]), int(offsets[b, me])
+                c_me, o_me, o_b = int(counts[b, me]), int(offsets[b, me]), int(offsets[b, 0])
                 _lib.check(lib.tpnet_pack_rows(C.byref(st), nodes[o_me:o_me + c_me].data_ptr() if c_me else None, c_me,
                                                now, lam, send.data_ptr(), stream), "pack_rows")
-                recv = exchange_rows(send[:maxc], maxc, self.group)
-                for r in range(G):
-                    c_r, o_r = int(counts[b, r]), int(offsets[b, r])
-                    if r == me or c_r == 0:
-                        continue
-                    _lib.check(lib.tpnet_unpack_rows(C.byref(st), nodes[o_r:o_r + c_r].data_ptr(), c_r, now,
-                                                     recv[r].data_ptr(), stream), "unpack_rows")
+                # one all-gather of the padded [maxc, L*d] bundles -> recv[G][maxc][L*d] (a dense prefix of recv_all)
+                recv = recv_all.view(-1)[:G * maxc * row].view(G, maxc, row)
+                if nccl:
+                    dist.all_gather_into_tensor(recv, send[:maxc], group=self.group)
+                else:
+                    dist.all_gather([recv[r] for r in range(G)], send[:maxc], group=self.group)
+                # one launch scatters every peer's rows into the local table
+                _lib.check(lib.tpnet_unpack_gathered(C.byref(st), nodes[o_b:o_b + int(tot[b])].data_ptr(), int(tot[b]),
+                                                     now, recv.data_ptr(), maxc, offs_rel[b].data_ptr(), G, me, stream),
+                           "unpack_gathered")
             _lib.check(lib.tpnet_step_batch(C.byref(st), src.data_ptr(), dst.data_ptr(),
                                             neg.data_ptr() if neg is not None else None, t.data_ptr(), E, B, b, lam,
                                             lid0 + b, flags, G, me, out_pos.data_ptr(),
