@@ -153,6 +153,75 @@ def decoder(name, N, d, L, lam, B, seed):
     np.savez_compressed(os.path.join(OUT, name), **out)
 
 
+def call_sequence(name, seed=11):
+    """G8: the reference's own training-step call sequence on a toy graph (train_link_prediction.py:246-261,
+    321-373): TPNet backbone + LinkPredictor_v1 + 'recent' NeighborSampler + random NegativeEdgeSampler, with a
+    recorder around the RandomProjectionModule methods.  Stores the stream, the sampler seeds, and per batch the
+    index arrays of the four get_pair_wise_feature calls, the update arguments and P / now_time afterwards."""
+    from models.TPNet import TPNet
+    from utils.utils import get_neighbor_sampler, NegativeEdgeSampler
+    from utils.DataLoader import Data
+    rng = np.random.RandomState(seed)
+    U, I, E, B, K, L, d, lam = 12, 9, 70, 16, 4, 3, 32, 1e-6
+    src = rng.randint(1, U + 1, E).astype(np.int64)
+    dst = (U + rng.randint(1, I + 1, E)).astype(np.int64)
+    t = np.sort(rng.uniform(0.0, 5.0e5, E)).astype(np.float64)
+    eid = np.arange(1, E + 1).astype(np.int64)
+    N = U + I + 1
+    data = Data(src, dst, t, eid, np.zeros(E))
+    sampler = get_neighbor_sampler(data, sample_neighbor_strategy='recent', time_scaling_factor=0.0, seed=0)
+    neg_sampler = NegativeEdgeSampler(src_node_ids=src, dst_node_ids=dst)            # train sampler: unseeded
+    node_feat = np.zeros((N, 16), dtype=np.float32)
+    edge_feat = rng.randn(E + 1, 16).astype(np.float32)
+    rp = make_rp(N, E, d, L, lam, t[0], seed=seed)
+    out = dict(N=N, U=U, I=I, E=E, B=B, K=K, L=L, d=d, lam=lam, t0=t[0], src=src, dst=dst, t=t, eid=eid,
+               P0=rp.random_projections[0].detach().numpy().copy(), np_seed=1234)
+    calls = []
+    orig_pair, orig_upd = rp.get_pair_wise_feature, rp.update
+
+    def rec_pair(src_node_ids, dst_node_ids):
+        calls.append(("pair", np.array(src_node_ids).copy(), np.array(dst_node_ids).copy()))
+        return orig_pair(src_node_ids=src_node_ids, dst_node_ids=dst_node_ids)
+
+    def rec_upd(src_node_ids, dst_node_ids, node_interact_times):
+        calls.append(("update", np.array(src_node_ids).copy(), np.array(dst_node_ids).copy(),
+                      np.array(node_interact_times).copy()))
+        return orig_upd(src_node_ids=src_node_ids, dst_node_ids=dst_node_ids, node_interact_times=node_interact_times)
+
+    rp.get_pair_wise_feature, rp.update = rec_pair, rec_upd
+    torch.manual_seed(seed)
+    backbone = TPNet(node_raw_features=node_feat, edge_raw_features=edge_feat, neighbor_sampler=sampler,
+                     time_feat_dim=8, random_projections=rp, num_neighbors=K, num_layers=1, dropout=0.0, device='cpu')
+    decoder = LinkPredictor_v1(input_dim1=16, input_dim2=16, hidden_dim=16, output_dim=1, random_projections=rp,
+                               not_encode=False)
+    np.random.seed(int(out["np_seed"]))             # the unseeded negative sampler draws from the global numpy RNG
+    rp.reset_random_projections()                   # epoch start (train_link_prediction.py:246-248)
+    rp.random_projections[0].data = torch.from_numpy(out["P0"]).clone()   # re-inject P[0] (reset redraws it)
+    nb = 0
+    with torch.no_grad():
+        for b0 in range(0, E, B):                   # shuffle=False loader: chronological, ragged tail
+            s = slice(b0, min(b0 + B, E))
+            bs, bd, bt = src[s], dst[s], t[s]
+            _, bneg = neg_sampler.sample(size=len(bs))
+            n0 = len(calls)
+            es, ed = backbone.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt)
+            ns, nd = backbone.compute_src_dst_node_temporal_embeddings(src_node_ids=bs, dst_node_ids=bneg, node_interact_times=bt)
+            decoder(src_node_ids=bs, dst_node_ids=bd, src_node_embeddings=es, dst_node_embeddings=ed)
+            decoder(src_node_ids=bs, dst_node_ids=bneg, src_node_embeddings=ns, dst_node_embeddings=nd)
+            rp.update(src_node_ids=bs, dst_node_ids=bd, node_interact_times=bt)
+            batch_calls = calls[n0:]
+            assert [c[0] for c in batch_calls] == ["pair"] * 4 + ["update"]
+            for k, c in enumerate(batch_calls[:4]):
+                out[f"b{nb}_pair{k}_u"] = c[1]; out[f"b{nb}_pair{k}_v"] = c[2]
+            out[f"b{nb}_neg"] = bneg
+            out[f"b{nb}_upd_src"], out[f"b{nb}_upd_dst"], out[f"b{nb}_upd_t"] = batch_calls[4][1:]
+            out[f"b{nb}_P"] = np.stack([rp.random_projections[i].detach().numpy() for i in range(1, L + 1)])
+            out[f"b{nb}_now"] = rp.now_time.detach().numpy().copy()
+            nb += 1
+    out["nb"] = nb
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
     traj("g1_update_d16_L3.npz", N=64, d=16, L=3, lam=1e-6, nb=8, B=16, seed=1)
@@ -164,4 +233,5 @@ if __name__ == "__main__":
     backup_reload("g5_backup_reload.npz", N=50, d=32, L=3, lam=1e-6, B=20, seed=6)
     traj("g6_use_matrix_N30.npz", N=30, d=-1, L=3, lam=1e-6, nb=5, B=10, seed=8, use_matrix=True)
     decoder("g7_decoder.npz", N=60, d=32, L=3, lam=1e-6, B=12, seed=9)
+    call_sequence("g8_call_sequence.npz")
     print("golden vectors written to", OUT)
