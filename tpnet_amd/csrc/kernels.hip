@@ -11,6 +11,8 @@
 // reproduces the reference's rounding; the Gram uses explicit fmaf.
 #include "tpnet_common.h"
 
+#include <cstdlib>
+
 namespace tpnet {
 
 #ifdef TPNET_STAMPS
@@ -34,7 +36,9 @@ static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (v
 #define TPNET_BLOCK 512
 #endif
 static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the pair/step kernels
-static constexpr int HEAVY_BLOCKS = 24;   // workgroups of a step launch reserved for heavy update items
+// workgroups of a step launch reserved for heavy (item, layer) units: measured optima on MI355X (C2: 36-42, the
+// one-pass grid leaves the rest to pairs and light items; B = 10 000: >= 128, the grid is multi-pass anyway)
+static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_LARGE = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
 // helpers
@@ -502,16 +506,20 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
     }
 }
 
-// heavy item: the whole workgroup owns the target.  Group g sums the g-th slice of the contribution list; the slices'
-// partial sums are added in slice order through LDS (fixed order: results are reproducible run to run, but the
-// association differs from the strictly sequential sum -- TPNET_FLAG_SEQUENTIAL turns heavy items off).
+// heavy item: a whole workgroup computes ONE LAYER of the target's new bundle.  The layers of the update are
+// independent sums (new[i][u] needs only layer i-1 of the partners), so a hub is spread over L workgroups -- L CUs'
+// worth of load bandwidth -- without any reduction across workgroups.  Inside the workgroup, group g sums the g-th
+// slice of the contribution list; the slices' partial sums are added in slice order through LDS (fixed order:
+// reproducible run to run, but the association differs from the strictly sequential sum -- TPNET_FLAG_SEQUENTIAL
+// turns heavy items off).  `layer` = i-1 in 0..L-1; the layer-0 workgroup publishes the new version.
 template <int LPP, int VPL, int W, int L, bool FULL>
 __device__ __forceinline__ void update_item_block(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                                   const float* __restrict__ s_coef, int32_t u, uint32_t j0,
-                                                  uint32_t cnt, uint32_t bid, double t_last, double lambda,
-                                                  float* __restrict__ part /* LDS [L*F][BLOCK] */) {
+                                                  uint32_t cnt, int layer, uint32_t bid, double t_last, double lambda,
+                                                  float* __restrict__ part /* LDS [F][BLOCK] */) {
     constexpr int F = VPL * W;
     constexpr int G = BLOCK / LPP;
+    constexpr int U = 8;
     const int d = S.d;
     const int nvec = d / W;
     const int gl = threadIdx.x % LPP;
@@ -520,54 +528,84 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
     const uint32_t per = (cnt + G - 1) / G;
     const uint32_t lo = (uint32_t)g * per < cnt ? (uint32_t)g * per : cnt;
     const uint32_t hi = lo + per < cnt ? lo + per : cnt;
+    const uint32_t jb = j0 + lo, je = j0 + hi;
 
     const MetaView mu = read_meta(meta, u, bid, t_last, lambda);
-    const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
-    float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
+    const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d) + (int64_t)layer * d;
+    float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d) + (int64_t)layer * d;
+    float gu = mu.g;                                    // target decay of layer (layer+1): g^(layer+1)
+    for (int z = 0; z < layer; ++z) gu *= mu.g;
 
     for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
-        float acc[L][F];
-        float old[L][F];   // the target's pre-batch rows: fetched up front by group 0, consumed after the barrier
+        float acc[F], old[F];
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
+        for (int k = 0; k < F; ++k) acc[k] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < F; ++k) acc[i][k] = 0.0f;
+        for (int j = 0; j < VPL; ++j) {                 // the target's pre-batch row: fetched up front by group 0
+            const int vi = c0 + j * LPP + gl;
+            ldv_pred<W>(qold, vi, g == 0 && vi < nvec, &old[j * W]);
+        }
+        for (uint32_t r0 = jb; __any(r0 < je); r0 += LPP) {
+            // (partner, weight) and the partners' meta records lane-parallel, then U rows in flight per group
+            const uint32_t jm = r0 + (uint32_t)gl;
+            const bool mine = jm < je;
+            const int32_t my_pv = mine ? s_partner[jm] : 0;
+            const float my_w = mine ? s_coef[jm] : 0.0f;
+            const MetaView my_m = read_meta(meta, my_pv, bid, t_last, lambda);
+            float my_g = 1.0f;                          // partner decay of its layer `layer`: g^layer
+            for (int z = 0; z < layer; ++z) my_g *= my_m.g;
+            const uint32_t n_here = (r0 < je) ? ((je - r0 < (uint32_t)LPP) ? je - r0 : (uint32_t)LPP) : 0u;
+            for (uint32_t k0 = 0; __any(k0 < n_here); k0 += U) {
+                float r[U][F], w[U], gg[U];
+                bool ok[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int sl = (int)k0 + k;
+                    ok[k] = (uint32_t)sl < n_here;
+                    const int32_t pv = __shfl(my_pv, sl, LPP);
+                    const int cp = __shfl(my_m.copy, sl, LPP);
+                    w[k] = __shfl(my_w, sl, LPP);
+                    gg[k] = __shfl(my_g, sl, LPP);
+                    const float* rp = (layer == 0) ? S.p0 + (int64_t)pv * d
+                                                   : S.q + ((int64_t)cp * S.N + pv) * ((int64_t)L * d) + (int64_t)(layer - 1) * d;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        const int vi = c0 + j * LPP + gl;
+                        ldv_maybe<W, FULL>(rp, vi, ok[k] && vi < nvec, &r[k][j * W]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (ok[k]) {
+#pragma unroll
+                        for (int x = 0; x < F; ++x) {
+                            const float m = (r[k][x] * gg[k]) * w[k];
+                            acc[x] = acc[x] + m;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < F; ++k) part[k * BLOCK + threadIdx.x] = acc[k];
+        __syncthreads();
+        if (g == 0) {
+            float tot[F];
+#pragma unroll
+            for (int k = 0; k < F; ++k) tot[k] = old[k] * gu;
+            for (int q = 0; q < G; ++q) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) tot[k] = tot[k] + part[k * BLOCK + q * LPP + gl];
+            }
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                ldv_pred<W>(qold + (int64_t)i * d, vi, g == 0 && vi < nvec, &old[i][j * W]);
-            }
-        }
-        // heavy items keep twice as many rows in flight per group (U*L vectors per lane)
-        accumulate_range<LPP, VPL, W, L, 4, FULL>(S, s_partner, s_coef, j0 + lo, j0 + hi, bid, t_last, lambda, gl, c0,
-                                                  acc);
-#pragma unroll
-        for (int i = 0; i < L; ++i)
-#pragma unroll
-            for (int k = 0; k < F; ++k) part[(i * F + k) * BLOCK + threadIdx.x] = acc[i][k];
-        __syncthreads();
-        if (g == 0) {
-            float gi = 1.0f;
-#pragma unroll
-            for (int i = 0; i < L; ++i) {
-                gi *= mu.g;
-                float tot[F];
-#pragma unroll
-                for (int k = 0; k < F; ++k) tot[k] = old[i][k] * gi;
-                for (int gg = 0; gg < G; ++gg) {
-#pragma unroll
-                    for (int k = 0; k < F; ++k) tot[k] = tot[k] + part[(i * F + k) * BLOCK + gg * LPP + gl];
-                }
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const int vi = c0 + j * LPP + gl;
-                    if (FULL || vi < nvec) stv<W>(qnew + (int64_t)i * d, vi, &tot[j * W]);
-                }
+                if (FULL || vi < nvec) stv<W>(qnew, vi, &tot[j * W]);
             }
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (layer == 0 && threadIdx.x == 0) {
         meta[u].tref[mu.copy ^ 1] = t_last;
         meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
     }
@@ -575,32 +613,33 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 
 // ---------------------------------------------------------------------------------------------------------------
 // fused per-batch step: readout (src,dst) and (src,neg) on the pre-batch state + update, ONE launch.
-// Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target); the others walk a work index
+// Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target and layer); the others walk a work index
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, int W, int L, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, int64_t e0, int32_t ne_,
-                                                double lambda, uint32_t bid, uint32_t flags) {
+                                                double lambda, uint32_t bid, uint32_t flags, int HEAVY_BLOCKS) {
     constexpr int GPB = BLOCK / LPP;
     constexpr int GPW = 64 / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
-    __shared__ float part[L * VPL * W * BLOCK];
+    __shared__ float part[VPL * W * BLOCK];
     unsigned long long* dbg = p.dbg;
     (void)dbg;
     STAMP(0);
     // e0/ne come with the launch and the item records are fetched speculatively (their slots always exist), so neither
     // the id loads nor the item loads wait for the descriptor (clocks, item counts): both are in flight together.
     const BatchDesc D = p.desc[b];
-    if (blockIdx.x < HEAVY_BLOCKS) {
+    if ((int)blockIdx.x < HEAVY_BLOCKS) {
         if (flags & ROLE_UPDATE) {
+            // heavy work unit = (item, layer): L consecutive workgroups share an item
             const Item* heavy = p.heavy + 2 * e0;
-            const uint32_t cap = 2u * (uint32_t)ne_;
+            const uint32_t cap = 2u * (uint32_t)ne_ * (uint32_t)L;
             for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
-                const Item I = heavy[h];
-                if (h >= D.n_heavy) break;
+                const Item I = heavy[h / L];
+                if (h / L >= D.n_heavy) break;
                 if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
-                update_item_block<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, bid, D.t_last,
-                                                  lambda, part);
+                update_item_block<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, (int)(h % L),
+                                                        bid, D.t_last, lambda, part);
                 STAMP(7);
             }
         }
@@ -973,6 +1012,8 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
     TPNET_DISPATCH(({
         constexpr int GPB = BLOCK / LPP;
         static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL>);
+        static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
+        const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 2048 ? HEAVY_BLOCKS_SMALL : HEAVY_BLOCKS_LARGE);
         // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
         // chain of dependent memory round trips, so every workgroup should be resident at once (a workgroup that
         // starts after another one has finished doubles the chain) -- the item slots give way first (a batch
@@ -985,7 +1026,7 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
         int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
         if (grid > HEAVY_BLOCKS + 256 * 8) grid = HEAVY_BLOCKS + 256 * 8;
         hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b,
-                           b * batch, ne, lambda, launch_id, flags);
+                           b * batch, ne, lambda, launch_id, flags, HEAVY_BLOCKS);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;

@@ -10,7 +10,7 @@
 
 namespace tpnet {
 
-static constexpr uint32_t HEAVY_THRESHOLD = 6u;  // contributions per target above which an item is "heavy"
+static constexpr uint32_t HEAVY_THRESHOLD = 8u;  // contributions per target above which an item is "heavy"
 
 static inline int ceil_log2_u64(uint64_t x) {
     int b = 0;
@@ -240,12 +240,12 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     size_t tmp = p.sort_tmp_bytes;
     TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
                                             (size_t)nc, 0u, (unsigned)(node_bits + batch_bits), s, false));
-    // heavy threshold: a target with more contributions than this gets a whole workgroup (24 are reserved per launch).
-    // Small batches are bound by the longest dependent chain, so the bar is low (6); big batches are bound by
-    // throughput and by the serial loop of the few heavy workgroups, so only real hubs qualify (measured optimum
-    // ~B/200 on Reddit- and LastFM-shaped streams at B = 10 000).
+    // heavy threshold: a target with more contributions than this gets L workgroups (one per layer).  Small batches are
+    // bound by the longest dependent chain, so the bar is low (8); big batches are bound by throughput and by the serial
+    // loop of the reserved heavy workgroups, so only real hubs qualify (measured optimum ~B/300 on Reddit- and
+    // LastFM-shaped streams at B = 10 000).
     static const char* thr_env = getenv("TPNET_DEV_HEAVY_THRESHOLD");
-    uint32_t thr = (uint32_t)(batch / 200);
+    uint32_t thr = (uint32_t)(batch / 300);
     thr = thr < HEAVY_THRESHOLD ? HEAVY_THRESHOLD : (thr > 128u ? 128u : thr);
     if (thr_env) thr = (uint32_t)atoi(thr_env);
     if (flags & TPNET_FLAG_SEQUENTIAL) thr = 0xFFFFFFFFu;
