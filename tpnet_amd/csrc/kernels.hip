@@ -627,8 +627,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
     (void)dbg;
     STAMP(0);
     // e0/ne come with the launch and the item records are fetched speculatively (their slots always exist), so neither
-    // the id loads nor the item loads wait for the descriptor (clocks, item counts): both are in flight together.
-    const BatchDesc D = p.desc[b];
+    // the id loads nor the item loads wait for the batch descriptor (clocks, item counts).  The descriptor is read
+    // AFTER those vector loads have been issued: it is a scalar load whose wait (lgkmcnt) would otherwise sit in front
+    // of them and put one more memory round trip on every wave's critical path.
+    const BatchDesc* __restrict__ Dp = p.desc + b;
     if ((int)blockIdx.x < HEAVY_BLOCKS) {
         if (flags & ROLE_UPDATE) {
             // heavy work unit = (item, layer): L consecutive workgroups share an item
@@ -636,10 +638,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             const uint32_t cap = 2u * (uint32_t)ne_ * (uint32_t)L;
             for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
                 const Item I = heavy[h / L];
-                if (h / L >= D.n_heavy) break;
+                const uint32_t n_heavy = Dp->n_heavy;
+                const double t_last = Dp->t_last;
+                if (h / L >= n_heavy) break;
                 if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
                 update_item_block<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, (int)(h % L),
-                                                        bid, D.t_last, lambda, part);
+                                                        bid, t_last, lambda, part);
                 STAMP(7);
             }
         }
@@ -677,18 +681,21 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
                 }
                 u = a.src[e];
             }
+            const double now = Dp->now;
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
             const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
             if (!__any(mine)) continue;
-            gram_pair<LPP, VPL, W, L, FULL>(S, u, v, mine, bid, D.now, lambda, do_scale, out, gl, p.dbg);
+            gram_pair<LPP, VPL, W, L, FULL>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg);
             STAMP(5);
         } else {
             const int64_t it = w - RP;
             Item I = items[it < cap_items ? it : 0];
-            if (wave0 - RP >= (int64_t)D.n_light) break;   // wave-uniform: no item of this wave exists (and none later)
-            const bool valid = it < (int64_t)D.n_light &&
+            const int64_t n_light = (int64_t)Dp->n_light;
+            const double t_last = Dp->t_last;
+            if (wave0 - RP >= n_light) break;   // wave-uniform: no item of this wave exists (and none later)
+            const bool valid = it < n_light &&
                                (a.own_mod <= 1 || (I.target % a.own_mod) == a.own_rem);   // targets belong to their owner
-            update_item<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I, valid, bid, D.t_last, lambda, gl);
+            update_item<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, gl);
             STAMP(6);
         }
     }
