@@ -108,28 +108,39 @@ class ShardedStreamRunner:
         tot = counts.sum(axis=1)
         now = rp._now_host
         nccl = G > 1 and dist.get_backend(self.group) == "nccl"
+        # host-side loop: everything per batch is precomputed as plain ints / raw pointers (the loop issues 3 kernel
+        # launches + 1 collective per batch and must not be the bottleneck)
+        stp = C.byref(st)
+        nodes_ptr, send_ptr, recv_ptr = nodes.data_ptr(), send.data_ptr(), recv_all.data_ptr()
+        offs_ptr = offs_rel.data_ptr()
+        cnt_me = counts[:, me].tolist(); off_me = offsets[:, me].tolist(); off_0 = offsets[:, 0].tolist()
+        maxcs = counts.max(axis=1).tolist(); tots = tot.tolist(); t_last_l = [float(x) for x in t_last]
+        src_p, dst_p, t_p = src.data_ptr(), dst.data_ptr(), t.data_ptr()
+        neg_p = neg.data_ptr() if neg is not None else None
+        op_p = out_pos.data_ptr(); on_p = out_neg.data_ptr() if out_neg is not None else None
+        ws_p, ws_n = ws.data_ptr(), ws.numel()
+        pack, unpack, step = lib.tpnet_pack_rows, lib.tpnet_unpack_gathered, lib.tpnet_step_batch
+        flat_recv = recv_all.view(-1)
         for b in range(nb):
-            maxc = int(counts[b].max())
+            maxc = maxcs[b]
             if G > 1 and maxc > 0:
-                c_me, o_me, o_b = int(counts[b, me]), int(offsets[b, me]), int(offsets[b, 0])
-                _lib.check(lib.tpnet_pack_rows(C.byref(st), nodes[o_me:o_me + c_me].data_ptr() if c_me else None, c_me,
-                                               now, lam, send.data_ptr(), stream), "pack_rows")
+                rc = pack(stp, nodes_ptr + 8 * off_me[b], cnt_me[b], now, lam, send_ptr, stream)
+                if rc:
+                    _lib.check(rc, "pack_rows")
                 # one all-gather of the padded [maxc, L*d] bundles -> recv[G][maxc][L*d] (a dense prefix of recv_all)
-                recv = recv_all.view(-1)[:G * maxc * row].view(G, maxc, row)
+                recv = flat_recv[:G * maxc * row]
                 if nccl:
-                    dist.all_gather_into_tensor(recv, send[:maxc], group=self.group)
+                    dist.all_gather_into_tensor(recv, send[:maxc].view(-1), group=self.group)
                 else:
-                    dist.all_gather([recv[r] for r in range(G)], send[:maxc], group=self.group)
+                    dist.all_gather(list(recv.view(G, maxc * row).unbind(0)), send[:maxc].view(-1), group=self.group)
                 # one launch scatters every peer's rows into the local table
-                _lib.check(lib.tpnet_unpack_gathered(C.byref(st), nodes[o_b:o_b + int(tot[b])].data_ptr(), int(tot[b]),
-                                                     now, recv.data_ptr(), maxc, offs_rel[b].data_ptr(), G, me, stream),
-                           "unpack_gathered")
-            _lib.check(lib.tpnet_step_batch(C.byref(st), src.data_ptr(), dst.data_ptr(),
-                                            neg.data_ptr() if neg is not None else None, t.data_ptr(), E, B, b, lam,
-                                            lid0 + b, flags, G, me, out_pos.data_ptr(),
-                                            out_neg.data_ptr() if out_neg is not None else None, ws.data_ptr(),
-                                            ws.numel(), stream), "step_batch")
-            now = float(t_last[b])
+                rc = unpack(stp, nodes_ptr + 8 * off_0[b], tots[b], now, recv_ptr, maxc, offs_ptr + 8 * G * b, G, me, stream)
+                if rc:
+                    _lib.check(rc, "unpack_gathered")
+            rc = step(stp, src_p, dst_p, neg_p, t_p, E, B, b, lam, lid0 + b, flags, G, me, op_p, on_p, ws_p, ws_n, stream)
+            if rc:
+                _lib.check(rc, "step_batch")
+            now = t_last_l[b]
         rp._now_host = now
         rp._params_valid = False
         rp._parameters["now_time"].data.fill_(now)
