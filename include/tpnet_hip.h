@@ -106,6 +106,13 @@ int tpnet_gather_rows(const tpnet_state* st, const int64_t* ids, int64_t n, doub
 int tpnet_pair_gram(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
                     double lambda, uint32_t flags, float* out, void* stream);
 
+/* Two pairwise readouts that share their first node, u's rows loaded once: out1[p] = G(u_p, v1_p), out2[p] =
+ * G(u_p, v2_p) (same layout and scaling as tpnet_pair_gram).  This is the shape of the reference's callers: the
+ * decoder's (src,dst)/(src,neg) pairs (models/modules.py:112) and the encoder's relative encodings, where every
+ * neighbour is paired with the edge's src AND dst (models/TPNet.py:311-316). */
+int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_t* v1, const int64_t* v2, int64_t n,
+                           double now_time, double lambda, uint32_t flags, float* out1, float* out2, void* stream);
+
 /* Workspace for tpnet_update / tpnet_run_stream with at most max_edges edges per call. */
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
 

@@ -333,3 +333,42 @@ def test_c2_properties(c2):
                                    dev(c2["t"], a, b), c["B"]))
     assert torch.equal(torch.cat([outs[0][0], outs[1][0]]), fp1)
     np.testing.assert_array_equal(_layers(rp4), _layers(rp1))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# shared-first-node readout (the encoder's tile/repeat pattern, models/TPNet.py:313-316)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,L", [(128, 3), (64, 2), (256, 3), (120, 3), (512, 1), (30, 4)])
+def test_shared_first_node_readout(d, L):
+    """pair_gram_shared(w, a, b) == (pair_gram(w, a), pair_gram(w, b)); get_pair_wise_feature takes that path
+    automatically for the encoder's index pattern and returns the reference's row order."""
+    _need_gpu()
+    rng = np.random.RandomState(d + L)
+    N, B, K = 300, 24, 5
+    src, dst, neg, t = _random_stream(rng, N, 6 * B, 2.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    rp = _module(N, d, L, 2e-6, t[0], P0=P0)
+    st = O.OracleState(P0, L, 2e-6, t[0])
+    for b in range(5):
+        s = slice(b * B, (b + 1) * B)
+        rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
+    s = slice(5 * B, 6 * B)
+    neigh = rng.randint(0, N, (2 * B, K)); neigh[rng.rand(2 * B, K) < 0.3] = 0
+    w = neigh.reshape(-1)
+    a = np.repeat(np.tile(src[s], 2), K); b_ = np.repeat(np.tile(dst[s], 2), K)
+    g1, g2 = rp.pair_gram_shared(w, a, b_)
+    r1, r2 = rp.pair_gram(w, a), rp.pair_gram(w, b_)
+    if d in (64, 128, 256, 512):                      # one chunk: the very same fma chains
+        assert torch.equal(g1, r1) and torch.equal(g2, r2)
+    else:
+        np.testing.assert_allclose(g1.cpu().numpy(), r1.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(g2.cpu().numpy(), r2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    _assert_features(g1.cpu().numpy(), st, w, a)
+    _assert_features(g2.cpu().numpy(), st, w, b_)
+    # the reference's call: src = tile(neigh, 2), dst = [repeat(tile(src,2),K); repeat(tile(dst,2),K)]
+    rp.mlp = torch.nn.Identity()
+    full = rp.get_pair_wise_feature(np.tile(w, 2), np.concatenate([a, b_]))
+    assert torch.equal(full, torch.cat([g1, g2], dim=0))
+    # a pair list that only looks similar must take the generic path and still be right
+    odd = rp.get_pair_wise_feature(np.concatenate([w, w[::-1]]), np.concatenate([a, b_]))
+    _assert_features(odd.cpu().numpy()[len(w):], st, w[::-1], b_)

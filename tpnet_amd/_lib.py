@@ -42,6 +42,7 @@ SIGNATURES = {
     "tpnet_decay": (C.c_int, [_SP, C.POINTER(C.c_float), C.c_double, _P]),
     "tpnet_gather_rows": (C.c_int, [_SP, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "tpnet_pair_gram": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P]),
+    "tpnet_pair_gram_shared": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P, _P]),
     "tpnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_uint32,
                                C.c_uint32, _P, C.c_size_t, _P]),

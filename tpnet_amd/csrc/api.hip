@@ -175,6 +175,14 @@ int tpnet_pair_gram(const tpnet_state* st, const int64_t* u, const int64_t* v, i
     return launch_pair_gram(*st, u, v, n, now_time, lambda, flags, out, (hipStream_t)stream);
 }
 
+int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_t* v1, const int64_t* v2, int64_t n,
+                           double now_time, double lambda, uint32_t flags, float* out1, float* out2, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!u || !v1 || !v2 || !out1 || !out2))) return TPNET_ERR_BAD_ARG;
+    return launch_pair_gram_shared(*st, u, v1, v2, n, now_time, lambda, flags, out1, out2, (hipStream_t)stream);
+}
+
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
 
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,

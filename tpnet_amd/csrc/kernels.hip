@@ -278,6 +278,183 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// pairwise readout of TWO pairs that share their first node: out1 = G(u, v1), out2 = G(u, v2).  u's rows are loaded
+// once.  This is the shape of both callers of the readout: the decoder's (src,dst) / (src,neg) pairs
+// (models/modules.py:112, train_link_prediction.py:359-368) and the encoder's relative encodings, where every
+// neighbour w is paired with the edge's src AND dst (models/TPNet.py:311-316: first half of the pair list =
+// G(w, src), second half = G(w, dst)).
+// ---------------------------------------------------------------------------------------------------------------
+// Only the distinct inner products are formed and reduced, in ONE recursive-halving pass for both outputs:
+//   slots = [ u.u (tri) | u.v1 (R*R) | u.v2 (R*R) | v1.v1 (tri) | v2.v2 (tri) ],  R = L+1, tri = R(R+1)/2
+// = 62 slots at L = 3 (one 64-value reduction instead of two, 62 dot products instead of 72, 12 row loads instead of
+// 16); afterwards every lane picks the (at most two per output) slots its output elements mirror from by shuffles.
+template <int LPP, int L>
+struct SharedCfg {
+    static constexpr int R = L + 1;
+    static constexpr int TRI = R * (R + 1) / 2;
+    static constexpr int O_UU = 0, O_UV1 = TRI, O_UV2 = TRI + R * R, O_V1 = TRI + 2 * R * R, O_V2 = 2 * TRI + 2 * R * R;
+    static constexpr int NS = 3 * TRI + 2 * R * R;
+    static constexpr int MPS = ((NS + LPP - 1) / LPP) * LPP;
+    static constexpr int PERS = MPS / LPP;
+    static constexpr __host__ __device__ int tri(int i, int j) { return i * R - i * (i - 1) / 2 + (j - i); }   // i <= j
+};
+
+template <int LPP, int VPL, int W, int L, bool FULL>
+__device__ __forceinline__ void gram_shared(const tpnet_state& S, int64_t u, int64_t v1, int64_t v2, bool valid,
+                                            uint32_t bid, double now, double lambda, bool do_scale,
+                                            float* __restrict__ out1, float* __restrict__ out2, int gl) {
+    using C = GramCfg<LPP, L>;
+    using SC = SharedCfg<LPP, L>;
+    constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
+    const int d = S.d;
+    const int nvec = d / W;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+
+    bool idok = valid && (uint64_t)u < (uint64_t)S.N && (uint64_t)v1 < (uint64_t)S.N && (uint64_t)v2 < (uint64_t)S.N;
+    if (valid && !idok && gl == 0) atomicAdd(S.err, 1u);
+    if (!idok) { u = 0; v1 = 0; v2 = 0; }
+
+    const float* rowp[3][NR];
+    float rs[3][NR];
+    {
+        const int64_t ids[3] = {u, v1, v2};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const MetaView m = read_meta(meta, ids[s], bid, now, lambda);
+            rowp[s][0] = S.p0 + ids[s] * (int64_t)d;
+            rs[s][0] = 1.0f;
+            const float* qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
+            float g = 1.0f;
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+                g *= m.g;
+                rowp[s][i] = qb + (int64_t)(i - 1) * d;
+                rs[s][i] = g;
+            }
+        }
+    }
+    float acc[SC::MPS];
+#pragma unroll
+    for (int i = 0; i < SC::MPS; ++i) acc[i] = 0.0f;
+
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
+        float f[3][NR][F];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const int vi = c0 + j * LPP + gl;
+                    ldv_maybe<W, FULL>(rowp[s][a], vi, vi < nvec, &f[s][a][j * W]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int a = 1; a < NR; ++a) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) f[s][a][k] *= rs[s][a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+#pragma unroll
+            for (int b = a; b < NR; ++b) {
+                float s0 = acc[SC::O_UU + SC::tri(a, b)], s1 = acc[SC::O_V1 + SC::tri(a, b)],
+                      s2 = acc[SC::O_V2 + SC::tri(a, b)];
+#pragma unroll
+                for (int k = 0; k < F; ++k) {
+                    s0 = fmaf(f[0][a][k], f[0][b][k], s0);
+                    s1 = fmaf(f[1][a][k], f[1][b][k], s1);
+                    s2 = fmaf(f[2][a][k], f[2][b][k], s2);
+                }
+                acc[SC::O_UU + SC::tri(a, b)] = s0;
+                acc[SC::O_V1 + SC::tri(a, b)] = s1;
+                acc[SC::O_V2 + SC::tri(a, b)] = s2;
+            }
+#pragma unroll
+            for (int b = 0; b < NR; ++b) {
+                float s1 = acc[SC::O_UV1 + a * NR + b], s2 = acc[SC::O_UV2 + a * NR + b];
+#pragma unroll
+                for (int k = 0; k < F; ++k) {
+                    s1 = fmaf(f[0][a][k], f[1][b][k], s1);
+                    s2 = fmaf(f[0][a][k], f[2][b][k], s2);
+                }
+                acc[SC::O_UV1 + a * NR + b] = s1;
+                acc[SC::O_UV2 + a * NR + b] = s2;
+            }
+        }
+    }
+    Halve<SC::MPS, LPP / 2>::run(acc, gl);        // lane gl now holds the complete sums of slots [gl*PERS, ...)
+
+    // output element idx = a*NN + b of the two Gram matrices -> the slot it comes from
+#pragma unroll
+    for (int k = 0; k < C::PER; ++k) {
+        int idx = gl * C::PER + k;
+        const bool in = idx < C::NG;
+        idx = in ? idx : 0;
+        const int a = idx / NN, b = idx - a * NN;
+        int s1, s2;
+        if (a < NR && b < NR) {
+            const int i = a < b ? a : b, j = a < b ? b : a;
+            s1 = s2 = SC::O_UU + SC::tri(i, j);
+        } else if (a < NR) {                       // (u row a, v row b-NR)
+            s1 = SC::O_UV1 + a * NR + (b - NR);
+            s2 = SC::O_UV2 + a * NR + (b - NR);
+        } else if (b < NR) {                       // mirrored
+            s1 = SC::O_UV1 + b * NR + (a - NR);
+            s2 = SC::O_UV2 + b * NR + (a - NR);
+        } else {
+            const int x = a - NR, y = b - NR;
+            const int i = x < y ? x : y, j = x < y ? y : x;
+            s1 = SC::O_V1 + SC::tri(i, j);
+            s2 = SC::O_V2 + SC::tri(i, j);
+        }
+        float x1 = 0.0f, x2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SC::PERS; ++j) {
+            const float t1 = __shfl(acc[j], s1 / SC::PERS, LPP);
+            const float t2 = __shfl(acc[j], s2 / SC::PERS, LPP);
+            x1 = (s1 % SC::PERS == j) ? t1 : x1;
+            x2 = (s2 % SC::PERS == j) ? t2 : x2;
+        }
+        if (do_scale) {
+            x1 = (x1 < 0.0f) ? 0.0f : x1;          // NaN < 0 is false: NaN passes through (:127)
+            x2 = (x2 < 0.0f) ? 0.0f : x2;
+            x1 = logf(x1 + 1.0f);                  // log(x + 1), not log1p (:128)
+            x2 = logf(x2 + 1.0f);
+        }
+        if (!idok) { x1 = __builtin_nanf(""); x2 = x1; }
+        if (valid && in) {
+            out1[idx] = x1;
+            out2[idx] = x2;
+        }
+    }
+}
+
+template <int LPP, int VPL, int W, int L, bool FULL>
+__global__ __launch_bounds__(BLOCK) void k_pair_gram_shared(tpnet_state S, const int64_t* __restrict__ u,
+                                                            const int64_t* __restrict__ v1,
+                                                            const int64_t* __restrict__ v2, int64_t n, double now,
+                                                            double lambda, uint32_t flags, float* __restrict__ out1,
+                                                            float* __restrict__ out2) {
+    constexpr int GPB = BLOCK / LPP;
+    constexpr int NG = GramCfg<LPP, L>::NG;
+    const int gl = threadIdx.x % LPP;
+    const int g = threadIdx.x / LPP;
+    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
+        const int64_t p = base + g;
+        const bool valid = p < n;
+        const int64_t uu = valid ? u[p] : 0, a1 = valid ? v1[p] : 0, a2 = valid ? v2[p] : 0;
+        gram_shared<LPP, VPL, W, L, FULL>(S, uu, a1, a2, valid, READER_BID, now, lambda, do_scale, out1 + p * NG,
+                                          out2 + p * NG, gl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // update (models/TPNet.py:90-96, all layers at once) of ONE target node u:
 //   new[i][u] = old[i][u] * g_u^i  +  sum_j  w_j * ( P[i-1][partner_j] * g_partner^(i-1) ),   i = 1..L
 // Contributions are summed in sorted order = the reference's index order (src-side edges, then dst-side edges).
@@ -655,6 +832,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
     const int64_t ne = ne_;
     const int64_t npos = ((flags & ROLE_READOUT) && a.out_pos) ? ne : 0;
     const int64_t nneg = ((flags & ROLE_READOUT) && a.out_neg) ? ne : 0;
+    // (a shared-src unit per edge -- gram_shared -- was measured here: it halves the readout waves but doubles each
+    // wave's VALU chain: C1 +30 %, C2 +5 % slower, C3/C5 +1 % faster; the pair stays the unit)
     const int64_t npairs = npos + nneg;
     const int64_t RP = (npairs + GPW - 1) / GPW * GPW;
     const int64_t cap_items = (flags & ROLE_UPDATE) ? 2 * ne : 0;   // upper bound of the light items (slots exist)
@@ -1012,6 +1191,18 @@ static int resident_blocks(K kernel) {
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return cus * per_cu;
+}
+
+int launch_pair_gram_shared(const tpnet_state& st, const int64_t* u, const int64_t* v1, const int64_t* v2, int64_t n,
+                            double now, double lambda, uint32_t flags, float* out1, float* out2, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    TPNET_DISPATCH(({
+        const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
+        hipLaunchKernelGGL((k_pair_gram_shared<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, u, v1, v2, n,
+                           now, lambda, flags, out1, out2);
+    }));
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
 }
 
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,

@@ -283,9 +283,35 @@ class RandomProjectionModule(nn.Module):
                    "pair_gram")
         return out
 
+    def pair_gram_shared(self, node_ids: np.ndarray, first_ids: np.ndarray, second_ids: np.ndarray):
+        """Two readouts that share their first node, whose rows are fetched once: (G(node, first), G(node, second)),
+        each [n, (2L+2)^2] before self.mlp."""
+        self._ensure_engine()
+        if not (len(node_ids) == len(first_ids) == len(second_ids)):
+            raise ValueError("node_ids, first_ids and second_ids must have the same length")
+        u, v1, v2 = self._to_device(self._check_ids(node_ids, "node_ids"), self._check_ids(first_ids, "first_ids"),
+                                    self._check_ids(second_ids, "second_ids"))
+        n = u.numel()
+        out = torch.empty((2, n, self.pair_wise_feature_dim), dtype=torch.float32, device=self._dev())
+        st = self._state()
+        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        _lib.check(_lib.load().tpnet_pair_gram_shared(C.byref(st), u.data_ptr(), v1.data_ptr(), v2.data_ptr(), n,
+                                                      self._now_host, float(self.time_decay_weight), flags,
+                                                      out[0].data_ptr(), out[1].data_ptr(), self._stream()),
+                   "pair_gram_shared")
+        return out[0], out[1]
+
     def get_pair_wise_feature(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray):
         """models/TPNet.py:112-129.  No gradient flows into the projections (requires_grad=False in the
-        reference, :49-62); self.mlp stays a trainable torch module."""
+        reference, :49-62); self.mlp stays a trainable torch module.
+        The encoder calls this with src_node_ids = tile(neighbours, 2) (models/TPNet.py:313-316): when the two halves
+        of src_node_ids are equal, each neighbour's rows are fetched once for both of its pairs."""
+        src = np.asarray(src_node_ids)
+        n = len(src)
+        if n >= 2 and n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:]):
+            dst = np.asarray(dst_node_ids)
+            g1, g2 = self.pair_gram_shared(src[: n // 2], dst[: n // 2], dst[n // 2:])
+            return self.mlp(torch.cat([g1, g2], dim=0))
         return self.mlp(self.pair_gram(src_node_ids, dst_node_ids))
 
     def reset_random_projections(self):
