@@ -130,7 +130,8 @@ def main():
                           out_neg=out_neg[:(b_ - a) * Bg], t_end=float(t[b_ * Bg - 1]))
         else:
             t_last = t[np.minimum(np.arange(a + 1, b_ + 1) * Bg, len(t)) - 1]
-            runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last)
+            # features stay sharded by the owner of the pair's src node (a sharded decoder consumes them in place)
+            runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last, merge_outputs=False)
 
     out_pos = out_neg = None
     if runner is None:

@@ -72,9 +72,10 @@ class ShardedStreamRunner:
     def owned_nodes(self):
         return torch.arange(self.me, self.rp.node_num, self.G, dtype=torch.int64, device=self.rp._dev())
 
-    def run_stream(self, src, dst, neg, t, batch_size: int, t_host_last=None):
-        """Same contract as RandomProjectionModule.run_stream, over all ranks.  Returns (feat_pos, feat_neg), complete
-        on every rank."""
+    def run_stream(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
+        """Same contract as RandomProjectionModule.run_stream, over all ranks.  Returns (feat_pos, feat_neg): complete
+        on every rank if merge_outputs (one all-reduce of disjoint rows at the end), otherwise each rank holds the
+        rows of the pairs whose src node it owns and zeros elsewhere (a sharded consumer needs no merge)."""
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
@@ -144,7 +145,7 @@ class ShardedStreamRunner:
         rp._now_host = now
         rp._params_valid = False
         rp._parameters["now_time"].data.fill_(now)
-        if G > 1:
+        if G > 1 and merge_outputs:
             dist.all_reduce(out_pos, group=self.group)          # disjoint rows: the sum is a merge
             if out_neg is not None:
                 dist.all_reduce(out_neg, group=self.group)
