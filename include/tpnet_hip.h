@@ -167,6 +167,19 @@ int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, doub
 int tpnet_unpack_gathered(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* recv,
                           int64_t maxc, const int64_t* offs, int32_t G, int32_t me, void* stream);
 
+/* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
+ * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,
+ * per node sorted by time (stable: ties keep the reference's append order), neighbours strictly BEFORE the query
+ * time, the K most recent at the back of the row, zeros in front. */
+size_t tpnet_sampler_bytes(int64_t E, int64_t num_nodes);
+/* sampler: caller-owned device buffer of tpnet_sampler_bytes(E, num_nodes); src/dst/t (and optional edge_ids, NULL =
+ * 1..E) are device arrays of E interactions; num_nodes = largest node id + 1. */
+int tpnet_sampler_build(void* sampler, size_t sampler_bytes, const int64_t* src, const int64_t* dst, const double* t,
+                        const int64_t* edge_ids, int64_t E, int64_t num_nodes, void* stream);
+/* out_ids [n][K] int64 (required), out_eids [n][K] int64 and out_times [n][K] double (optional, may be NULL). */
+int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const int64_t* node_ids, const double* times,
+                        int64_t n, int32_t K, int64_t* out_ids, int64_t* out_eids, double* out_times, void* stream);
+
 /* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
  * the last call (and clears the words), TPNET_OK otherwise. */
 int tpnet_check_errors(const tpnet_state* st, void* stream);

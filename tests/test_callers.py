@@ -164,3 +164,49 @@ def test_decoder_logits_match_reference(golden_dir):
     out = dec(src_node_ids=g["u"], dst_node_ids=g["v"], src_node_embeddings=torch.from_numpy(g["src_emb"]).to("cuda:0"),
               dst_node_embeddings=torch.from_numpy(g["dst_emb"]).to("cuda:0"))
     np.testing.assert_allclose(out.detach().cpu().numpy(), g["logits"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,N,E,K", [(0, 40, 300, 5), (1, 500, 5000, 20), (2, 7, 60, 3), (3, 30, 0, 4)])
+def test_gpu_recent_sampler_matches_host_restatement(seed, N, E, K):
+    """f-3: the device sampler against RecentNeighborSampler (itself pinned to the reference's NeighborSampler through
+    fixture G8): ties in time, nodes without history, queries before the first edge, ids outside the graph."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd.sampler import GpuRecentNeighborSampler
+    rng = np.random.RandomState(seed)
+    src = rng.randint(1, N, E).astype(np.int64)
+    dst = rng.randint(1, N, E).astype(np.int64)
+    t = np.sort(np.round(rng.uniform(0, 50.0, E), 0 if seed != 1 else 3))       # many equal timestamps
+    if E:
+        dst[::11] = src[::11]                                                    # self loops
+    gpu = GpuRecentNeighborSampler(src, dst, t, num_nodes=N + 3)
+    host = RecentNeighborSampler(src, dst, t) if E else None
+    q_nodes = rng.randint(0, N + 3, 400).astype(np.int64)
+    q_times = np.concatenate([rng.uniform(-1.0, 60.0, 300), rng.choice(t, 100) if E else rng.uniform(0, 1, 100)])
+    got = gpu.get_historical_neighbors(q_nodes, q_times, K)
+    if host is None:
+        assert all(np.all(g == 0) for g in got)
+        return
+    want = host.get_historical_neighbors(q_nodes, q_times, K)
+    for g, w, name in zip(got, want, ("neighbour ids", "edge ids", "times")):
+        np.testing.assert_array_equal(g, w, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_gpu_sampler_reproduces_reference_call_sequence(golden_dir):
+    """The G8 epoch again, with the device sampler in the loop instead of the host one."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd.sampler import GpuRecentNeighborSampler
+    g = _g8(golden_dir)
+    src, dst, t = g["src"], g["dst"], g["t"]
+    rec = _Recorder()
+    np.random.seed(int(g["np_seed"]))
+    run_epoch(rec, GpuRecentNeighborSampler(src, dst, t, g["eid"]), RandomNegativeSampler(src, dst), src, dst, t,
+              int(g["B"]), int(g["K"]))
+    calls = rec.calls[1:]
+    for b in range(int(g["nb"])):
+        for k in range(4):
+            np.testing.assert_array_equal(calls[5 * b + k][1], g[f"b{b}_pair{k}_u"])
+            np.testing.assert_array_equal(calls[5 * b + k][2], g[f"b{b}_pair{k}_v"])
