@@ -180,6 +180,14 @@ int tpnet_sampler_build(void* sampler, size_t sampler_bytes, const int64_t* src,
 int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const int64_t* node_ids, const double* times,
                         int64_t n, int32_t K, int64_t* out_ids, int64_t* out_eids, double* out_times, void* stream);
 
+/* ---- the step behind the path (BASELINE config 5): self.mlp = Linear(64,256)->ReLU->Linear(256,64)
+ * (models/TPNet.py:64-65,129) fused in one kernel on the bf16 matrix cores, fp32 accumulate, L = 3 only.
+ * x [n][64] f32 (the readout's features), y [n][64] f32.  w1_bf16: [256][64] bf16 = mlp[0].weight; w2p_bf16: [64][256]
+ * bf16 = mlp[2].weight with its hidden axis permuted per 32-tile to the accumulator order
+ * k' = 16 s + 8 h + j  <-  k = 16 s + 8 (j>>2) + 4 h + (j&3)   (s in 0..1, h in 0..1, j in 0..7). */
+int tpnet_mlp64_bf16(const float* x, int64_t n, const void* w1_bf16, const float* b1, const void* w2p_bf16,
+                     const float* b2, float* y, void* stream);
+
 /* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
  * the last call (and clears the words), TPNET_OK otherwise. */
 int tpnet_check_errors(const tpnet_state* st, void* stream);

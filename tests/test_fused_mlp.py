@@ -1,0 +1,77 @@
+"""f-1: self.mlp fused on the bf16 matrix cores (tpnet_mlp64_bf16).  bf16 operands: tolerance 2e-2, NOT the 1e-4
+parity bar of the fp32 path -- which is why it is opt-in."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_w2_permutation_is_a_permutation_per_tile():
+    from tpnet_amd.fused_mlp import permute_w2
+    w2 = torch.arange(64 * 256, dtype=torch.float32).reshape(64, 256)
+    p = permute_w2(w2)
+    assert p.shape == (64, 256)
+    for ht in range(8):
+        assert sorted(p[0, ht * 32:(ht + 1) * 32].tolist()) == list(range(ht * 32, ht * 32 + 32))
+    # position 16 s + 8 h + j  <-  hidden 16 s + 8 (j>>2) + 4 h + (j&3)
+    assert p[0, 8 * 1 + 5].item() == 8 * 1 + 4 * 1 + 1      # s=0,h=1,j=5 -> 8 + 4 + 1
+    assert p[3, 32 + 16 + 2].item() == 3 * 256 + 32 + 16 + 2
+
+
+@pytest.mark.gpu
+def test_fused_mlp_exact_on_bf16_representable_integers():
+    """Asymmetric small-integer weights/inputs: every product and sum is exact in bf16 x bf16 -> fp32, so the kernel
+    must equal the fp32 reference bit for bit -- catches any wrong lane/register/permutation mapping."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd.fused_mlp import fused_mlp
+    g = torch.Generator().manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64)).cuda()
+    with torch.no_grad():
+        mlp[0].weight.copy_(torch.randint(-3, 4, (256, 64), generator=g).float())
+        mlp[0].bias.copy_(torch.randint(-8, 9, (256,), generator=g).float())
+        mlp[2].weight.copy_(torch.randint(-2, 3, (64, 256), generator=g).float())
+        mlp[2].bias.copy_(torch.randint(-8, 9, (64,), generator=g).float())
+    for n in (1, 31, 32, 33, 1000, 4097):
+        x = torch.randint(0, 4, (n, 64), generator=g).float().cuda()
+        with torch.no_grad():
+            want = mlp(x)
+            got = fused_mlp(mlp, x)
+        assert torch.equal(got, want), f"n={n}: max |delta| {(got - want).abs().max().item()}"
+
+
+@pytest.mark.gpu
+def test_fused_mlp_numerics_and_gradients():
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd.fused_mlp import fused_mlp
+    torch.manual_seed(1)
+    mlp = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64)).cuda()
+    x = (torch.rand(5000, 64, device="cuda") * 12.0)            # log(relu(G)+1) features: non-negative, O(10)
+    want = mlp(x)
+    got = fused_mlp(mlp, x)
+    err = (got - want).abs().max().item()
+    assert err < 2e-2 * max(1.0, want.abs().max().item()), err
+    gy = torch.randn_like(want)
+    gw = torch.autograd.grad(want, list(mlp.parameters()), gy)
+    gf = torch.autograd.grad(got, list(mlp.parameters()), gy)
+    for a, b in zip(gf, gw):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_module_uses_fused_mlp_when_asked():
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import RandomProjectionModule
+    rp = RandomProjectionModule(node_num=100, edge_num=500, dim_factor=10, num_layer=3, time_decay_weight=1e-6,
+                                device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0), not_scale=False,
+                                enforce_dim=128).to("cuda:0")
+    rng = np.random.RandomState(0)
+    src, dst = rng.randint(1, 100, 64), rng.randint(1, 100, 64)
+    rp.update(src, dst, np.sort(rng.uniform(0, 1e5, 64)))
+    ref = rp.get_pair_wise_feature(src, dst)
+    rp.fused_mlp = True
+    out = rp.get_pair_wise_feature(src, dst)
+    assert (out - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    out.sum().backward()
+    assert rp.mlp[2].weight.grad is not None

@@ -1,0 +1,81 @@
+"""self.mlp of RandomProjectionModule (Linear(64,256) -> ReLU -> Linear(256,64), models/TPNet.py:64-65,129) as one
+bf16 MFMA kernel (C ABI: tpnet_mlp64_bf16; SURVEY.md §8 f-1, BASELINE config 5).
+
+Opt-in (`RandomProjectionModule.fused_mlp = True`): bf16 operands with fp32 accumulation are NOT within the 1e-4
+parity budget of the fp32 path (expect ~1e-2 relative), so the default stays the torch fp32 layers.  Forward runs
+the fused kernel; backward recomputes the hidden layer with torch in fp32 and returns exact fp32 gradients for the
+four parameter tensors (the input features carry no gradient: the projections are requires_grad=False)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+F, H = 64, 256
+
+
+def permute_w2(w2: torch.Tensor) -> torch.Tensor:
+    """[64][256] -> the hidden axis of every 32-tile in accumulator order: position 16 s + 8 h + j of a tile holds the
+    hidden unit 16 s + 8 (j>>2) + 4 h + (j&3) (the order in which a 32x32 MFMA result tile lays its rows out over the
+    16 registers of lane half h)."""
+    idx = []
+    for ht in range(H // 32):
+        for s in range(2):
+            for h in range(2):
+                for j in range(8):
+                    idx.append(ht * 32 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3))
+    return w2[:, torch.tensor(idx, device=w2.device)].contiguous()
+
+
+def supported(mlp: torch.nn.Module) -> bool:
+    return (isinstance(mlp, torch.nn.Sequential) and len(mlp) == 3 and isinstance(mlp[0], torch.nn.Linear)
+            and isinstance(mlp[1], torch.nn.ReLU) and isinstance(mlp[2], torch.nn.Linear)
+            and mlp[0].in_features == F and mlp[0].out_features == H and mlp[2].in_features == H
+            and mlp[2].out_features == F and mlp[0].bias is not None and mlp[2].bias is not None)
+
+
+def _prepared(mlp):
+    """bf16 / permuted copies of the weights, rebuilt only when a parameter changed (optimizer step, load_state_dict,
+    .to()): keyed on (data_ptr, _version) of the four tensors."""
+    ps = (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias)
+    key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+    cache = getattr(mlp, "_tpnet_prepared", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            prep = (ps[0].detach().to(torch.bfloat16).contiguous(), ps[1].detach().float().contiguous(),
+                    permute_w2(ps[2].detach()).to(torch.bfloat16).contiguous(), ps[3].detach().float().contiguous())
+        cache = (key, prep)
+        mlp._tpnet_prepared = cache
+    return cache[1]
+
+
+class _FusedMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, prep):
+        if x.device.type != "cuda" or x.dtype != torch.float32:
+            raise _lib.TPNetHipError("fused mlp needs float32 features on the GPU")
+        x = x.contiguous()
+        n = x.shape[0]
+        y = torch.empty((n, F), dtype=torch.float32, device=x.device)
+        w1b, b1c, w2p, b2c = prep
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(_lib.load().tpnet_mlp64_bf16(x.data_ptr(), n, w1b.data_ptr(), b1c.data_ptr(), w2p.data_ptr(),
+                                                b2c.data_ptr(), y.data_ptr(), stream), "mlp64_bf16")
+        ctx.save_for_backward(x, w1, b1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        pre = torch.addmm(b1, x, w1.t())                 # fp32 recompute of the hidden layer
+        hid = torch.relu(pre)
+        gw2 = gy.t() @ hid
+        gb2 = gy.sum(0)
+        gh = (gy @ w2) * (pre > 0)
+        gw1 = gh.t() @ x
+        gb1 = gh.sum(0)
+        return None, gw1, gb1, gw2, gb2, None
+
+
+def fused_mlp(mlp: torch.nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    return _FusedMLP.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, _prepared(mlp))

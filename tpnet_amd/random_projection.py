@@ -52,6 +52,7 @@ class RandomProjectionModule(nn.Module):
         self.node_feature_dim = 128
         self.not_scale = not_scale
         self.exact = bool(exact)
+        self.fused_mlp = False               # opt-in: self.mlp on the bf16 matrix cores (tpnet_amd/fused_mlp.py)
         if self.use_matrix:
             self.dim = self.node_num
             for i in range(self.num_layer + 1):
@@ -311,8 +312,15 @@ class RandomProjectionModule(nn.Module):
         if n >= 2 and n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:]):
             dst = np.asarray(dst_node_ids)
             g1, g2 = self.pair_gram_shared(src[: n // 2], dst[: n // 2], dst[n // 2:])
-            return self.mlp(torch.cat([g1, g2], dim=0))
-        return self.mlp(self.pair_gram(src_node_ids, dst_node_ids))
+            return self._apply_mlp(torch.cat([g1, g2], dim=0))
+        return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
+
+    def _apply_mlp(self, feats: torch.Tensor) -> torch.Tensor:
+        if self.fused_mlp:
+            from . import fused_mlp as fm
+            if fm.supported(self.mlp):
+                return fm.fused_mlp(self.mlp, feats)
+        return self.mlp(feats)
 
     def reset_random_projections(self):
         """models/TPNet.py:131-139."""
