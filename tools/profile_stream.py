@@ -13,6 +13,7 @@ ap.add_argument("--reps", type=int, default=3); ap.add_argument("--batch", type=
 a = ap.parse_args()
 c = dict(CONFIGS[a.config]); B = a.batch or c["B"]; E = a.batches * B
 src, dst, t, N = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
+print(f"{a.config}: N={N} E={E} d={c['d']} state {(2 * N * 3 + N) * c['d'] * 4 / 1e9:.1f} GB", flush=True)
 neg = synthetic_negatives(c["U"], N, E, B, 1)
 dev = torch.device("cuda:0")
 rp = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=c["E"], dim_factor=10, num_layer=3, time_decay_weight=c["lam"],

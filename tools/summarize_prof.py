@@ -42,7 +42,10 @@ def main(cfg, tag):
                   f"FETCH_SIZE avg per k_step launch = {res.get('fetch', 0):.1f} KiB (x2 gfx950 correction -> {fetch_b / 1e6:.2f} MB); "
                   f"WRITE_SIZE avg = {res.get('write', 0):.1f} KiB ({write_b / 1e6:.2f} MB)",
                   f"memory-side traffic per launch ~ {(fetch_b + write_b) / 1e6:.2f} MB vs algorithmic {bpl / 1e6:.2f} MB "
-                  f"(ratio {(fetch_b + write_b) / bpl:.2f}; the whole state fits the 256 MB Infinity Cache, whose hits are counted)", ""]
+                  f"(ratio {(fetch_b + write_b) / bpl:.2f}) = {(fetch_b + write_b) / avg:.0f} GB/s on the memory side; " +
+                  ("the whole state fits the 256 MB Infinity Cache, whose hits are counted"
+                   if (c["U"] + c["I"] + 1) * 7 * c["d"] * 4 < 256e6 else
+                   f"state {(c['U'] + c['I'] + 1) * 7 * c['d'] * 4 / 1e9:.0f} GB >> Infinity Cache: this is HBM traffic"), ""]
     import json
     js = {"config": cfg, "kernel": "k_step", "launches": len(dur), "avg_ns": avg, "median_ns": st.median(dur),
           "algorithmic_bytes_per_launch": bpl,

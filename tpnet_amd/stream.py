@@ -7,6 +7,9 @@ CONFIGS = {
     "C1": dict(U=8227, I=1000, E=157474, span=2.678e6, lam=1e-6, d=64, B=200, desc="Wikipedia-shape d=64 B=200"),
     "C2": dict(U=8227, I=1000, E=157474, span=2.678e6, lam=1e-6, d=128, B=1000, desc="Wikipedia-shape d=128 B=1000"),
     "C3": dict(U=10000, I=984, E=672447, span=2.678e6, lam=1e-6, d=256, B=10000, desc="Reddit-shape d=256 B=10000"),
+    # C4 on ONE GPU: 10 M nodes, d=256 -> 72 GB of state, far beyond the 256 MB Infinity Cache: the HBM-bound case
+    "C4": dict(U=5000000, I=5000000, E=200000000, span=2.678e6 * 64, lam=1e-7, d=256, B=10000,
+               desc="synthetic 10 M nodes power-law stream d=256 B=10000"),
     "C5": dict(U=980, I=1000, E=1293103, span=1.37e8, lam=1e-7, d=512, B=10000, desc="LastFM-shape d=512 B=10000"),
 }
 
