@@ -372,3 +372,56 @@ def test_shared_first_node_readout(d, L):
     # a pair list that only looks similar must take the generic path and still be right
     odd = rp.get_pair_wise_feature(np.concatenate([w, w[::-1]]), np.concatenate([a, b_]))
     _assert_features(odd.cpu().numpy()[len(w):], st, w[::-1], b_)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the other BASELINE.json configs: oracle on a prefix (the numpy oracle needs ~1 s per 10 000-edge batch),
+# size-independent properties on the whole stream
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,nb_oracle", [("C1", 12), ("C3", 4), ("C5", 3)])
+def test_other_configs_prefix_against_oracle(cfg, nb_oracle):
+    _need_gpu()
+    from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+    c = CONFIGS[cfg]
+    B, d = c["B"], c["d"]
+    E = nb_oracle * B + B // 2                              # ragged tail
+    src, dst, t, N = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
+    neg = synthetic_negatives(c["U"], N, E, B, 1)
+    torch.manual_seed(0)
+    P0 = torch.normal(0, 1 / np.sqrt(d), (N, d)).numpy()
+    rp = _module(N, d, 3, c["lam"], 0.0, P0=P0, E=c["E"])
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    fp, fn = rp.run_stream(dev(src), dev(dst), dev(neg), dev(t), B)
+    fp = fp.cpu().numpy(); fn = fn.cpu().numpy()
+    st = O.OracleState(P0, 3, c["lam"], 0.0)
+    for b in range(0, E, B):
+        s = slice(b, min(b + B, E))
+        _assert_features(fp[s], st, src[s], dst[s], f"{cfg} pos batch {b // B}")
+        _assert_features(fn[s], st, src[s], neg[s], f"{cfg} neg batch {b // B}")
+        O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, f"{cfg} state")
+    rp.check_device_errors()
+
+
+def test_c3_full_stream_properties():
+    """Reddit-shaped stream at full size (672 447 edges, d=256, B=10 000, 68 batches): bit-for-bit run-to-run
+    determinism of every feature and of the final state, and exact linearity in P[0]."""
+    _need_gpu()
+    from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+    c = CONFIGS["C3"]
+    src, dst, t, N = synthetic_stream(c["U"], c["I"], c["E"], c["span"], 0)
+    neg = synthetic_negatives(c["U"], N, c["E"], c["B"], 1)
+    torch.manual_seed(0)
+    P0 = torch.normal(0, 1 / np.sqrt(c["d"]), (N, c["d"])).numpy()
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    outs = []
+    for scale in (1.0, 1.0, 2.0):
+        rp = _module(N, c["d"], 3, c["lam"], 0.0, P0=(scale * P0).astype(np.float32), E=c["E"])
+        fp, fn = rp.run_stream(ds, dd, dn, dt, c["B"], t_end=float(t[-1]))
+        outs.append((fp, fn, _layers(rp)))
+        rp.check_device_errors()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[2][2], 2.0 * outs[0][2])
+    assert np.isfinite(outs[0][2]).all() and float(np.abs(outs[0][2][2]).max()) > 0
