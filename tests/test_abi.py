@@ -122,3 +122,13 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def test_module_copy_and_pickle_on_cpu():
+    import copy, pickle
+    rp = _mk()
+    rp2 = copy.deepcopy(rp)
+    assert torch.equal(rp2.random_projections[0], rp.random_projections[0])
+    assert rp2.random_projections[0].data_ptr() != rp.random_projections[0].data_ptr()
+    rp3 = pickle.loads(pickle.dumps(rp))
+    assert sorted(rp3.state_dict().keys()) == sorted(rp.state_dict().keys())

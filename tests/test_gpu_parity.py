@@ -425,3 +425,39 @@ def test_c3_full_stream_properties():
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
     np.testing.assert_array_equal(outs[2][2], 2.0 * outs[0][2])
     assert np.isfinite(outs[0][2]).all() and float(np.abs(outs[0][2][2]).max()) > 0
+
+
+def test_deepcopy_pickle_and_launch_id_wrap():
+    """Plumbing robustness: deepcopy / pickle of a module whose truth lives in the engine; the launch-id counter
+    wrapping (consolidation through export + import) must not change results."""
+    _need_gpu()
+    import copy, pickle
+    from tpnet_amd import random_projection as rpmod
+    rng = np.random.RandomState(3)
+    N, d, L, B = 200, 128, 3, 50
+    src, dst, neg, t = _random_stream(rng, N, 6 * B, 1.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    a = _module(N, d, L, 1e-6, t[0], P0=P0)
+    b = _module(N, d, L, 1e-6, t[0], P0=P0)
+    old = rpmod._MAX_LAUNCH_ID
+    try:
+        for k in range(6):
+            s = slice(k * B, (k + 1) * B)
+            a.update(src[s], dst[s], t[s])
+            if k == 2:
+                rpmod._MAX_LAUNCH_ID = b._launch_id + 1          # force the consolidation path on the next call
+            b.update(src[s], dst[s], t[s])
+            if k == 3:
+                assert b._launch_id <= 3                          # counter restarted
+                rpmod._MAX_LAUNCH_ID = old
+    finally:
+        rpmod._MAX_LAUNCH_ID = old
+    # consolidation materialises the pending decay: one extra f32 rounding per element
+    _assert_state(_layers(b), _layers(a), 1e-5, "after launch-id consolidation")
+    c = copy.deepcopy(a)
+    e = pickle.loads(pickle.dumps(a))
+    for m in (c, e):
+        np.testing.assert_array_equal(_layers(m), _layers(a))
+        m.update(src[:B], dst[:B], t[-B:] + 10.0)
+    np.testing.assert_array_equal(_layers(c), _layers(e))
+    assert not np.array_equal(_layers(c), _layers(a))            # the copies own their state

@@ -85,7 +85,13 @@ class RandomProjectionModule(nn.Module):
     # plumbing
     # ------------------------------------------------------------------------------------------------------
     def _plist(self):
-        return self._modules["random_projections"]
+        # the Parameter OBJECTS of the list are stable (`.data = ...`, `.to()`, load_state_dict keep them), so they are
+        # looked up once: nn.ParameterList.__getitem__ costs microseconds and the hot methods need them every call
+        refs = self.__dict__.get("_param_refs")
+        if refs is None or len(refs) != self.num_layer + 1:
+            refs = list(self._modules["random_projections"])
+            self.__dict__["_param_refs"] = refs
+        return refs
 
     def __getattr__(self, name):
         # external readers of `random_projections` / `now_time` see the reference's eager values
@@ -147,6 +153,9 @@ class RandomProjectionModule(nn.Module):
 
     def _ensure_engine(self):
         """Make the engine state current: import the Parameters if somebody wrote them since the last sync."""
+        if self._engine_valid and not self._params_valid and self._eng is not None \
+                and self._eng["dev"] == self._plist()[0].device:
+            return                              # steady state of the batch loop: the engine is the only truth
         self._engine()
         if self._engine_valid and self._params_valid and self._param_sig != self._sig():
             self._engine_valid = False          # Parameters were written behind our back (.data = ..., copy_, ...)
@@ -191,17 +200,56 @@ class RandomProjectionModule(nn.Module):
         return ids
 
     def _to_device(self, *arrays):
-        """ONE host->device copy for several equally long 8-byte arrays (int64 ids, float64 times): the reference
-        issues one copy per array (TPNet.py:74-77); a pageable copy costs ~15 us of latency each."""
+        """ONE asynchronous host->device copy for several equally long 8-byte arrays (int64 ids, float64 times)
+        through a small ring of pinned staging buffers.  The reference issues one pageable (blocking) copy per array
+        (TPNet.py:74-77); here the host only memcpy's into pinned memory and moves on."""
         n = arrays[0].size
-        host = np.empty((len(arrays), n), dtype=np.int64)
-        for k, a in enumerate(arrays):
-            host[k] = a.view(np.int64)
-        dev = torch.from_numpy(host).to(self._dev())
-        return [dev[k] if arrays[k].dtype == np.int64 else dev[k].view(torch.float64) for k in range(len(arrays))]
+        k = len(arrays)
+        dev = self._dev()
+        ring = self.__dict__.setdefault("_pin_ring", {"bufs": [], "pos": 0})
+        if not ring["bufs"]:
+            ring["bufs"] = [[None, None] for _ in range(8)]          # [pinned tensor, event of its last copy]
+        slot = ring["bufs"][ring["pos"]]
+        ring["pos"] = (ring["pos"] + 1) % len(ring["bufs"])
+        if slot[1] is not None:
+            slot[1].synchronize()                                     # the copy that last used this buffer is done
+        if slot[0] is None or slot[0].numel() < k * n:
+            slot[0] = torch.empty(max(k * n, 4096), dtype=torch.int64).pin_memory()
+        host = slot[0][: k * n].view(k, n)
+        hv = host.numpy()
+        for i, a in enumerate(arrays):
+            hv[i] = a.view(np.int64)
+        out = host.to(dev, non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        return [out[i] if arrays[i].dtype == np.int64 else out[i].view(torch.float64) for i in range(k)]
 
     def _ids_to_device(self, ids, what):
         return self._to_device(self._check_ids(ids, what))[0]
+
+    # copy / pickle: the engine buffers, pinned staging ring and cached refs are per-process plumbing, not state ------
+    def __getstate__(self):
+        if self._eng is not None and not self._params_valid:
+            self._materialize()                                    # the Parameters carry the state into the copy
+        d = dict(self.__dict__)
+        for k in ("_eng", "_pin_ring", "_param_refs"):
+            d.pop(k, None)
+        d["_eng"] = None
+        d["_engine_valid"] = False
+        d["_params_valid"] = True
+        d["_param_sig"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__dict__.update(copy.deepcopy(self.__getstate__(), memo))
+        return new
 
     # nn.Module hooks that read or write the Parameters wholesale ---------------------------------------------
     def state_dict(self, *args, **kwargs):
