@@ -118,11 +118,11 @@ size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
 
 /* update (models/TPNet.py:67-99) for one batch: src, dst device int64[B], t device double[B] (absolute times,
  * chronological; t[B-1] is the new now_time).  now_time = the module's clock before the call; launch_id = a
- * caller-kept counter, strictly increasing over calls that write the state (start at 1).  The host value of
- * t[B-1] is passed as t_last so that no device->host copy is needed. */
+ * caller-kept counter, strictly increasing over calls that write the state (start at 1).  The new clock t[B-1] is
+ * read on the device; the caller keeps its own host copy of it. */
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
-                 double t_last, double now_time, double lambda, uint32_t launch_id, uint32_t flags,
-                 void* workspace, size_t ws_bytes, void* stream);
+                 double now_time, double lambda, uint32_t launch_id, uint32_t flags, void* workspace,
+                 size_t ws_bytes, void* stream);
 
 /* The caller loop of train_link_prediction.py:253-373 / evaluate_models_utils.py:56-184 for a device-resident
  * edge stream: for each chronological batch of `batch` edges (last one partial): readout (src,dst) and

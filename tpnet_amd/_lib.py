@@ -44,8 +44,8 @@ SIGNATURES = {
     "tpnet_pair_gram": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P]),
     "tpnet_pair_gram_shared": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P, _P]),
     "tpnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
-    "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_uint32,
-                               C.c_uint32, _P, C.c_size_t, _P]),
+    "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,
+                               C.c_size_t, _P]),
     "tpnet_run_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                    C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(C.c_double), _P]),
     "tpnet_plan_stream": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P,

@@ -186,13 +186,12 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
 
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
-                 double t_last, double now_time, double lambda, uint32_t launch_id, uint32_t flags, void* workspace,
-                 size_t ws_bytes, void* stream) {
+                 double now_time, double lambda, uint32_t launch_id, uint32_t flags, void* workspace, size_t ws_bytes,
+                 void* stream) {
     int rc = check_state(st);
     if (rc) return rc;
     if (B < 1 || !src || !dst || !t) return TPNET_ERR_BAD_ARG;  // the reference raises on an empty batch (t[-1])
     if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
-    (void)t_last;
     if (plan_bytes(B, B) > ws_bytes) return TPNET_ERR_WORKSPACE;
     return run_stream_impl(*st, src, dst, nullptr, t, B, B, now_time, lambda, launch_id, flags, nullptr, nullptr,
                            workspace, ws_bytes, (hipStream_t)stream, nullptr);

@@ -297,8 +297,8 @@ class RandomProjectionModule(nn.Module):
             flags |= _lib.FLAG_SEQUENTIAL
         ws = self._workspace(B, B)
         lid = self._next_launch_ids(1)
-        _lib.check(lib.tpnet_update(C.byref(st), src.data_ptr(), dst.data_ptr(), t_dev.data_ptr(), B, next_time,
-                                    self._now_host, lam, lid, flags, ws.data_ptr(), ws.numel(), self._stream()),
+        _lib.check(lib.tpnet_update(C.byref(st), src.data_ptr(), dst.data_ptr(), t_dev.data_ptr(), B, self._now_host,
+                                    lam, lid, flags, ws.data_ptr(), ws.numel(), self._stream()),
                    "update")
         self._now_host = next_time
         self._params_valid = False
