@@ -461,3 +461,44 @@ def test_deepcopy_pickle_and_launch_id_wrap():
         m.update(src[:B], dst[:B], t[-B:] + 10.0)
     np.testing.assert_array_equal(_layers(c), _layers(e))
     assert not np.array_equal(_layers(c), _layers(a))            # the copies own their state
+
+
+# ---------------------------------------------------------------------------------------------------------
+# odd shapes: tiny dims / graphs / batches, every edge identical, every layer count
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 8, 12, 36, 100, 260])
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
+def test_odd_shapes_fuzz(d, L):
+    _need_gpu()
+    rng = np.random.RandomState(1000 * d + L)
+    for trial in range(3):
+        N = int(rng.randint(2, 7))
+        B = int(rng.randint(1, 5))
+        nb = int(rng.randint(1, 6))
+        E = nb * B - int(rng.randint(0, B))                 # ragged tail, possibly a single edge
+        E = max(E, 1)
+        src = rng.randint(0, N, E).astype(np.int64)         # id 0 allowed as an endpoint here: it is a legal row
+        dst = rng.randint(0, N, E).astype(np.int64)
+        if trial == 2:
+            src[:] = src[0]; dst[:] = dst[0]                # every edge the same pair
+        neg = rng.randint(0, N, E).astype(np.int64)
+        t = np.sort(rng.uniform(5.0, 5.0e5, E))
+        if trial == 1:
+            t[:] = t[0]                                     # all timestamps equal
+        lam = float(rng.choice([0.0, 1e-6, 3e-5]))
+        P0 = rng.randn(N, d).astype(np.float32)
+        for exact in (True, False):
+            rp = _module(N, d, L, lam, t[0], P0=P0, exact=exact)
+            st = O.OracleState(P0, L, lam, t[0])
+            dev = lambda x: torch.from_numpy(x).to(DEV)
+            fp, fn = rp.run_stream(dev(src), dev(dst), dev(neg), dev(t), B)
+            fp = fp.cpu().numpy(); fn = fn.cpu().numpy()
+            for b in range(0, E, B):
+                s = slice(b, min(b + B, E))
+                _assert_features(fp[s], st, src[s], dst[s], f"d={d} L={L} trial={trial} pos")
+                _assert_features(fn[s], st, src[s], neg[s], f"d={d} L={L} trial={trial} neg")
+                O.update(st, src[s], dst[s], t[s])
+            _assert_state(_layers(rp), np.stack(st.P[1:]), 5e-6 if exact else 1e-4, f"d={d} L={L} trial={trial}")
+            # the module API on the same final state
+            rows = rp.get_random_projections(np.arange(N))
+            np.testing.assert_allclose(np.stack([r.cpu().numpy() for r in rows[1:]]), _layers(rp), rtol=1e-6, atol=1e-30)
