@@ -541,7 +541,7 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
                                             const float* __restrict__ s_coef, Item I, bool valid, uint32_t bid,
                                             double t_last, double lambda, int gl) {
     constexpr int F = VPL * W;
-    constexpr int U = 4;
+    constexpr int U = (VPL * L <= 3) ? 6 : 4;   // one round of rows covers the whole tail of a light item (cnt <= 8)
     const int d = S.d;
     const int nvec = d / W;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
