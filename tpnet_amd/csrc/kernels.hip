@@ -1164,7 +1164,8 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
         const bool full = gm.w == 4 && st.d == gm.lpp * gm.vpl * 4;             \
         if (gm.w == 1) { TPNET_DISPATCH_L(64, 1, 1, false, CALL) }              \
         else if (gm.lpp == 16) { if (full) { TPNET_DISPATCH_L(16, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(16, 1, 4, false, CALL) } } \
-        else if (gm.lpp == 32) { if (full) { TPNET_DISPATCH_L(32, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 1, 4, false, CALL) } } \
+        else if (gm.lpp == 32 && gm.vpl == 1) { if (full) { TPNET_DISPATCH_L(32, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 1, 4, false, CALL) } } \
+        else if (gm.lpp == 32) { if (full) { TPNET_DISPATCH_L(32, 2, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 2, 4, false, CALL) } } \
         else if (gm.vpl == 1) { if (full) { TPNET_DISPATCH_L(64, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(64, 1, 4, false, CALL) } }  \
         else { if (full) { TPNET_DISPATCH_L(64, 2, 4, true, CALL) } else { TPNET_DISPATCH_L(64, 2, 4, false, CALL) } }                   \
     } while (0)

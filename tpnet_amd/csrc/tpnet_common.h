@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/tpnet_hip.h"
 
 namespace tpnet {
@@ -83,8 +84,15 @@ inline Geom pick_geom(int d) {
     const int nvec = d / 4;
     if (nvec <= 16) return {16, 1, 4};
     if (nvec <= 32) return {32, 1, 4};
-    if (nvec <= 64) return {64, 1, 4};
-    return {64, 2, 4};
+    static const char* g = getenv("TPNET_DEV_GEOM");          // developer override: "64x1", "64x2", "32x2"
+    if (g && g[0] == '6' && g[3] == '1' && nvec <= 64) return {64, 1, 4};
+    if (g && g[0] == '6') return {64, nvec <= 64 ? 1 : 2, 4};
+    if (g && g[0] == '3') return {32, 2, 4};
+    // d <= 256: 32 lanes x 2 vectors, not 64 x 1 -- the 64-value Gram reduction over 64 lanes needs v_permlane32_swap
+    // and costs 1 281 cycles against 545 over 32 lanes (tools/probes/reduce_probe.hip), and a wave then carries two
+    // pairs / targets instead of one (measured: C4 +19 %, encoder readout at d=256 +18 %, C3 unchanged).
+    if (nvec <= 64) return {32, 2, 4};
+    return {64, 2, 4};                                        // d = 512 (and chunks of 512 beyond): C5 is 1.6x faster so
 }
 
 // host-side launchers implemented in kernels.hip / plan.hip
