@@ -1158,11 +1158,13 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
         case 4: { constexpr int LPP = LPP_, VPL = VPL_, W = W_, L = 4; constexpr bool FULL = FULL_; CALL; } break; \
         default: return TPNET_ERR_BAD_ARG;                                      \
     }
-#define TPNET_DISPATCH(CALL)                                                    \
+#define TPNET_DISPATCH(CALL) TPNET_DISPATCH_G(pick_geom(st.d), CALL)
+#define TPNET_DISPATCH_G(GEOM, CALL)                                            \
     do {                                                                        \
-        const Geom gm = pick_geom(st.d);                                        \
+        const Geom gm = (GEOM);                                                 \
         const bool full = gm.w == 4 && st.d == gm.lpp * gm.vpl * 4;             \
         if (gm.w == 1) { TPNET_DISPATCH_L(64, 1, 1, false, CALL) }              \
+        else if (gm.lpp == 16 && gm.vpl == 2) { if (full) { TPNET_DISPATCH_L(16, 2, 4, true, CALL) } else { TPNET_DISPATCH_L(16, 2, 4, false, CALL) } } \
         else if (gm.lpp == 16) { if (full) { TPNET_DISPATCH_L(16, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(16, 1, 4, false, CALL) } } \
         else if (gm.lpp == 32 && gm.vpl == 1) { if (full) { TPNET_DISPATCH_L(32, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 1, 4, false, CALL) } } \
         else if (gm.lpp == 32) { if (full) { TPNET_DISPATCH_L(32, 2, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 2, 4, false, CALL) } } \
@@ -1173,7 +1175,7 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
 int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                      uint32_t flags, float* out, hipStream_t s) {
     if (n == 0) return TPNET_OK;
-    TPNET_DISPATCH(({
+    TPNET_DISPATCH_G(pick_geom(st.d, n >= 16384), ({
         const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
         hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, u, v, n, now, lambda,
                            flags, out);
