@@ -36,11 +36,8 @@ def make_workload(cfg, n_batches, rank):
     return src, dst, neg, t, N
 
 
-def cpu_baseline(cfg, src, dst, neg, t, N, P0, budget_s=12.0):
-    """The torch-CPU port of the reference ops (oracle/torch_port.py), timed on this box's host cores on a bounded
-    prefix of the same workload."""
+def _cpu_port_rate(cfg, src, dst, neg, t, P0, threads, budget_s):
     from oracle.torch_port import TorchPort
-    threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     B = cfg["B"]
     port = TorchPort(P0, 3, cfg["lam"], 0.0)
@@ -57,10 +54,40 @@ def cpu_baseline(cfg, src, dst, neg, t, N, P0, budget_s=12.0):
             done += 1
             if time.perf_counter() - t0 > budget_s:
                 break
-    el = time.perf_counter() - t0
-    return {"value": done * B / el, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"first {done} batches of {B} edges after 2 warm-up batches, torch-CPU port of the reference "
-                      f"ops incl. its eager dense decay, {threads} threads, pre-mlp features"}
+    return done * B / (time.perf_counter() - t0), done
+
+
+def cpu_baseline(cfg, src, dst, neg, t, N, P0, budget_s=10.0):
+    """The torch-CPU port of the reference ops (oracle/torch_port.py), timed on this box's host cores on a bounded
+    prefix of the same workload: with all (up to 16) cores, and with the reference's own setting of 3 intra-op threads
+    (train_link_prediction.py:124)."""
+    threads = min(os.cpu_count() or 1, 16)
+    rate, done = _cpu_port_rate(cfg, src, dst, neg, t, P0, threads, budget_s)
+    rate3, done3 = _cpu_port_rate(cfg, src, dst, neg, t, P0, 3, budget_s / 2)
+    torch.set_num_threads(threads)
+    B = cfg["B"]
+    return {"value": rate, "unit": "edges/s", "cores": threads, "kind": "port",
+            "value_3_threads": rate3,
+            "sample": f"first {done} batches of {B} edges after 2 warm-up batches ({done3} at 3 threads, the reference's "
+                      f"own torch.set_num_threads), torch-CPU port of the reference ops incl. its eager dense decay, "
+                      f"pre-mlp features"}
+
+
+def copy_bandwidth_gbs(dev):
+    """Measured device-to-device copy rate (read + write bytes / time) of a 1 GiB buffer: the practical HBM ceiling
+    next to the 8 TB/s spec peak."""
+    n = 1 << 28
+    x = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    y = torch.empty_like(x)
+    y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -187,6 +214,12 @@ def main():
                 "duration_note": "HIP events on the launch stream around the loop of step launches / launches: "
                                  "kernel duration + inter-kernel boundary (rocprofv3 per-kernel average: profiles/)",
                 "stream_ms_events": total_ms.value}
+        try:
+            cbw = copy_bandwidth_gbs(dev)
+            roof["copy_bandwidth_gbs_measured"] = cbw
+            roof["frac_of_measured_copy_bandwidth"] = achieved / cbw
+        except Exception:
+            pass
 
     if rank == 0:
         cpu = None
