@@ -502,3 +502,45 @@ def test_odd_shapes_fuzz(d, L):
             # the module API on the same final state
             rows = rp.get_random_projections(np.arange(N))
             np.testing.assert_allclose(np.stack([r.cpu().numpy() for r in rows[1:]]), _layers(rp), rtol=1e-6, atol=1e-30)
+
+
+def test_internal_chunking_with_a_small_workspace():
+    """tpnet_run_stream plans the stream in chunks when the caller's workspace cannot hold it at once; the chunked
+    run must equal the one-chunk run bit for bit (same launches, same clocks: the chunk's first batch reads the
+    previous chunk's last timestamp on the device)."""
+    _need_gpu()
+    import ctypes as C
+    from tpnet_amd import _lib
+    rng = np.random.RandomState(9)
+    N, d, L, B = 400, 128, 3, 64
+    E = 23 * B + 17
+    src, dst, neg, t = _random_stream(rng, N, E, 3.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    a = _module(N, d, L, 2e-6, t[0], P0=P0)
+    fa, na = a.run_stream(ds, dd, dn, dt, B)
+    b = _module(N, d, L, 2e-6, t[0], P0=P0)
+    b._ensure_engine()
+    lib = _lib.load()
+    full = lib.tpnet_workspace_bytes(E, B)
+    small = lib.tpnet_workspace_bytes(5 * B, B) + 4096          # room for 5 batches per chunk -> 5 chunks
+    assert small < full
+    ws = torch.empty(small, dtype=torch.uint8, device=DEV)
+    fb = torch.empty_like(fa); nb_ = torch.empty_like(na)
+    st = b._state()
+    t_end = C.c_double(0.0)
+    rc = lib.tpnet_run_stream(C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, float(t[0]),
+                              2e-6, 1, 0, fb.data_ptr(), nb_.data_ptr(), ws.data_ptr(), small, C.byref(t_end),
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and t_end.value == float(t[-1])
+    b._now_host = t_end.value
+    b._params_valid = False
+    assert torch.equal(fa, fb) and torch.equal(na, nb_)
+    np.testing.assert_array_equal(_layers(a), _layers(b))
+    # and a workspace that cannot hold even one batch is refused, not overrun
+    tiny = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = lib.tpnet_run_stream(C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, float(t[0]),
+                              2e-6, 100, 0, fb.data_ptr(), nb_.data_ptr(), tiny.data_ptr(), 1024, None,
+                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == -2

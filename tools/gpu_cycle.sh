@@ -1,5 +1,5 @@
 #!/bin/bash
-# one GPU cycle: parity tests, bench line, rocprofv3 kernel trace of a shorter bench run.  usage: scripts_gpu_cycle.sh TAG
+# one GPU cycle: parity tests, bench line, rocprofv3 kernel trace of a shorter bench run.  usage: tools/gpu_cycle.sh TAG
 TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
