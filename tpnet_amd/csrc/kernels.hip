@@ -254,7 +254,7 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
                     x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
                 }
                 if (!idok) x = __builtin_nanf("");
-                out[idx] = x;
+                __builtin_nontemporal_store(x, out + idx);   // features are consumed by another kernel: stream them out
             }
         }
     }
