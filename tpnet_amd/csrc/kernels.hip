@@ -794,8 +794,13 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, int W, int L, bool FULL>
-__global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Plan p, int64_t b, int64_t e0, int32_t ne_,
-                                                double lambda, uint32_t bid, uint32_t flags, int HEAVY_BLOCKS) {
+// The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
+// first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
+// -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
+__global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
+                                                const int64_t* __restrict__ a_neg, int64_t e0, int32_t ne_,
+                                                uint32_t flags, uint32_t bid, int HEAVY_BLOCKS, double lambda,
+                                                tpnet_state S, StreamArgs a, Plan p, int64_t b) {
     constexpr int GPB = BLOCK / LPP;
     constexpr int GPW = 64 / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
@@ -851,14 +856,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(tpnet_state S, StreamArgs a, Pla
             if (valid) {
                 if (w < npos) {
                     e = e0 + w;
-                    v = a.dst[e];
+                    v = a_dst[e];
                     out = a.out_pos + e * NG;
                 } else {
                     e = e0 + (w - npos);
-                    v = a.neg[e];
+                    v = a_neg[e];
                     out = a.out_neg + e * NG;
                 }
-                u = a.src[e];
+                u = a_src[e];
             }
             const double now = Dp->now;
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
@@ -1226,8 +1231,8 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
         if (item_blocks > room) item_blocks = room > item_min ? room : item_min;
         int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
         if (grid > HEAVY_BLOCKS + 256 * 8) grid = HEAVY_BLOCKS + 256 * 8;
-        hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, a, p, b,
-                           b * batch, ne, lambda, launch_id, flags, HEAVY_BLOCKS);
+        hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, a.src, a.dst,
+                           a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
