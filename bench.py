@@ -11,6 +11,8 @@ state + update() of the batch (the decoder-level unit of SURVEY.md §8d).  Workl
 starts.  Prints ONE JSON line (rank 0).
 """
 import argparse
+import os
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (the ROCm 7 default; 2 us per launch otherwise)
 import ctypes as C
 import json
 import os
@@ -93,8 +95,8 @@ def copy_bandwidth_gbs(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
