@@ -15,10 +15,13 @@ static int check_state(const tpnet_state* st) {
     return TPNET_OK;
 }
 
-// largest chunk (multiple of `batch`, at most E) whose plan fits the workspace
+// largest chunk (multiple of `batch`, at most E) whose plan fits the workspace.  Contribution indices are 32-bit inside a
+// chunk (Item::j0, the sort's payload), so a chunk never exceeds 2^30 edges however large the workspace is.
 static int64_t max_chunk(size_t ws_bytes, int64_t E, int64_t batch) {
-    if (plan_bytes(E, batch) <= ws_bytes) return E;
-    int64_t lo = 0, hi = (E + batch - 1) / batch;  // in batches; lo fits (0), hi does not
+    const int64_t hard = ((int64_t)1 << 30) / batch * batch;
+    const int64_t lim = (E < hard || hard < batch) ? E : hard;
+    if (plan_bytes(lim, batch) <= ws_bytes) return lim;
+    int64_t lo = 0, hi = (lim + batch - 1) / batch;  // in batches; lo fits (0), hi does not
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) / 2;
         if (plan_bytes(mid * batch, batch) <= ws_bytes) lo = mid; else hi = mid;
@@ -223,6 +226,7 @@ int tpnet_plan_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
     int rc = check_state(st);
     if (rc) return rc;
     if (E < 1 || batch < 1 || !src || !dst || !t) return TPNET_ERR_BAD_ARG;
+    if (E >= ((int64_t)1 << 30)) return TPNET_ERR_BAD_ARG;            // 32-bit contribution indices inside one plan
     if (plan_bytes(E, batch) > ws_bytes) return TPNET_ERR_WORKSPACE;
     Plan p{};
     rc = plan_carve(workspace, ws_bytes, E, batch, &p);
