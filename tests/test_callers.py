@@ -210,3 +210,31 @@ def test_gpu_sampler_reproduces_reference_call_sequence(golden_dir):
         for k in range(4):
             np.testing.assert_array_equal(calls[5 * b + k][1], g[f"b{b}_pair{k}_u"])
             np.testing.assert_array_equal(calls[5 * b + k][2], g[f"b{b}_pair{k}_v"])
+
+
+@pytest.mark.gpu
+def test_device_id_path_equals_host_id_path(golden_dir):
+    """The on-device caller path (device sampler -> device ids -> shared readout) produces the same encoder features
+    as the host-index path the reference's call sequence was pinned with."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import RandomProjectionModule
+    from tpnet_amd.sampler import GpuRecentNeighborSampler
+    from tpnet_amd.callers import link_prediction_batch
+    g = _g8(golden_dir)
+    src, dst, t = g["src"], g["dst"], g["t"]
+    B, K, L = int(g["B"]), int(g["K"]), int(g["L"])
+    mk = lambda: RandomProjectionModule(node_num=int(g["N"]), edge_num=int(g["E"]), dim_factor=10, num_layer=L,
+                                        time_decay_weight=float(g["lam"]), device="cuda:0", use_matrix=False,
+                                        beginning_time=np.float64(g["t0"]), not_scale=False,
+                                        enforce_dim=int(g["d"])).to("cuda:0")
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    host_s, dev_s = RecentNeighborSampler(src, dst, t, g["eid"]), GpuRecentNeighborSampler(src, dst, t, g["eid"])
+    for k in range(int(g["nb"])):
+        s = slice(k * B, min((k + 1) * B, len(src)))
+        neg = g[f"b{k}_neg"]
+        fa, oa = link_prediction_batch(a, host_s, src[s], dst[s], neg, t[s], K)
+        fb, ob = link_prediction_batch(b, dev_s, src[s], dst[s], neg, t[s], K)
+        for x, y in zip(fa + oa, fb + ob):
+            np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)

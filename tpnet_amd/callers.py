@@ -129,12 +129,24 @@ def link_prediction_batch(rp, neighbor_sampler, src: np.ndarray, dst: np.ndarray
     B = len(src)
     feats = []
     embs = []
+    on_device = hasattr(neighbor_sampler, "sample_device") and hasattr(rp, "get_pair_wise_feature_shared")
+    if on_device:      # ids stay on the GPU from the sampler to the readout (same pairs, same order as the host path)
+        dev = neighbor_sampler.device
+        src_t = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int64)).to(dev)
+        t2_t = torch.from_numpy(np.tile(np.asarray(t, dtype=np.float64), 2)).to(dev)
     for other in (dst, neg_dst):
         node_ids = np.concatenate([src, other])
-        neigh, _, _ = neighbor_sampler.get_historical_neighbors(node_ids=node_ids, node_interact_times=np.tile(t, 2),
-                                                                num_neighbors=num_neighbors)
-        u, v = encoder_pair_indices(neigh, src, other)
-        f = rp.get_pair_wise_feature(src_node_ids=u, dst_node_ids=v)                 # [4BK, F]
+        if on_device:
+            other_t = torch.from_numpy(np.ascontiguousarray(other, dtype=np.int64)).to(dev)
+            neigh, _, _ = neighbor_sampler.sample_device(torch.cat([src_t, other_t]), t2_t, num_neighbors, with_edges=False)
+            f = rp.get_pair_wise_feature_shared(neigh.reshape(-1), src_t.repeat(2).repeat_interleave(num_neighbors),
+                                                other_t.repeat(2).repeat_interleave(num_neighbors))
+        else:
+            neigh, _, _ = neighbor_sampler.get_historical_neighbors(node_ids=node_ids,
+                                                                    node_interact_times=np.tile(t, 2),
+                                                                    num_neighbors=num_neighbors)
+            u, v = encoder_pair_indices(neigh, src, other)
+            f = rp.get_pair_wise_feature(src_node_ids=u, dst_node_ids=v)             # [4BK, F]
         half = 2 * B * num_neighbors
         f = torch.cat([f[:half], f[half:]], dim=1).reshape(2 * B, num_neighbors, -1)  # TPNet.py:318-321
         feats.append(f)

@@ -190,6 +190,12 @@ class RandomProjectionModule(nn.Module):
         return first
 
     def _check_ids(self, ids, what):
+        if isinstance(ids, torch.Tensor) and ids.is_cuda:
+            # extension: ids already on the device (e.g. from the device-side sampler) are used in place; the kernels
+            # check the range themselves (bad ids are skipped, counted, and give NaN features)
+            if ids.dtype != torch.int64 or ids.dim() != 1:
+                raise ValueError(f"{what}: device ids must be a one-dimensional int64 tensor")
+            return ids.contiguous()
         ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int64)
         if ids.ndim != 1:
             raise ValueError(f"{what} must be one-dimensional")
@@ -203,6 +209,10 @@ class RandomProjectionModule(nn.Module):
         """ONE asynchronous host->device copy for several equally long 8-byte arrays (int64 ids, float64 times)
         through a small ring of pinned staging buffers.  The reference issues one pageable (blocking) copy per array
         (TPNet.py:74-77); here the host only memcpy's into pinned memory and moves on."""
+        if all(isinstance(a, torch.Tensor) for a in arrays):
+            return list(arrays)                                       # already resident
+        if any(isinstance(a, torch.Tensor) for a in arrays):
+            arrays = [a.cpu().numpy() if isinstance(a, torch.Tensor) else a for a in arrays]
         n = arrays[0].size
         k = len(arrays)
         dev = self._dev()
@@ -355,6 +365,8 @@ class RandomProjectionModule(nn.Module):
         reference, :49-62); self.mlp stays a trainable torch module.
         The encoder calls this with src_node_ids = tile(neighbours, 2) (models/TPNet.py:313-316): when the two halves
         of src_node_ids are equal, each neighbour's rows are fetched once for both of its pairs."""
+        if isinstance(src_node_ids, torch.Tensor):
+            return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
         src = np.asarray(src_node_ids)
         n = len(src)
         # (rows of <= 128 floats: the generic kernel's 16-lane geometry is as fast on long lists; measured)
@@ -363,6 +375,13 @@ class RandomProjectionModule(nn.Module):
             g1, g2 = self.pair_gram_shared(src[: n // 2], dst[: n // 2], dst[n // 2:])
             return self._apply_mlp(torch.cat([g1, g2], dim=0))
         return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
+
+    def get_pair_wise_feature_shared(self, node_ids, first_ids, second_ids):
+        """Extension: get_pair_wise_feature(tile(node_ids, 2), concat(first_ids, second_ids)) -- the encoder's pattern
+        (models/TPNet.py:313-316) -- with each node's rows fetched once.  Returns [2n, (2L+2)^2] in the reference's
+        row order (all (node, first) pairs, then all (node, second) pairs)."""
+        g1, g2 = self.pair_gram_shared(node_ids, first_ids, second_ids)
+        return self._apply_mlp(torch.cat([g1, g2], dim=0))
 
     def _apply_mlp(self, feats: torch.Tensor) -> torch.Tensor:
         if self.fused_mlp:
