@@ -112,7 +112,9 @@ def main():
     dev = torch.device("cuda", local_rank % ndev if backend != "nccl" else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # TPNET_BENCH_FORCE_DIST=1 (development): take the N>1 code path, collectives included, with a single rank
+    force_dist = os.environ.get("TPNET_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -126,67 +128,157 @@ def main():
     B, d, L = cfg["B"], cfg["d"], 3
     K, W = args.steps, args.warmup
 
-    # N = 1: configs[1] as is.  N > 1: the SAME graph row-sharded over the ranks (owner(n) = n % N), weak scaling:
-    # the global batch is N*B edges per step (B per GPU), every rank holds the whole stream, one RCCL all-gather of
-    # the touched rows per step (tpnet_amd/sharded.py).
+    # N = 1: configs[1] as is.  N > 1: the SAME graph and table cut over the ranks, weak scaling: the global batch is N*B
+    # edges per step (B per GPU), every rank holds the whole edge stream (32 bytes per edge).
+    #   cols (default): column sharding -- every rank keeps d/N columns of every row; the update needs no exchange, the
+    #                   raw Gram entries are reduce-scattered per chunk of steps behind the next chunk's kernels
+    #                   (tpnet_amd/sharded.py: ColumnShardedRunner).
+    #   rows:           row sharding, owner(n) = n % N, one RCCL all-gather of the touched rows per step
+    #                   (ShardedStreamRunner) -- north_star's layout; timed as a second, shorter leg and reported
+    #                   under "row_sharded" (TPNET_BENCH_SHARD=rows makes it the main leg).
     Bg = B * world
     cfg_run = dict(cfg, B=Bg)
     src, dst, neg, t, N = make_workload(cfg_run, W + K, 0)
-    torch.manual_seed(0)
-    P0 = torch.normal(0, 1 / np.sqrt(d), (N, d))
-    rp = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=cfg["E"], dim_factor=10, num_layer=L,
-                                          time_decay_weight=cfg["lam"], device=str(dev), use_matrix=False,
-                                          beginning_time=np.float64(0.0), not_scale=False, enforce_dim=d)
-    rp.random_projections[0].data = P0.clone()
-    rp = rp.to(dev)
+    shard = os.environ.get("TPNET_BENCH_SHARD", "cols") if (world > 1 or force_dist) else "single"
+    if shard == "cols" and (d % world or (d // world) % 4):
+        shard = "rows"
     to_dev = lambda x: torch.from_numpy(x).to(dev)
     d_src, d_dst, d_neg, d_t = to_dev(src), to_dev(dst), to_dev(neg), to_dev(t)
-    NG = rp.pair_wise_feature_dim
-    runner = None
-    if world > 1:
-        from tpnet_amd.sharded import ShardedStreamRunner
-        runner = ShardedStreamRunner(rp)
+    P0 = None
+
+    def make_full_module():
+        nonlocal P0
+        torch.manual_seed(0)
+        P0 = torch.normal(0, 1 / np.sqrt(d), (N, d))
+        m = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=cfg["E"], dim_factor=10, num_layer=L,
+                                             time_decay_weight=cfg["lam"], device=str(dev), use_matrix=False,
+                                             beginning_time=np.float64(0.0), not_scale=False, enforce_dim=d)
+        m.random_projections[0].data = P0.clone()
+        return m.to(dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(a, b_):
-        sl_ = slice(a * Bg, b_ * Bg)
-        if runner is None:
-            rp.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, out_pos=out_pos[:(b_ - a) * Bg],
-                          out_neg=out_neg[:(b_ - a) * Bg], t_end=float(t[b_ * Bg - 1]))
-        else:
+    CHUNK = 256                                    # steps per reduce-scatter of the column-sharded leg
+
+    def time_leg(run, k_steps):
+        """W untimed steps, then exactly k_steps timed ones between barrier + synchronize; max over ranks."""
+        if W > 0:
+            run(0, W)
+        barrier()
+        t0 = time.perf_counter()
+        run(W, W + k_steps)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    def rows_leg(k_steps):
+        from tpnet_amd.sharded import ShardedStreamRunner
+        m = make_full_module()
+        runner = ShardedStreamRunner(m)
+        m._workspace(max(k_steps, W) * Bg, Bg)
+
+        def run(a, b_):
+            sl_ = slice(a * Bg, b_ * Bg)
             t_last = t[np.minimum(np.arange(a + 1, b_ + 1) * Bg, len(t)) - 1]
             # features stay sharded by the owner of the pair's src node (a sharded decoder consumes them in place)
             runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last, merge_outputs=False)
+        el = time_leg(run, k_steps)
+        m.check_device_errors()
+        return el
 
+    rp = None
     out_pos = out_neg = None
-    if runner is None:
+    if shard == "single":
+        rp = make_full_module()
+        NG = rp.pair_wise_feature_dim
         out_pos = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
         out_neg = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
-    # warm-up: W untimed steps (also sizes the workspace for the timed call)
-    rp._workspace(K * Bg, Bg)
-    if W > 0:
-        run(0, W)
+        rp._workspace(K * Bg, Bg)
+
+        def run(a, b_):
+            sl_ = slice(a * Bg, b_ * Bg)
+            rp.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, out_pos=out_pos[:(b_ - a) * Bg],
+                          out_neg=out_neg[:(b_ - a) * Bg], t_end=float(t[b_ * Bg - 1]))
+        elapsed = time_leg(run, K)
+        rp.check_device_errors()
+    elif shard == "cols":
+        from tpnet_amd.sharded import ColumnShardedRunner
+        crun = ColumnShardedRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L,
+                                          time_decay_weight=cfg["lam"], device=dev, beginning_time=np.float64(0.0))
+        crun.rp._workspace(CHUNK * Bg, Bg)
+
+        def run(a, b_):
+            sl_ = slice(a * Bg, b_ * Bg)
+            ends = [min(x + CHUNK, b_) * Bg - 1 for x in range(a, b_, CHUNK)]
+            crun.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, chunk_steps=CHUNK, merge="scatter",
+                            t_chunk_last=t[ends])
+        elapsed = time_leg(run, K)
+        crun.rp.check_device_errors()
+    else:
+        elapsed = rows_leg(K)
+
+    par = {"single": "single GPU",
+           "cols": f"columns sharded over {world} GPUs ({d // world} of {d} per GPU), global batch {Bg} = {B} per GPU, no "
+                   f"per-step collective; raw Gram entries reduce-scattered (RCCL) per {CHUNK} steps behind the next "
+                   f"chunk's kernels",
+           "rows": f"rows sharded over {world} GPUs (owner = id % {world}), global batch {Bg} = {B} per GPU, one RCCL "
+                   f"all-gather of touched rows per step"}[shard]
+
+    def emit(row_info=None, roof=None, cpu=None):
+        line = {
+            "metric": "temporal edges/sec (proj-update + pairwise readout)",
+            "value": K * Bg / elapsed, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['desc']}, L=3, synthetic S({cfg['U']},{cfg['I']},E,span) "
+                                   f"stream of {(W + K) * Bg} edges, decoder-level unit (2 readouts + update per edge)",
+                       "batch": Bg, "dim": d, "num_layer": L, "nodes": N, "parallelism": par},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if row_info is not None:
+            line["row_sharded"] = row_info
+        print(json.dumps(line), flush=True)
+
+    # second leg at N > 1: the row-sharded layout on the same workload, fewer steps, behind a watchdog (a collective
+    # that never returns must not cost the main line)
+    row_info = None
+    if shard == "cols" and os.environ.get("TPNET_BENCH_ROWS_LEG", "1") != "0":
+        import threading
+        state = {"done": False}
+
+        def give_up():
+            if not state["done"]:
+                if rank == 0:
+                    emit({"error": "row-sharded leg did not finish within 150 s"})
+                os._exit(0)
+        wd = threading.Timer(150.0, give_up)
+        wd.daemon = True
+        kr = min(K, 500)
+        try:
+            wd.start()
+            el_r = rows_leg(kr)
+            row_info = {"value": kr * Bg / el_r, "unit": "edges/s", "steps": kr, "ms_per_step": el_r * 1e3 / kr,
+                        "parallelism": f"rows sharded over {world} GPUs (owner = id % {world}), one RCCL all-gather of "
+                                       f"touched rows per step"}
+        except Exception as ex:                   # noqa: BLE001 -- report, keep the main line
+            row_info = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        state["done"] = True
+        wd.cancel()
+
     sl = slice(W * Bg, (W + K) * Bg)
     a_src, a_dst, a_neg, a_t = d_src[sl], d_dst[sl], d_neg[sl], d_t[sl]
-    barrier()
-    t0 = time.perf_counter()
-    run(W, W + K)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    rp.check_device_errors()
 
     # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side), one extra
     # pass over the same K batches (state keeps advancing; throughput above is not affected)
     roof = None
-    if rank == 0 and world == 1:
+    if rank == 0 and shard == "single":
         lib = _lib.load()
         st = rp._state()
         ws = rp._workspace(K * B, B)
@@ -225,23 +317,9 @@ def main():
 
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and shard == "single":
             cpu = cpu_baseline(cfg, src, dst, neg, t, N, P0.numpy())
-        total_edges = K * Bg
-        line = {
-            "metric": "temporal edges/sec (proj-update + pairwise readout)",
-            "value": total_edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {cfg['desc']}, L=3, synthetic S({cfg['U']},{cfg['I']},E,span) "
-                                   f"stream of {(W + K) * Bg} edges, decoder-level unit (2 readouts + update per edge)",
-                       "batch": Bg, "dim": d, "num_layer": L, "nodes": N,
-                       "parallelism": "single GPU" if world == 1 else
-                       f"rows sharded over {world} GPUs (owner = id % {world}), global batch {Bg} = {B} per GPU, "
-                       f"one RCCL all-gather of touched rows per step"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line))
+        emit(row_info, roof, cpu)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -69,6 +69,11 @@ typedef struct tpnet_state {
 #define TPNET_FLAG_SEQUENTIAL 4u    /* update: never split a target's contributions over several wave groups:
                                        the sum is then accumulated in the reference's index order (src side,
                                        then dst side, models/TPNet.py:93-96) */
+#define TPNET_FLAG_PACKED 8u        /* readout (tpnet_pair_gram, tpnet_run_stream, tpnet_step_batch): write only the
+                                       (2L+2)(2L+3)/2 distinct entries a <= b of the symmetric Gram, raw (no x<0 -> 0 /
+                                       log), row-major upper triangle, row stride (2L+2)(2L+3)/2 floats -- the wire
+                                       format of the column-sharded table, whose partial inner products are summed
+                                       across GPUs before tpnet_gram_unpack finishes them */
 
 const char* tpnet_strerror(int status);
 int tpnet_abi_version(void);
@@ -187,6 +192,15 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
  * k' = 16 s + 8 h + j  <-  k = 16 s + 8 (j>>2) + 4 h + (j&3)   (s in 0..1, h in 0..1, j in 0..7). */
 int tpnet_mlp64_bf16(const float* x, int64_t n, const void* w1_bf16, const float* b1, const void* w2p_bf16,
                      const float* b2, float* y, void* stream);
+
+/* The readout's element-wise tail, in place on x[n]: x<0 -> 0, then log(x + 1) (models/TPNet.py:126-128).  For callers
+ * that ran the readout with TPNET_FLAG_NOT_SCALE because the raw Gram entries still had to be summed across GPUs
+ * (column-sharded table: every rank holds d/G columns of every row, the entries are partial inner products). */
+int tpnet_gram_finish(float* x, int64_t n, void* stream);
+
+/* packed[n][(2L+2)(2L+3)/2] (TPNET_FLAG_PACKED rows, summed over the ranks) -> out[n][(2L+2)^2]: mirrors the upper
+ * triangle and, unless TPNET_FLAG_NOT_SCALE, applies x<0 -> 0, log(x + 1). */
+int tpnet_gram_unpack(const float* packed, int64_t n, int32_t L, uint32_t flags, float* out, void* stream);
 
 /* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
  * the last call (and clears the words), TPNET_OK otherwise. */

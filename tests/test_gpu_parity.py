@@ -168,7 +168,8 @@ def _random_stream(rng, N, E, span, hub_frac=0.2):
 
 @pytest.mark.parametrize("d,L,N,B", [(64, 3, 300, 50), (128, 3, 500, 128), (256, 3, 200, 96), (512, 2, 150, 64),
                                      (120, 3, 260, 40), (140, 1, 90, 33), (30, 4, 64, 20), (1024, 1, 80, 16),
-                                     (128, 4, 333, 77), (64, 2, 1000, 500)])
+                                     (128, 4, 333, 77), (64, 2, 1000, 500), (16, 3, 400, 200), (32, 3, 300, 150),
+                                     (24, 2, 200, 64), (8, 4, 128, 100)])
 @pytest.mark.parametrize("exact", [True, False])
 def test_stream_matches_oracle(d, L, N, B, exact):
     """run_stream (fused readout + update per batch, ragged last batch) == oracle loop readout, readout, update."""
@@ -466,7 +467,7 @@ def test_deepcopy_pickle_and_launch_id_wrap():
 # ---------------------------------------------------------------------------------------------------------
 # odd shapes: tiny dims / graphs / batches, every edge identical, every layer count
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d", [1, 2, 3, 4, 8, 12, 36, 100, 260])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 8, 12, 16, 20, 32, 36, 100, 260])
 @pytest.mark.parametrize("L", [1, 2, 3, 4])
 def test_odd_shapes_fuzz(d, L):
     _need_gpu()
@@ -544,3 +545,40 @@ def test_internal_chunking_with_a_small_workspace():
                               2e-6, 100, 0, fb.data_ptr(), nb_.data_ptr(), tiny.data_ptr(), 1024, None,
                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# packed raw readout (the wire format of the column-sharded table) + tpnet_gram_unpack / tpnet_gram_finish
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,L", [(128, 3), (16, 3), (64, 2), (30, 1), (256, 4)])
+def test_packed_readout_unpacks_to_the_full_features(d, L):
+    _need_gpu()
+    import ctypes as C
+    from tpnet_amd import _lib
+    rng = np.random.RandomState(d + L)
+    N, B = 150, 64
+    E = 3 * B + 5
+    src, dst, neg, t = _random_stream(rng, N, E, 2.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    a = _module(N, d, L, 2e-6, t[0], P0=P0)
+    b = _module(N, d, L, 2e-6, t[0], P0=P0)
+    fp, fn = a.run_stream(dev(src), dev(dst), dev(neg), dev(t), B)
+    pp, pn = b.run_stream(dev(src), dev(dst), dev(neg), dev(t), B, packed=True)
+    NN = 2 * L + 2
+    assert pp.shape == (E, NN * (NN + 1) // 2) == (E, b.packed_feature_dim)
+    lib = _lib.load()
+    for full, pk in ((fp, pp), (fn, pn)):
+        out = torch.empty_like(full)
+        _lib.check(lib.tpnet_gram_unpack(pk.data_ptr(), E, L, 0, out.data_ptr(), b._stream()), "gram_unpack")
+        assert torch.equal(out, full)                      # same sums, same tail: identical bits
+    np.testing.assert_array_equal(_layers(a), _layers(b))
+    # module-level readout: packed -> unpack(NOT_SCALE) == raw; raw -> finish == scaled
+    raw = a.pair_gram(src[:B], neg[:B], raw=True)
+    pk = a.pair_gram(src[:B], neg[:B], packed=True)
+    out = torch.empty_like(raw)
+    _lib.check(lib.tpnet_gram_unpack(pk.data_ptr(), B, L, _lib.FLAG_NOT_SCALE, out.data_ptr(), a._stream()), "gram_unpack")
+    assert torch.equal(out, raw)
+    assert torch.equal(raw, raw.transpose(0, 1).reshape(NN, NN, B).permute(1, 0, 2).reshape(NN * NN, B).transpose(0, 1))  # symmetric
+    _lib.check(lib.tpnet_gram_finish(raw.data_ptr(), raw.numel(), a._stream()), "gram_finish")
+    assert torch.equal(raw, a.pair_gram(src[:B], neg[:B]))

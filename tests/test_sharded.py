@@ -146,3 +146,173 @@ def test_sharded_stream_equals_single_gpu(cfg):
     assert cmp[1] < 2e-4 and cmp[2] < 2e-4, cmp
     assert cmp[3] < 1e-5 and cmp[4], cmp
     np.testing.assert_array_equal(lay[0], lay[1])            # after sync_full_state every rank holds the same table
+
+
+# =========================================================================================================
+# column (dim) sharding: tpnet_amd.sharded.ColumnShardedRunner
+# =========================================================================================================
+class _FakeShard:
+    """Stands in for the local module on the CPU tier: writes 'partial features' (rank+1)*(edge+1) so that the
+    merged value of edge e is known: sum_r (r+1)(e+1)."""
+    not_scale = True
+    num_layer = 0                    # NN = 2: full rows of 4, packed rows of 3
+    pair_wise_feature_dim = 4
+    packed_feature_dim = 3
+    dim = 8
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.calls = []
+        self.e0 = 0
+
+    def _dev(self):
+        return torch.device("cpu")
+
+    def run_stream(self, src, dst, neg, t, B, out_pos=None, out_neg=None, t_end=None, packed=False):
+        assert packed
+        n = src.numel()
+        e = torch.arange(self.e0, self.e0 + n, dtype=torch.float32)
+        out_pos.copy_(((self.rank + 1) * (e + 1))[:, None].expand(n, 3))
+        if out_neg is not None:
+            out_neg.copy_((-(self.rank + 1) * (e + 1))[:, None].expand(n, 3))
+        self.calls.append((n, t_end))
+        self.e0 += n
+
+
+def _cpu_unpack(self, packed, out):
+    """CPU stand-in of tpnet_gram_unpack for the fake shard (NN = 2: entries (0,0), (0,1), (1,1))."""
+    out.copy_(packed[:, [0, 1, 1, 2]])
+    return out
+
+
+def _col_cpu_worker(rank, world, port, E, B, chunk_steps, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from tpnet_amd.sharded import ColumnShardedRunner
+        ColumnShardedRunner._unpack = _cpu_unpack            # the real one is a HIP kernel
+        src, dst, neg, t = _stream(2, 40, E)
+        ts = lambda x: torch.from_numpy(x)
+        ok = True
+        for merge in ("scatter", "all"):
+            fake = _FakeShard(rank)
+            runner = ColumnShardedRunner(fake, 8 * world)
+            fp, fn, idx = runner.run_stream(ts(src), ts(dst), ts(neg), ts(t), B, chunk_steps=chunk_steps, merge=merge)
+            tot = sum(r + 1 for r in range(world))
+            if merge == "all":
+                want = tot * (torch.arange(E, dtype=torch.float32) + 1)
+                ok &= idx is None and bool(torch.equal(fp[:, 0], want)) and bool(torch.equal(fn[:, 2], -want))
+            else:
+                keep = idx >= 0
+                want = tot * (idx[keep].to(torch.float32) + 1)
+                ok &= bool(torch.equal(fp[keep][:, 1], want)) and bool(torch.equal(fn[keep][:, 3], -want))
+                ok &= bool((fp[~keep] == 0).all())                       # padding rows carry zeros
+                allidx = [torch.empty_like(idx) for _ in range(world)]
+                dist.all_gather(allidx, idx)
+                got = torch.cat(allidx)
+                ok &= bool(torch.equal(torch.sort(got[got >= 0]).values, torch.arange(E)))   # every edge exactly once
+            # chunks end on batch boundaries and carry their own clock
+            ce = chunk_steps * B
+            ok &= [c[0] for c in fake.calls] == [min(ce, E - a) for a in range(0, E, ce)]
+            ok &= [c[1] for c in fake.calls] == [float(t[min(a + ce, E) - 1]) for a in range(0, E, ce)]
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E,B,chunk_steps", [(530, 64, 3), (96, 16, 2), (7, 3, 1)])
+def test_column_runner_merge_logic_gloo_world2(E, B, chunk_steps):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_col_cpu_worker, args=(r, 2, port, E, B, chunk_steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def _col_gpu_worker(rank, world, port, cfg, q):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        import tpnet_amd
+        from tpnet_amd.sharded import ColumnShardedRunner
+        N, d, L, E, B, lam, exact = cfg
+        dev = torch.device("cuda:0")
+        src, dst, neg, t = _stream(6, N, E)
+        P0 = torch.from_numpy((np.random.RandomState(3).randn(N, d) / np.sqrt(d)).astype(np.float32))
+        runner = ColumnShardedRunner.create(node_num=N, edge_num=E, dim=d, num_layer=L, time_decay_weight=lam,
+                                            device=dev, beginning_time=np.float64(t[0]), seed=1, exact=exact)
+        own_draw = runner.rp.random_projections[0].detach().cpu().clone()
+        runner.set_full_p0(P0)
+        D = lambda x: torch.from_numpy(x).to(dev)
+        half = (E // (2 * B)) * B
+        fp, fn, idx = runner.run_stream(D(src[:half]), D(dst[:half]), D(neg[:half]), D(t[:half]), B, chunk_steps=2)
+        # second part through the module-level calls (what a per-batch training loop does)
+        fp2 = []
+        for a in range(half, E, B):
+            s = slice(a, min(a + B, E))
+            fp2.append(runner.pair_gram(src[s], dst[s]))
+            runner.update(src[s], dst[s], t[s])
+        fp2 = torch.cat(fp2)
+        full = runner.gather_full_layers().cpu()
+        runner.rp.check_device_errors()
+        allp = [torch.empty_like(fp) for _ in range(world)]; alli = [torch.empty_like(idx) for _ in range(world)]
+        alln = [torch.empty_like(fn) for _ in range(world)]
+        dist.all_gather(allp, fp); dist.all_gather(alli, idx); dist.all_gather(alln, fn)
+        if rank == 0:
+            ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L,
+                                                   time_decay_weight=lam, device="cuda:0", use_matrix=False,
+                                                   beginning_time=np.float64(t[0]), not_scale=False, enforce_dim=d,
+                                                   exact=exact)
+            ref.random_projections[0].data = P0.clone()
+            ref = ref.to(dev)
+            rfp, rfn = ref.run_stream(D(src[:half]), D(dst[:half]), D(neg[:half]), D(t[:half]), B)
+            rfp2 = []
+            for a in range(half, E, B):
+                s = slice(a, min(a + B, E))
+                rfp2.append(ref.pair_gram(src[s], dst[s]))
+                ref.update(src[s], dst[s], t[s])
+            rfp2 = torch.cat(rfp2)
+            rl = torch.stack([ref.random_projections[i].detach() for i in range(L + 1)]).cpu()
+            ii = torch.cat(alli); keep = ii >= 0
+            gp = torch.empty_like(rfp); gn = torch.empty_like(rfn)
+            gp[ii[keep]] = torch.cat(allp)[keep]; gn[ii[keep]] = torch.cat(alln)[keep]
+            q.put(("cmp", int(keep.sum()) == half, float((gp - rfp).abs().max()), float((gn - rfn).abs().max()),
+                   float((fp2 - rfp2).abs().max()), bool(torch.equal(full, rl)),
+                   float((full - rl).abs().max() / rl.abs().max()), float(runner.rp.now_time.item()) == float(t[-1])))
+        q.put(("p0", rank, own_draw.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(211, 128, 3, 700, 100, 2e-6, False), (150, 64, 2, 333, 50, 1e-6, True),
+                                 (90, 32, 3, 420, 60, 2e-6, False)])
+def test_column_sharded_stream_equals_single_gpu(cfg):
+    """Two ranks (gloo) sharing cuda:0, each with half of the columns: features == the single-GPU features up to the
+    association of the sum over d, the table == the single-GPU table (bit for bit in exact mode: a column's
+    arithmetic does not depend on which other columns share its GPU)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_col_gpu_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    msgs = [q.get(timeout=300) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=120)
+    cmp = [m for m in msgs if m[0] == "cmp"][0]
+    p0s = {m[1]: m[2] for m in msgs if m[0] == "p0"}
+    assert cmp[1] and cmp[7], cmp
+    assert cmp[2] < 2e-4 and cmp[3] < 2e-4 and cmp[4] < 2e-4, cmp
+    if cfg[-1]:
+        assert cmp[5], cmp                                    # exact mode: identical bits
+    assert cmp[6] < 1e-5, cmp
+    # the ranks' own draws of P[0] are independent and scaled for the FULL width
+    assert not np.array_equal(p0s[0], p0s[1])
+    assert abs(np.std(np.concatenate([p0s[0], p0s[1]])) * np.sqrt(cfg[1]) - 1.0) < 0.05

@@ -9,7 +9,9 @@ os.environ.setdefault("TPNET_DEV_LIB", os.path.join(ROOT, "tpnet_amd", "libtpnet
 import tpnet_amd
 from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "C2"
-c = CONFIGS[cfgname]; B = c["B"]; nbw = 40; E = (nbw + 1) * B
+c = dict(CONFIGS[cfgname])
+if len(sys.argv) > 3: c["d"] = int(sys.argv[2]); c["B"] = int(sys.argv[3])      # overrides: stamps.py C2 16 8000
+B = c["B"]; nbw = 40; E = (nbw + 1) * B
 src, dst, t, N = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
 neg = synthetic_negatives(c["U"], N, E, B, 1)
 dev = torch.device("cuda:0")
@@ -23,7 +25,7 @@ for rep in range(3):
 rp._eng["ws"][: 1 << 20].zero_()
 rp.run_stream(ds[nbw * B:], dd[nbw * B:], dn[nbw * B:], dt[nbw * B:], B, t_end=float(t[-1]))           # ONE launch
 torch.cuda.synchronize()
-raw = rp._eng["ws"][: 1 << 20].cpu().numpy().view(np.uint64).reshape(-1, 8, 2)[:4000].astype(np.int64)
+raw = rp._eng["ws"][: 1 << 20].cpu().numpy().view(np.uint64).reshape(-1, 8, 2)[:8000].astype(np.int64)
 clk, wall = raw[:, :, 0], raw[:, :, 1]
 used = clk[:, 0] > 0
 t0 = wall[used, 0].min()

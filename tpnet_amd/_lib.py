@@ -13,6 +13,7 @@ TPNET_MAX_LAYERS = 4
 FLAG_NOT_SCALE = 1
 FLAG_EAGER_DECAY = 2
 FLAG_SEQUENTIAL = 4
+FLAG_PACKED = 8
 
 ERR_INDEX = -4
 
@@ -59,6 +60,8 @@ SIGNATURES = {
     "tpnet_sampler_build": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "tpnet_sample_recent": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "tpnet_mlp64_bf16": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "tpnet_gram_finish": (C.c_int, [_P, C.c_int64, _P]),
+    "tpnet_gram_unpack": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_uint32, _P, _P]),
     "tpnet_check_errors": (C.c_int, [_SP, _P]),
     "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                     C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),

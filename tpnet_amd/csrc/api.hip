@@ -183,6 +183,7 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
     int rc = check_state(st);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!u || !v1 || !v2 || !out1 || !out2))) return TPNET_ERR_BAD_ARG;
+    if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;   // packed rows exist for the one-pair readout only
     return launch_pair_gram_shared(*st, u, v1, v2, n, now_time, lambda, flags, out1, out2, (hipStream_t)stream);
 }
 
@@ -281,6 +282,16 @@ int tpnet_unpack_gathered(const tpnet_state* st, const int64_t* ids, int64_t n, 
     if (rc) return rc;
     if (n < 0 || G < 1 || me < 0 || me >= G || maxc < 0 || (n > 0 && (!ids || !recv || !offs))) return TPNET_ERR_BAD_ARG;
     return launch_unpack_gathered(*st, ids, n, now_time, recv, maxc, offs, G, me, (hipStream_t)stream);
+}
+
+int tpnet_gram_finish(float* x, int64_t n, void* stream) {
+    if (n < 0 || (n > 0 && !x)) return TPNET_ERR_BAD_ARG;
+    return tpnet::launch_gram_finish(x, n, (hipStream_t)stream);
+}
+
+int tpnet_gram_unpack(const float* packed, int64_t n, int32_t L, uint32_t flags, float* out, void* stream) {
+    if (n < 0 || L < 1 || L > TPNET_MAX_LAYERS || (n > 0 && (!packed || !out))) return TPNET_ERR_BAD_ARG;
+    return tpnet::launch_gram_unpack(packed, n, L, flags, out, (hipStream_t)stream);
 }
 
 int tpnet_check_errors(const tpnet_state* st, void* stream) {

@@ -151,6 +151,7 @@ struct GramCfg {
     static constexpr int NR = L + 1;
     static constexpr int NN = 2 * NR;
     static constexpr int NG = NN * NN;
+    static constexpr int NT = NN * (NN + 1) / 2;   // distinct entries of the symmetric Gram (TPNET_FLAG_PACKED rows)
     static constexpr int MP = ((NG + LPP - 1) / LPP) * LPP;
     static constexpr int PER = MP / LPP;
 };
@@ -168,7 +169,7 @@ __device__ __forceinline__ void ldv_maybe(const float* __restrict__ row, int vi,
 template <int LPP, int VPL, int W, int L, bool FULL>
 __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
                                           double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
-                                          unsigned long long* dbg = nullptr) {
+                                          unsigned long long* dbg = nullptr, bool packed = false) {
     using C = GramCfg<LPP, L>;
     constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
     const int d = S.d;
@@ -254,7 +255,13 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
                     x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
                 }
                 if (!idok) x = __builtin_nanf("");
-                __builtin_nontemporal_store(x, out + idx);   // features are consumed by another kernel: stream them out
+                int o = idx;
+                if (packed) {                    // TPNET_FLAG_PACKED: only the entries a <= b, row-major upper triangle
+                    const int a = idx / NN, b = idx - a * NN;
+                    if (a > b) continue;
+                    o = a * NN - (a * (a - 1)) / 2 + (b - a);
+                }
+                __builtin_nontemporal_store(x, out + o);     // features are consumed by another kernel: stream them out
             }
         }
     }
@@ -268,12 +275,15 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
     constexpr int NG = GramCfg<LPP, L>::NG;
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
-    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
+    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
+    const int stride = packed ? GramCfg<LPP, L>::NT : NG;
     for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
         const int64_t p = base + g;
         const bool valid = p < n;
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
-        gram_pair<LPP, VPL, W, L, FULL>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * NG, gl);
+        gram_pair<LPP, VPL, W, L, FULL>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * stride, gl,
+                                        nullptr, packed);
     }
 }
 
@@ -833,7 +843,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_sr
     }
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
-    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
+    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
+    const int ostride = packed ? GramCfg<LPP, L>::NT : NG;
     const int64_t ne = ne_;
     const int64_t npos = ((flags & ROLE_READOUT) && a.out_pos) ? ne : 0;
     const int64_t nneg = ((flags & ROLE_READOUT) && a.out_neg) ? ne : 0;
@@ -857,11 +869,11 @@ __global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_sr
                 if (w < npos) {
                     e = e0 + w;
                     v = a_dst[e];
-                    out = a.out_pos + e * NG;
+                    out = a.out_pos + e * ostride;
                 } else {
                     e = e0 + (w - npos);
                     v = a_neg[e];
-                    out = a.out_neg + e * NG;
+                    out = a.out_neg + e * ostride;
                 }
                 u = a_src[e];
             }
@@ -869,7 +881,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_sr
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
             const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
             if (!__any(mine)) continue;
-            gram_pair<LPP, VPL, W, L, FULL>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg);
+            gram_pair<LPP, VPL, W, L, FULL>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, packed);
             STAMP(5);
         } else {
             const int64_t it = w - RP;
@@ -1154,6 +1166,52 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
     return TPNET_OK;
 }
 
+// element-wise tail of the readout on a buffer of raw Gram entries (same two operations, in the same order, as the
+// fused store of gram_pair)
+__global__ void k_gram_finish(float* __restrict__ x, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = x[i];
+        v = (v < 0.0f) ? 0.0f : v;
+        x[i] = logf(v + 1.0f);
+    }
+}
+
+// packed rows (TPNET_FLAG_PACKED: NN(NN+1)/2 raw entries a <= b) -> full [NN*NN] feature rows, with the element-wise tail
+__global__ void k_gram_unpack(const float* __restrict__ packed, int64_t n, int NN, int do_scale, float* __restrict__ out) {
+    const int NG = NN * NN, NT = NN * (NN + 1) / 2;
+    const int64_t total = n * NG;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t p = i / NG;
+        const int idx = (int)(i - p * NG);
+        int a = idx / NN, b = idx - a * NN;
+        if (a > b) { const int z = a; a = b; b = z; }
+        float v = packed[p * NT + a * NN - (a * (a - 1)) / 2 + (b - a)];
+        if (do_scale) {
+            v = (v < 0.0f) ? 0.0f : v;
+            v = logf(v + 1.0f);
+        }
+        out[i] = v;
+    }
+}
+
+int launch_gram_unpack(const float* packed, int64_t n, int L, uint32_t flags, float* out, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    const int NN = 2 * L + 2;
+    hipLaunchKernelGGL(k_gram_unpack, dim3(grid_for(n * NN * NN, 256, 256 * 16)), dim3(256), 0, s, packed, n, NN,
+                       (flags & TPNET_FLAG_NOT_SCALE) ? 0 : 1, out);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_gram_finish(float* x, int64_t n, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_gram_finish, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, x, n);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 // dispatch over (geometry, L, exact-fit)
 #define TPNET_DISPATCH_L(LPP_, VPL_, W_, FULL_, CALL)                           \
     switch (st.L) {                                                             \
@@ -1169,6 +1227,8 @@ int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, dou
         const Geom gm = (GEOM);                                                 \
         const bool full = gm.w == 4 && st.d == gm.lpp * gm.vpl * 4;             \
         if (gm.w == 1) { TPNET_DISPATCH_L(64, 1, 1, false, CALL) }              \
+        else if (gm.lpp == 4) { if (full) { TPNET_DISPATCH_L(4, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(4, 1, 4, false, CALL) } } \
+        else if (gm.lpp == 8) { if (full) { TPNET_DISPATCH_L(8, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(8, 1, 4, false, CALL) } } \
         else if (gm.lpp == 16 && gm.vpl == 2) { if (full) { TPNET_DISPATCH_L(16, 2, 4, true, CALL) } else { TPNET_DISPATCH_L(16, 2, 4, false, CALL) } } \
         else if (gm.lpp == 16) { if (full) { TPNET_DISPATCH_L(16, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(16, 1, 4, false, CALL) } } \
         else if (gm.lpp == 32 && gm.vpl == 1) { if (full) { TPNET_DISPATCH_L(32, 1, 4, true, CALL) } else { TPNET_DISPATCH_L(32, 1, 4, false, CALL) } } \

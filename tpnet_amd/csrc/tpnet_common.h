@@ -88,6 +88,10 @@ inline Geom pick_geom(int d, bool many = false) {
     static const char* g0 = getenv("TPNET_DEV_GEOM");
     if (g0 && g0[0] == '1' && g0[3] == '2' && nvec <= 32) return {16, 2, 4};   // developer override "16x2"
     if (many && nvec > 16 && nvec <= 32) return {16, 2, 4};
+    // narrow rows (the column slices of a dim-sharded table, tpnet_amd/sharded.py): 4 / 8 lanes per row, so that a wave
+    // carries 16 / 8 pairs instead of 4 with three quarters of its lanes idle
+    if (nvec <= 4) return {4, 1, 4};
+    if (nvec <= 8) return {8, 1, 4};
     if (nvec <= 16) return {16, 1, 4};
     if (nvec <= 32) return {32, 1, 4};
     static const char* g = getenv("TPNET_DEV_GEOM");          // developer override: "64x1", "64x2", "32x2"
@@ -106,6 +110,8 @@ int launch_state_init(const tpnet_state& st, double t0, hipStream_t s);
 int launch_import(const tpnet_state& st, const float* const* layers_dev, double now, hipStream_t s);
 int launch_export(const tpnet_state& st, float* const* layers_dev, double now, double lambda, hipStream_t s);
 int launch_decay(const tpnet_state& st, const float* factors_host, double t_new, hipStream_t s);
+int launch_gram_finish(float* x, int64_t n, hipStream_t s);
+int launch_gram_unpack(const float* packed, int64_t n, int L, uint32_t flags, float* out, hipStream_t s);
 int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
                        hipStream_t s);
 int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,

@@ -326,17 +326,29 @@ class RandomProjectionModule(nn.Module):
                    "gather_rows")
         return [out[i] for i in range(self.num_layer + 1)]
 
-    def pair_gram(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray) -> torch.Tensor:
-        """The pairwise feature BEFORE self.mlp (models/TPNet.py:119-128): [n, (2L+2)^2] on the GPU."""
+    @property
+    def packed_feature_dim(self) -> int:
+        """Distinct entries of the symmetric (2L+2) x (2L+2) Gram: the row length of `packed` readouts."""
+        nn_ = 2 * self.num_layer + 2
+        return nn_ * (nn_ + 1) // 2
+
+    def pair_gram(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, raw: bool = False,
+                  packed: bool = False) -> torch.Tensor:
+        """The pairwise feature BEFORE self.mlp (models/TPNet.py:119-128): [n, (2L+2)^2] on the GPU.  `raw` leaves
+        out the x<0 -> 0, log(x+1) tail whatever `not_scale` says (partial inner products of a column shard);
+        `packed` (implies raw) returns only the distinct entries a <= b: [n, packed_feature_dim]."""
         self._ensure_engine()
         if len(src_node_ids) != len(dst_node_ids):
             raise ValueError("src_node_ids and dst_node_ids must have the same length")
         u, v = self._to_device(self._check_ids(src_node_ids, "src_node_ids"),
                                self._check_ids(dst_node_ids, "dst_node_ids"))
         n = u.numel()
-        out = torch.empty((n, self.pair_wise_feature_dim), dtype=torch.float32, device=self._dev())
+        out = torch.empty((n, self.packed_feature_dim if packed else self.pair_wise_feature_dim),
+                          dtype=torch.float32, device=self._dev())
         st = self._state()
-        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        flags = _lib.FLAG_NOT_SCALE if (self.not_scale or raw or packed) else 0
+        if packed:
+            flags |= _lib.FLAG_PACKED
         _lib.check(_lib.load().tpnet_pair_gram(C.byref(st), u.data_ptr(), v.data_ptr(), n, self._now_host,
                                                float(self.time_decay_weight), flags, out.data_ptr(), self._stream()),
                    "pair_gram")
@@ -426,11 +438,13 @@ class RandomProjectionModule(nn.Module):
     # extension: device-resident edge stream (the reference's batch loop, train_link_prediction.py:253-373)
     # ------------------------------------------------------------------------------------------------------
     def run_stream(self, src: torch.Tensor, dst: torch.Tensor, neg, t: torch.Tensor, batch_size: int,
-                   want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None):
+                   want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None,
+                   raw: bool = False, packed: bool = False):
         """For each chronological batch: pre-mlp pairwise features of (src,dst) and (src,neg) on the pre-batch
         state, then update().  src/dst/neg: int64 [E] on the GPU, t: float64 [E] on the GPU.  Returns
         (feat_pos, feat_neg) of shape [E, (2L+2)^2] (None where not requested).  `t_end` = t[-1] if the caller
-        already has it on the host (avoids one 8-byte device->host copy)."""
+        already has it on the host (avoids one 8-byte device->host copy).  `raw` / `packed`: features without the
+        x<0 -> 0, log(x+1) tail / only their distinct entries, rows of packed_feature_dim (see pair_gram)."""
         self._ensure_engine()
         dev = self._dev()
         E = int(src.numel())
@@ -440,7 +454,7 @@ class RandomProjectionModule(nn.Module):
         if neg is not None and (neg.device != dev or neg.dtype != torch.int64 or neg.numel() != E):
             raise ValueError("run_stream: neg must be an int64 tensor of the same length on the same device")
         want_neg = want_neg and neg is not None
-        NG = self.pair_wise_feature_dim
+        NG = self.packed_feature_dim if packed else self.pair_wise_feature_dim
         if want_pos and out_pos is None:
             out_pos = torch.empty((E, NG), dtype=torch.float32, device=dev)
         if want_neg and out_neg is None:
@@ -451,7 +465,9 @@ class RandomProjectionModule(nn.Module):
         st = self._state()
         nb = (E + batch_size - 1) // batch_size
         lid = self._next_launch_ids(nb)
-        flags = (_lib.FLAG_NOT_SCALE if self.not_scale else 0)
+        flags = (_lib.FLAG_NOT_SCALE if (self.not_scale or raw or packed) else 0)
+        if packed:
+            flags |= _lib.FLAG_PACKED
         if self.exact:
             flags |= _lib.FLAG_EAGER_DECAY | _lib.FLAG_SEQUENTIAL
         t_out = C.c_double(0.0)

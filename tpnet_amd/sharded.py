@@ -1,5 +1,15 @@
-"""Row-sharded multi-GPU runner of the temporal-walk-matrix hot path (new capability: the
-reference is single-device, utils/load_configs.py:88).
+"""Multi-GPU runners of the temporal-walk-matrix hot path (new capability: the reference is
+single-device, utils/load_configs.py:88).  Two ways to cut the table, both one process per GPU:
+
+* `ShardedStreamRunner`  -- ROW sharding, the contract of BASELINE.json's north_star: described below.
+* `ColumnShardedRunner`  -- COLUMN (dim) sharding (SURVEY.md §8e "worth measuring"): every rank keeps all N rows but
+  only d/G of the d columns.  The update is column-wise independent (P[i][u, :] += w * P[i-1][v, :]), so it needs NO
+  exchange at all; only the readout's inner products are partial sums, and they are summed over the ranks when the
+  features leave the path (one reduce-scatter per chunk of steps, overlapped with the next chunk's kernels).  No
+  collective sits on the per-batch critical path, which is what a 7 us step needs: see DESIGN.md §6.
+
+Row sharding
+------------
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI in production; "gloo" in the tests).
 Rows are owned cyclically, owner(n) = n % G (spreads the power-law head over the ranks).  Every rank holds the
@@ -19,12 +29,16 @@ rows and are merged by one all-reduce at the end of the stream.  Results equal t
 extra f32 rounding of the exchanged rows' pending decay (<= 1e-6 relative).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import _lib
+
+# development: issue the collectives even with a single rank (exercises the RCCL calls on a one-GPU box)
+_FORCE = os.environ.get("TPNET_DEV_FORCE_COLLECTIVES") == "1"
 
 
 def plan_touched(src: torch.Tensor, dst: torch.Tensor, neg, batch: int, N: int, G: int):
@@ -108,7 +122,7 @@ class ShardedStreamRunner:
         offs_rel = torch.from_numpy(offsets - offsets[:, :1]).to(dev).contiguous()   # [nb, G] owner runs inside a batch
         tot = counts.sum(axis=1)
         now = rp._now_host
-        nccl = G > 1 and dist.get_backend(self.group) == "nccl"
+        nccl = (G > 1 or _FORCE) and dist.get_backend(self.group) == "nccl"
         # host-side loop: everything per batch is precomputed as plain ints / raw pointers (the loop issues 3 kernel
         # launches + 1 collective per batch and must not be the bottleneck)
         stp = C.byref(st)
@@ -124,7 +138,7 @@ class ShardedStreamRunner:
         flat_recv = recv_all.view(-1)
         for b in range(nb):
             maxc = maxcs[b]
-            if G > 1 and maxc > 0:
+            if (G > 1 or _FORCE) and maxc > 0:
                 rc = pack(stp, nodes_ptr + 8 * off_me[b], cnt_me[b], now, lam, send_ptr, stream)
                 if rc:
                     _lib.check(rc, "pack_rows")
@@ -177,3 +191,190 @@ class ShardedStreamRunner:
             _lib.check(lib.tpnet_unpack_rows(C.byref(st), ids_r.data_ptr(), ids_r.numel(), rp._now_host,
                                              recv[r].data_ptr(), stream), "unpack_rows")
         rp._params_valid = False
+
+
+# =====================================================================================================================
+class ColumnShardedRunner:
+    """Column (dim) sharding of the table over the ranks of `group`: rank r holds columns [r*d/G, (r+1)*d/G) of every
+    row of P[0..L] in an ordinary `RandomProjectionModule` of dim d/G.
+
+    * update():  local, no communication (each column of models/TPNet.py:87-97 evolves on its own; the time weights
+      and decay factors do not depend on the column).  The local slice is bit-identical to the same columns of a
+      single-GPU table.
+    * readout:   the local Gram entries are partial inner products (sum over the local columns); they are summed
+      across ranks BEFORE the x<0 -> 0, log(x+1) tail (tpnet_gram_finish), so the result differs from the
+      single-GPU one only in the association of the f32 sum over d.
+    * stream:    `run_stream` walks the stream in chunks of steps; a chunk's raw features are reduce-scattered over
+      the ranks (each rank ends up with the finished features of 1/G of the chunk's edges -- the shape a
+      data-parallel decoder consumes) while the next chunk's kernels run.
+    """
+
+    def __init__(self, rp_local, full_dim: int, group=None):
+        self.rp = rp_local
+        self.group = group
+        self.G = dist.get_world_size(group)
+        self.me = dist.get_rank(group)
+        self.full_dim = int(full_dim)
+        if rp_local.dim * self.G != self.full_dim:
+            raise ValueError(f"local dim {rp_local.dim} x {self.G} ranks != full dim {full_dim}")
+
+    # ---- construction -------------------------------------------------------------------------------------------
+    @classmethod
+    def create(cls, node_num: int, edge_num: int, dim: int, num_layer: int, time_decay_weight: float, device,
+               beginning_time, not_scale: bool = False, group=None, seed: int = 0, exact: bool = False):
+        """Build the local module.  P[0] ~ N(0, 1/sqrt(dim)) over the FULL width (models/TPNet.py:58); each rank draws
+        its own columns from a generator seeded with (seed, rank), so the slices are independent whatever the
+        process-wide seed is."""
+        from .random_projection import RandomProjectionModule
+        G = dist.get_world_size(group)
+        me = dist.get_rank(group)
+        if dim % G:
+            raise ValueError(f"dim {dim} is not divisible by the {G} ranks")
+        rp = RandomProjectionModule(node_num=node_num, edge_num=edge_num, dim_factor=1, num_layer=num_layer,
+                                    time_decay_weight=time_decay_weight, device=str(device), use_matrix=False,
+                                    beginning_time=beginning_time, not_scale=not_scale, enforce_dim=dim // G,
+                                    exact=exact)
+        self = cls(rp, dim, group)
+        self._seed = int(seed)
+        self._draw_p0(0)
+        self.rp = rp.to(device)
+        return self
+
+    def _draw_p0(self, epoch: int):
+        gen = torch.Generator().manual_seed((self._seed * 1000003 + epoch) * 1021 + self.me)
+        p0 = self.rp._plist()[0]
+        fresh = torch.normal(0.0, 1.0 / np.sqrt(self.full_dim), (self.rp.node_num, self.rp.dim), generator=gen)
+        p0.data.copy_(fresh.to(p0.device))
+
+    def set_full_p0(self, P0_full: torch.Tensor):
+        """Take this rank's columns of a full-width [N, d] layer-0 matrix (tests, checkpoints of a single-GPU run)."""
+        dl = self.rp.dim
+        self.rp._plist()[0].data.copy_(P0_full[:, self.me * dl:(self.me + 1) * dl].to(self.rp._plist()[0].device))
+
+    def reset_random_projections(self, epoch: int = 0):
+        """models/TPNet.py:132-139 on the shard: layers 1..L to zero, clock to the beginning, P[0] redrawn."""
+        self.rp.reset_random_projections()
+        if hasattr(self, "_seed"):
+            self._draw_p0(epoch + 1)
+
+    # ---- module-level API -----------------------------------------------------------------------------------------
+    def update(self, src_node_ids, dst_node_ids, node_interact_times):
+        self.rp.update(src_node_ids=src_node_ids, dst_node_ids=dst_node_ids, node_interact_times=node_interact_times)
+
+    def _unpack(self, packed: torch.Tensor, out: torch.Tensor):
+        """Summed packed rows -> full feature rows, with the element-wise tail (tpnet_gram_unpack)."""
+        n = packed.shape[0]
+        if n:
+            flags = _lib.FLAG_NOT_SCALE if self.rp.not_scale else 0
+            _lib.check(_lib.load().tpnet_gram_unpack(packed.data_ptr(), n, self.rp.num_layer, flags, out.data_ptr(),
+                                                     self.rp._stream()), "gram_unpack")
+        return out
+
+    def pair_gram(self, src_node_ids, dst_node_ids) -> torch.Tensor:
+        """Complete pre-mlp features on every rank: local partial Gram (distinct entries only), all-reduce, unpack."""
+        pk = self.rp.pair_gram(src_node_ids, dst_node_ids, packed=True)
+        if self.G > 1 or _FORCE:
+            dist.all_reduce(pk, group=self.group)
+        out = torch.empty((pk.shape[0], self.rp.pair_wise_feature_dim), dtype=torch.float32, device=pk.device)
+        return self._unpack(pk, out)
+
+    def get_pair_wise_feature(self, src_node_ids, dst_node_ids):
+        return self.rp._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
+
+    # ---- device-resident stream -----------------------------------------------------------------------------------
+    def run_stream(self, src, dst, neg, t, batch_size: int, chunk_steps: int = 256, merge: str = "scatter",
+                   t_chunk_last=None):
+        """Same per-batch semantics as RandomProjectionModule.run_stream, over all ranks.
+
+        merge = "scatter": returns (feat_pos, feat_neg, edge_index): this rank's share of the finished features,
+                           [M, (2L+2)^2] each, and the global edge number of every row (int64 [M], -1 = padding row of
+                           a chunk whose edge count is not a multiple of the world size).
+        merge = "all":     returns (feat_pos, feat_neg, None) with all E rows on every rank (all-reduce).
+        On the wire: the (2L+2)(2L+3)/2 distinct raw Gram entries per pair (144 B at L=3), f32.
+        `t_chunk_last`: t at the last edge of every chunk, if the caller has it on the host (else one small
+        device->host copy up front)."""
+        rp, G, me = self.rp, self.G, self.me
+        if merge not in ("scatter", "all"):
+            raise ValueError("merge must be 'scatter' or 'all'")
+        dev = rp._dev()
+        E, B = int(src.numel()), int(batch_size)
+        NG, NT = rp.pair_wise_feature_dim, rp.packed_feature_dim
+        ce = max(1, int(chunk_steps)) * B
+        bounds = [(a, min(a + ce, E)) for a in range(0, E, ce)]
+        have_neg = neg is not None
+        if E == 0:
+            z = torch.empty((0, NG), dtype=torch.float32, device=dev)
+            return z, (z.clone() if have_neg else None), (torch.empty(0, dtype=torch.int64, device=dev) if merge == "scatter" else None)
+        if t_chunk_last is None:
+            idx = torch.tensor([b - 1 for _, b in bounds], device=dev)
+            t_chunk_last = t[idx].cpu().numpy()
+        coll = G > 1 or _FORCE
+        nccl = coll and dist.get_backend(self.group) == "nccl"
+        K = 2 if have_neg else 1
+        scatter = merge == "scatter"
+        # rank r receives rows [r*m, (r+1)*m) of every (padded) chunk in scatter mode, all rows otherwise
+        ms = [((b - a) + G - 1) // G if scatter else (b - a) for a, b in bounds]
+        offs = np.concatenate([[0], np.cumsum(ms)]).astype(np.int64)
+        M = int(offs[-1])
+        outs = [torch.empty((M, NG), dtype=torch.float32, device=dev) for _ in range(K)]
+        edge_index = torch.empty(M, dtype=torch.int64, device=dev) if scatter else None
+        mmax = max(ms)
+        rows_raw = mmax * G if scatter else mmax
+        # two rotating sets of buffers: chunk c+1 is computed while chunk c is on the wire
+        raws = [[torch.zeros((rows_raw, NT), dtype=torch.float32, device=dev) for _ in range(K)] for _ in range(2)]
+        recvs = [[torch.empty((mmax, NT), dtype=torch.float32, device=dev) for _ in range(K)] for _ in range(2)] \
+            if scatter else raws
+        works = []
+
+        def finish(c):                            # chunk c: wait for its collectives, then unpack + element-wise tail
+            self._complete(works, c)
+            for k in range(K):
+                self._unpack(recvs[c % 2][k][:ms[c]], outs[k][offs[c]:offs[c + 1]])
+
+        for c, (a, b) in enumerate(bounds):
+            n, m = b - a, ms[c]
+            raw = raws[c % 2]
+            if scatter and n < m * G:             # padding rows of a ragged chunk: defined values on the wire
+                for r_ in raw:
+                    r_[n:m * G].zero_()
+            rp.run_stream(src[a:b], dst[a:b], neg[a:b] if have_neg else None, t[a:b], B, out_pos=raw[0][:n],
+                          out_neg=raw[1][:n] if have_neg else None, t_end=float(t_chunk_last[c]), packed=True)
+            w = []
+            for k in range(K):
+                if not scatter:
+                    if coll:
+                        w.append(dist.all_reduce(raw[k][:n], group=self.group, async_op=True))
+                elif nccl:
+                    w.append(dist.reduce_scatter_tensor(recvs[c % 2][k][:m], raw[k][:m * G], group=self.group,
+                                                        async_op=True))
+                elif coll:                         # gloo (tests): all-reduce, keep the own share
+                    dist.all_reduce(raw[k][:m * G], group=self.group)
+                    recvs[c % 2][k][:m].copy_(raw[k][me * m:(me + 1) * m])
+                else:
+                    recvs[c % 2][k][:m].copy_(raw[k][:m])
+            works.append(w)
+            if scatter:
+                ids = a + me * m + torch.arange(m, device=dev, dtype=torch.int64)
+                edge_index[offs[c]:offs[c + 1]] = torch.where(ids < b, ids, torch.full_like(ids, -1))
+            if c >= 1:                            # chunk c-1 has had chunk c's kernels to hide behind
+                finish(c - 1)
+        finish(len(bounds) - 1)
+        return outs[0], (outs[1] if have_neg else None), edge_index
+
+    @staticmethod
+    def _complete(works, c):
+        if c < len(works):
+            for w in works[c]:
+                if w is not None:
+                    w.wait()                      # the compute stream waits for the collective (no host block with nccl)
+            works[c] = []
+
+    def gather_full_layers(self):
+        """All ranks' column slices side by side: [L+1, N, d] on every rank (tests / checkpoints; N*d*(L+1)*4 bytes)."""
+        rp = self.rp
+        local = torch.stack([rp.random_projections[i].detach() for i in range(rp.num_layer + 1)])    # [L+1, N, dl]
+        if self.G == 1:
+            return local
+        parts = [torch.empty_like(local) for _ in range(self.G)]
+        dist.all_gather(parts, local.contiguous(), group=self.group)
+        return torch.cat(parts, dim=2)
