@@ -161,7 +161,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    CHUNK = 256                                    # steps per reduce-scatter of the column-sharded leg
 
     def time_leg(run, k_steps):
         """W untimed steps, then exactly k_steps timed ones between barrier + synchronize; max over ranks."""
@@ -212,13 +211,12 @@ def main():
         from tpnet_amd.sharded import ColumnShardedRunner
         crun = ColumnShardedRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L,
                                           time_decay_weight=cfg["lam"], device=dev, beginning_time=np.float64(0.0))
-        crun.rp._workspace(CHUNK * Bg, Bg)
+        crun.rp._workspace(min(K * Bg, 2_000_000 + Bg), Bg)
 
         def run(a, b_):
             sl_ = slice(a * Bg, b_ * Bg)
-            ends = [min(x + CHUNK, b_) * Bg - 1 for x in range(a, b_, CHUNK)]
-            crun.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, chunk_steps=CHUNK, merge="scatter",
-                            t_chunk_last=t[ends])
+            ends = [a * Bg + hi - 1 for _, hi in crun.chunk_bounds((b_ - a) * Bg, Bg)]
+            crun.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, merge="scatter", t_chunk_last=t[ends])
         elapsed = time_leg(run, K)
         crun.rp.check_device_errors()
     else:
@@ -226,8 +224,8 @@ def main():
 
     par = {"single": "single GPU",
            "cols": f"columns sharded over {world} GPUs ({d // world} of {d} per GPU), global batch {Bg} = {B} per GPU, no "
-                   f"per-step collective; raw Gram entries reduce-scattered (RCCL) per {CHUNK} steps behind the next "
-                   f"chunk's kernels",
+                   f"per-step collective; the 36 distinct raw Gram entries per pair are reduce-scattered (RCCL) per "
+                   f"chunk of ~2M edges behind the next chunk's kernels",
            "rows": f"rows sharded over {world} GPUs (owner = id % {world}), global batch {Bg} = {B} per GPU, one RCCL "
                    f"all-gather of touched rows per step"}[shard]
 

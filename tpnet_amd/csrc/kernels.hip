@@ -38,7 +38,7 @@ static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (v
 static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the pair/step kernels
 // workgroups of a step launch reserved for heavy (item, layer) units: measured optima on MI355X (C2: 36-42, the
 // one-pass grid leaves the rest to pairs and light items; B = 10 000: >= 128, the grid is multi-pass anyway)
-static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_LARGE = 128;
+static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_MEDIUM = 64, HEAVY_BLOCKS_LARGE = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
 // helpers
@@ -154,6 +154,7 @@ struct GramCfg {
     static constexpr int NT = NN * (NN + 1) / 2;   // distinct entries of the symmetric Gram (TPNET_FLAG_PACKED rows)
     static constexpr int MP = ((NG + LPP - 1) / LPP) * LPP;
     static constexpr int PER = MP / LPP;
+    static constexpr int STAGE = (LPP < 16) ? NG * (BLOCK / LPP) : 1;   // LDS floats of the staged store (narrow rows)
 };
 
 // FULL = the row is exactly one chunk (d == LPP*VPL*W): no tail predicate, no chunk loop; callers guarantee that an
@@ -166,10 +167,14 @@ __device__ __forceinline__ void ldv_maybe(const float* __restrict__ row, int vi,
 // ---------------------------------------------------------------------------------------------------------------
 // pairwise readout of ONE pair by one group of LPP lanes (models/TPNet.py:119-128)
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L, bool FULL>
+// PACKED (TPNET_FLAG_PACKED): only the NT distinct entries a <= b are written, raw, row-major upper triangle.
+// `stage`: LDS, GramCfg::STAGE floats per workgroup, used by the narrow geometries (LPP < 16) only: there a lane ends up
+// with 8 or 16 consecutive outputs, so a direct store touches one 64-byte line per lane and instruction; the values go
+// through LDS instead and leave as whole lines (measured at d=16, B=8000: the store phase of a readout wave 5.6 -> 0.7 us).
+template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED = false>
 __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
                                           double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
-                                          unsigned long long* dbg = nullptr, bool packed = false) {
+                                          unsigned long long* dbg = nullptr, float* __restrict__ stage = nullptr) {
     using C = GramCfg<LPP, L>;
     constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
     const int d = S.d;
@@ -244,24 +249,64 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
     Halve<C::MP, LPP / 2>::run(acc, gl);
     STAMP(4);
 
-    if (valid) {
+    if constexpr (LPP < 16) {
+        // finished values -> this group's LDS row (full or packed layout) -> whole-line stores
+        constexpr int NOUT = PACKED ? C::NT : C::NG;
+        float* sg = stage + (threadIdx.x / LPP) * C::NG;
 #pragma unroll
         for (int k = 0; k < C::PER; ++k) {
             const int idx = gl * C::PER + k;
             if (idx < C::NG) {
                 float x = acc[k];
-                if (do_scale) {
+                if (do_scale && !PACKED) {
                     x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (:127)
                     x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
                 }
                 if (!idok) x = __builtin_nanf("");
-                int o = idx;
-                if (packed) {                    // TPNET_FLAG_PACKED: only the entries a <= b, row-major upper triangle
+                if constexpr (PACKED) {
                     const int a = idx / NN, b = idx - a * NN;
-                    if (a > b) continue;
-                    o = a * NN - (a * (a - 1)) / 2 + (b - a);
+                    if (a <= b) sg[a * NN - (a * (a - 1)) / 2 + (b - a)] = x;
+                } else {
+                    sg[idx] = x;
                 }
-                __builtin_nontemporal_store(x, out + o);     // features are consumed by another kernel: stream them out
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // the group's lanes are in one wave: LDS executes in issue order
+        if constexpr (NOUT % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j * LPP < NOUT / 4; ++j) {
+                const int c = j * LPP + gl;
+                if (valid && c < NOUT / 4) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));   // rows are 16-byte aligned (checked by the launchers)
+                    const v4f q = reinterpret_cast<const v4f*>(sg)[c];
+                    __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(out) + c);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j * LPP < NOUT; ++j) {
+                const int c = j * LPP + gl;
+                if (valid && c < NOUT) __builtin_nontemporal_store(sg[c], out + c);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // the row is reused by the next pair of this group
+    } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < C::PER; ++k) {
+            const int idx = gl * C::PER + k;
+            if (idx < C::NG) {
+                float x = acc[k];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (:127)
+                    x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
+                }
+                if (!idok) x = __builtin_nanf("");
+                if constexpr (PACKED) {
+                    const int a = idx / NN, b = idx - a * NN;
+                    if (a <= b) __builtin_nontemporal_store(x, out + (a * NN - (a * (a - 1)) / 2 + (b - a)));
+                } else {
+                    __builtin_nontemporal_store(x, out + idx);   // features are consumed by another kernel: stream them out
+                }
             }
         }
     }
@@ -278,12 +323,17 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
     const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
     const int stride = packed ? GramCfg<LPP, L>::NT : NG;
+    __shared__ float stage[GramCfg<LPP, L>::STAGE];
     for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
         const int64_t p = base + g;
         const bool valid = p < n;
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
-        gram_pair<LPP, VPL, W, L, FULL>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * stride, gl,
-                                        nullptr, packed);
+        if (packed)
+            gram_pair<LPP, VPL, W, L, FULL, true>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * stride,
+                                                  gl, nullptr, stage);
+        else
+            gram_pair<LPP, VPL, W, L, FULL, false>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * stride,
+                                                   gl, nullptr, stage);
     }
 }
 
@@ -693,6 +743,120 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// light item on NARROW rows (LPP = 4 or 8 lanes per row: d <= 32, the column slices of a dim-sharded table).
+// One row of such a table is a single 64- or 128-byte vector load, so a light item is nothing but a chain of dependent
+// round trips -- and with LPP lanes per item only LPP contributions' (partner, weight, meta) could be fetched per
+// round.  Here an item owns IL = 16 lanes = IG sub-groups of LPP lanes instead: the 16 lanes fetch 16 contributions'
+// (partner, weight) and meta records at once, sub-group s accumulates contributions s, s+IG, s+2IG, ... and the IG
+// partial sums are added through DPP row rotations at the end.  The association of the sum differs from the index
+// order (like the heavy path's), so TPNET_FLAG_SEQUENTIAL launches use the 16-lane geometry instead (launch_step).
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float a) {
+    return a + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), CTRL, 0xF, 0xF, false));
+}
+
+template <int LPP, int L>
+__device__ __forceinline__ void update_item_narrow(const tpnet_state& S, const int32_t* __restrict__ s_partner,
+                                                   const float* __restrict__ s_coef, Item I, bool valid, uint32_t bid,
+                                                   double t_last, double lambda, int il /* lane of the item, 0..15 */) {
+    static_assert(LPP == 4 || LPP == 8, "narrow geometry");
+    constexpr int IL = 16, IG = IL / LPP;
+    constexpr int KS = 2;                           // steps (contributions per sub-group) whose rows are in flight at once
+    const int d = S.d;
+    const int nvec = d / 4;
+    const int gl = il % LPP, sub = il / LPP;
+    const bool vok = gl < nvec;                     // d < 4*LPP: the last lanes of a row have no vector
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    if (!valid) { I.target = 0; I.cnt = 0; I.p0 = 0; I.p1 = 0; I.j0 = 0; }
+    const int32_t u = I.target;
+    const uint32_t cnt = I.cnt;
+
+    const MetaView mu = read_meta(meta, u, bid, t_last, lambda);
+    const float* qold = S.q + ((int64_t)mu.copy * S.N + u) * ((int64_t)L * d);
+    float* qnew = S.q + ((int64_t)(mu.copy ^ 1) * S.N + u) * ((int64_t)L * d);
+
+    float acc[L][4];
+    // the target's pre-batch rows (sub-group 0 carries them; the others start from zero)
+#pragma unroll
+    for (int i = 0; i < L; ++i) ldv_pred<4>(qold + (int64_t)i * d, gl, valid && sub == 0 && vok, acc[i]);
+    {
+        float g = 1.0f;
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            g *= mu.g;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[i][x] *= g;
+        }
+    }
+
+    for (uint32_t r0 = 0; __any(r0 < cnt); r0 += IL) {
+        // (partner, weight) of contribution r0 + il, lane-parallel: the first two ride in the item record
+        const uint32_t c = r0 + (uint32_t)il;
+        const bool mine = c < cnt;
+        int32_t my_pv = 0;
+        float my_w = 0.0f;
+        if (c == 0) { my_pv = I.p0; my_w = I.w0; }
+        else if (c == 1) { my_pv = I.p1; my_w = I.w1; }
+        else if (mine) { my_pv = s_partner[I.j0 + c]; my_w = s_coef[I.j0 + c]; }
+        if (!mine) my_pv = 0;
+        const MetaView my_m = read_meta(meta, my_pv, bid, t_last, lambda);
+        const uint32_t n_here = (r0 < cnt) ? ((cnt - r0 < (uint32_t)IL) ? cnt - r0 : (uint32_t)IL) : 0u;
+        for (uint32_t k0 = 0; __any(k0 * IG < n_here); k0 += KS) {
+            float r[KS][L][4], w[KS], g[KS];
+            bool ok[KS];
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int sl = ((int)k0 + k) * IG + sub;           // contribution (of this round) of my sub-group
+                ok[k] = (uint32_t)sl < n_here;
+                const int32_t pv = __shfl(my_pv, sl, IL);
+                const int cp = __shfl(my_m.copy, sl, IL);
+                w[k] = __shfl(my_w, sl, IL);
+                g[k] = __shfl(my_m.g, sl, IL);
+                const float* r0p = S.p0 + (int64_t)pv * d;
+                const float* rq = S.q + ((int64_t)cp * S.N + pv) * ((int64_t)L * d);
+#pragma unroll
+                for (int i = 0; i < L; ++i)
+                    ldv_pred<4>((i == 0) ? r0p : rq + (int64_t)(i - 1) * d, gl, ok[k] && vok, r[k][i]);
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                if (ok[k]) {
+                    float gi = 1.0f;
+#pragma unroll
+                    for (int i = 0; i < L; ++i) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const float m = (r[k][i][x] * gi) * w[k];   // (P[i-1][partner], decayed) * time weight (:91-92)
+                            acc[i][x] = acc[i][x] + m;
+                        }
+                        gi *= g[k];
+                    }
+                }
+            }
+        }
+    }
+    // add the sub-groups' partial sums: rotations inside the 16-lane row leave the total in every lane
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            float v = dpp_add<0x128 /* row_ror:8 */>(acc[i][x]);
+            if constexpr (IG == 4) v = dpp_add<0x124 /* row_ror:4 */>(v);
+            acc[i][x] = v;
+        }
+    }
+    if (valid && sub == 0 && vok) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) stv<4>(qnew + (int64_t)i * d, gl, acc[i]);
+    }
+    if (valid && il == 0) {
+        meta[u].tref[mu.copy ^ 1] = t_last;
+        meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
+    }
+}
+
 // heavy item: a whole workgroup computes ONE LAYER of the target's new bundle.  The layers of the update are
 // independent sums (new[i][u] needs only layer i-1 of the partners), so a hub is spread over L workgroups -- L CUs'
 // worth of load bandwidth -- without any reduction across workgroups.  Inside the workgroup, group g sums the g-th
@@ -807,14 +971,15 @@ template <int LPP, int VPL, int W, int L, bool FULL>
 // The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
 // first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
 // -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
-__global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
+__global__ __launch_bounds__(BLOCK, (LPP < 16 && W == 4) ? 2 : 1) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
                                                 const int64_t* __restrict__ a_neg, int64_t e0, int32_t ne_,
                                                 uint32_t flags, uint32_t bid, int HEAVY_BLOCKS, double lambda,
                                                 tpnet_state S, StreamArgs a, Plan p, int64_t b) {
     constexpr int GPB = BLOCK / LPP;
     constexpr int GPW = 64 / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
-    __shared__ float part[VPL * W * BLOCK];
+    constexpr int STG = GramCfg<LPP, L>::STAGE;
+    __shared__ float part[(VPL * W * BLOCK > STG) ? VPL * W * BLOCK : STG];   // heavy items' partial sums / readout staging
     unsigned long long* dbg = p.dbg;
     (void)dbg;
     STAMP(0);
@@ -854,7 +1019,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_sr
     const int64_t npairs = npos + nneg;
     const int64_t RP = (npairs + GPW - 1) / GPW * GPW;
     const int64_t cap_items = (flags & ROLE_UPDATE) ? 2 * ne : 0;   // upper bound of the light items (slots exist)
-    const int64_t total = RP + cap_items;
+    // narrow rows: an item takes 16 lanes = ISL group slots of the work index space (update_item_narrow)
+    constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
+    const int64_t total = RP + cap_items * ISL;
     const Item* items = p.light + 2 * e0;
     const int64_t nblk = (int64_t)gridDim.x - HEAVY_BLOCKS;
 
@@ -881,17 +1048,23 @@ __global__ __launch_bounds__(BLOCK) void k_step(const int64_t* __restrict__ a_sr
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
             const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
             if (!__any(mine)) continue;
-            gram_pair<LPP, VPL, W, L, FULL>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, packed);
+            if (packed)
+                gram_pair<LPP, VPL, W, L, FULL, true>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part);
+            else
+                gram_pair<LPP, VPL, W, L, FULL, false>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part);
             STAMP(5);
         } else {
-            const int64_t it = w - RP;
+            const int64_t it = (w - RP) / ISL;
             Item I = items[it < cap_items ? it : 0];
             const int64_t n_light = (int64_t)Dp->n_light;
             const double t_last = Dp->t_last;
-            if (wave0 - RP >= n_light) break;   // wave-uniform: no item of this wave exists (and none later)
+            if ((wave0 - RP) / ISL >= n_light) break;   // wave-uniform: no item of this wave exists (and none later)
             const bool valid = it < n_light &&
                                (a.own_mod <= 1 || (I.target % a.own_mod) == a.own_rem);   // targets belong to their owner
-            update_item<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, gl);
+            if constexpr (ISL > 1)
+                update_item_narrow<LPP, L>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, (int)(threadIdx.x % 16));
+            else
+                update_item<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, gl);
             STAMP(6);
         }
     }
@@ -1240,6 +1413,7 @@ int launch_gram_finish(float* x, int64_t n, hipStream_t s) {
 int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                      uint32_t flags, float* out, hipStream_t s) {
     if (n == 0) return TPNET_OK;
+    if (reinterpret_cast<uintptr_t>(out) & 15) return TPNET_ERR_BAD_ARG;   // feature rows leave as 16-byte vectors
     TPNET_DISPATCH_G(pick_geom(st.d, n >= 16384), ({
         const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
         hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, u, v, n, now, lambda,
@@ -1275,19 +1449,25 @@ int launch_pair_gram_shared(const tpnet_state& st, const int64_t* u, const int64
 
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
-    TPNET_DISPATCH(({
+    // narrow rows (d <= 32): 4 / 8 lanes per row with 16-lane items, whose sums are not in index order -- a
+    // TPNET_FLAG_SEQUENTIAL launch keeps the 16-lane geometry
+    if ((reinterpret_cast<uintptr_t>(a.out_pos) | reinterpret_cast<uintptr_t>(a.out_neg)) & 15) return TPNET_ERR_BAD_ARG;
+    Geom geom = pick_geom(st.d);
+    if ((flags & TPNET_FLAG_SEQUENTIAL) && geom.w == 4 && geom.lpp < 16) geom = Geom{16, 1, 4};
+    TPNET_DISPATCH_G(geom, ({
         constexpr int GPB = BLOCK / LPP;
+        constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
         static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL>);
         static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
-        const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 2048 ? HEAVY_BLOCKS_SMALL : HEAVY_BLOCKS_LARGE);
+        const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : ne <= 2048 ? HEAVY_BLOCKS_MEDIUM : HEAVY_BLOCKS_LARGE);
         // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
         // chain of dependent memory round trips, so every workgroup should be resident at once (a workgroup that
         // starts after another one has finished doubles the chain) -- the item slots give way first (a batch
         // rarely has more than ne distinct light targets; the grid-stride loop covers the rest).
         const int pair_blocks = grid_for(2 * (int64_t)ne, GPB, 1 << 20);
-        int item_blocks = grid_for(2 * (int64_t)ne, GPB, 1 << 20);
+        int item_blocks = grid_for(2 * (int64_t)ne * ISL, GPB, 1 << 20);
         const int room = resident - HEAVY_BLOCKS - pair_blocks;
-        const int item_min = grid_for(((int64_t)ne * 3) / 4 + 1, GPB, 1 << 20);
+        const int item_min = grid_for((((int64_t)ne * 3) / 4 + 1) * ISL, GPB, 1 << 20);
         if (item_blocks > room) item_blocks = room > item_min ? room : item_min;
         int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
         if (grid > HEAVY_BLOCKS + 256 * 8) grid = HEAVY_BLOCKS + 256 * 8;

@@ -282,8 +282,30 @@ class ColumnShardedRunner:
         return self.rp._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
 
     # ---- device-resident stream -----------------------------------------------------------------------------------
-    def run_stream(self, src, dst, neg, t, batch_size: int, chunk_steps: int = 256, merge: str = "scatter",
-                   t_chunk_last=None):
+    @staticmethod
+    def chunk_bounds(E: int, B: int, chunk_steps=None, chunk_edges: int = 2_000_000, min_tail_steps: int = 64):
+        """Edge ranges [a, b) of the chunks: whole batches, about `chunk_edges` edges each (a plan of a few million
+        keys takes rocPRIM's one-sweep radix sort; much smaller ones fall to its merge sort, ~2x the time per key).  The
+        LAST chunk is halved repeatedly down to `min_tail_steps` steps: its collective has no later kernels to hide
+        behind, so it should be short.  `chunk_steps` fixes the size instead (no tail splitting)."""
+        if chunk_steps is not None:
+            ce = max(1, int(chunk_steps)) * B
+            return [(a, min(a + ce, E)) for a in range(0, E, ce)]
+        steps = max(1, int(chunk_edges) // B)
+        ce = steps * B
+        bounds = [(a, min(a + ce, E)) for a in range(0, E, ce)]
+        a, b = bounds.pop()
+        nb = (b - a + B - 1) // B
+        while nb >= 2 * min_tail_steps:
+            h = nb // 2
+            bounds.append((a, a + h * B))
+            a += h * B
+            nb -= h
+        bounds.append((a, b))
+        return bounds
+
+    def run_stream(self, src, dst, neg, t, batch_size: int, chunk_steps=None, merge: str = "scatter",
+                   t_chunk_last=None, chunk_edges: int = 2_000_000):
         """Same per-batch semantics as RandomProjectionModule.run_stream, over all ranks.
 
         merge = "scatter": returns (feat_pos, feat_neg, edge_index): this rank's share of the finished features,
@@ -291,16 +313,15 @@ class ColumnShardedRunner:
                            a chunk whose edge count is not a multiple of the world size).
         merge = "all":     returns (feat_pos, feat_neg, None) with all E rows on every rank (all-reduce).
         On the wire: the (2L+2)(2L+3)/2 distinct raw Gram entries per pair (144 B at L=3), f32.
-        `t_chunk_last`: t at the last edge of every chunk, if the caller has it on the host (else one small
-        device->host copy up front)."""
+        Chunks: see chunk_bounds.  `t_chunk_last`: t at the last edge of every chunk, if the caller has it on the
+        host (else one small device->host copy up front)."""
         rp, G, me = self.rp, self.G, self.me
         if merge not in ("scatter", "all"):
             raise ValueError("merge must be 'scatter' or 'all'")
         dev = rp._dev()
         E, B = int(src.numel()), int(batch_size)
         NG, NT = rp.pair_wise_feature_dim, rp.packed_feature_dim
-        ce = max(1, int(chunk_steps)) * B
-        bounds = [(a, min(a + ce, E)) for a in range(0, E, ce)]
+        bounds = self.chunk_bounds(E, B, chunk_steps, chunk_edges)
         have_neg = neg is not None
         if E == 0:
             z = torch.empty((0, NG), dtype=torch.float32, device=dev)
