@@ -38,6 +38,17 @@ static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (v
 static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the pair/step kernels
 // workgroups of a step launch reserved for heavy (item, layer) units: measured optima on MI355X (C2: 36-42, the
 // one-pass grid leaves the rest to pairs and light items; B = 10 000: >= 128, the grid is multi-pass anyway)
+// __launch_bounds__'s second argument in HIP-Clang = minimum waves per SIMD the kernel must fit (4 -> at most 128 VGPRs ->
+// two 512-thread workgroups per CU; 2 -> no constraint below 256 VGPRs).
+#ifndef TPNET_MINW16
+#define TPNET_MINW16 2
+#endif
+#ifndef TPNET_MINW32
+#define TPNET_MINW32 2
+#endif
+constexpr int min_waves_per_simd(int lpp, int vpl, int w) {
+    return (w != 4) ? 2 : (lpp < 16) ? 4 : (lpp == 16 && vpl == 1) ? TPNET_MINW16 : (lpp == 32 && vpl == 1) ? TPNET_MINW32 : 2;
+}
 static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_MEDIUM = 64, HEAVY_BLOCKS_LARGE = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -971,7 +982,7 @@ template <int LPP, int VPL, int W, int L, bool FULL>
 // The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
 // first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
 // -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
-__global__ __launch_bounds__(BLOCK, (LPP < 16 && W == 4) ? 2 : 1) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
+__global__ __launch_bounds__(BLOCK, min_waves_per_simd(LPP, VPL, W)) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
                                                 const int64_t* __restrict__ a_neg, int64_t e0, int32_t ne_,
                                                 uint32_t flags, uint32_t bid, int HEAVY_BLOCKS, double lambda,
                                                 tpnet_state S, StreamArgs a, Plan p, int64_t b) {
