@@ -77,13 +77,26 @@ __device__ __forceinline__ void ldv_pred(const float* __restrict__ row, int vi, 
 #pragma unroll
     for (int k = 0; k < W; ++k) dst[k] = ok ? dst[k] : 0.0f;
 }
-template <int W>
+// NT: stream the new row out instead of leaving it dirty in this XCD's L2.  The end of a kernel has to write the dirty
+// lines back anyway (the next launch's readers sit on all 8 XCDs), so for a mid-size batch doing it while the kernel
+// runs shortens the kernel boundary (C2: 7.06 -> 6.81 us per step, d=64 B=2000: -3 %; slower at C1 and C3, where it is
+// off).  Compile-time: LLVM sinks a nontemporal and a plain store of one value into ONE plain store.
+template <int W, bool NT = false>
 __device__ __forceinline__ void stv(float* __restrict__ row, int vi, const float* src) {
     if constexpr (W == 4) {
-        reinterpret_cast<float4*>(row)[vi] = make_float4(src[0], src[1], src[2], src[3]);
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f q = {src[0], src[1], src[2], src[3]};
+        if constexpr (NT) __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(row) + vi);
+        else reinterpret_cast<v4f*>(row)[vi] = q;
     } else {
         row[vi] = src[0];
     }
+}
+
+// the writer's last act: the new copy's reference time, then the version word that makes the copy current
+__device__ __forceinline__ void publish_meta(NodeMeta* m, int copy, double t_last, uint32_t bid) {
+    m->tref[copy] = t_last;
+    m->ver = (bid << 1) | (uint32_t)copy;
 }
 
 struct MetaView {
@@ -607,7 +620,7 @@ __device__ __forceinline__ void accumulate_range(const tpnet_state& S, const int
 //   -> { meta of target, partner 0, partner 1 }  and  { (partner, weight) of the remaining contributions, one per lane }
 //   -> { rows of target, partner 0, partner 1 }   and  { meta of the remaining partners, one per lane }
 //   -> rows of the remaining partners, U at a time
-template <int LPP, int VPL, int W, int L, bool FULL>
+template <int LPP, int VPL, int W, int L, bool FULL, bool NT>
 __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                             const float* __restrict__ s_coef, Item I, bool valid, uint32_t bid,
                                             double t_last, double lambda, int gl) {
@@ -744,13 +757,12 @@ __device__ __forceinline__ void update_item(const tpnet_state& S, const int32_t*
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                if (valid && (FULL || vi < nvec)) stv<W>(qnew + (int64_t)i * d, vi, &acc[i][j * W]);
+                if (valid && (FULL || vi < nvec)) stv<W, NT>(qnew + (int64_t)i * d, vi, &acc[i][j * W]);
             }
         }
     }
     if (valid && gl == 0) {
-        meta[u].tref[mu.copy ^ 1] = t_last;
-        meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
+        publish_meta(meta + u, mu.copy ^ 1, t_last, bid);
     }
 }
 
@@ -863,8 +875,7 @@ __device__ __forceinline__ void update_item_narrow(const tpnet_state& S, const i
         for (int i = 0; i < L; ++i) stv<4>(qnew + (int64_t)i * d, gl, acc[i]);
     }
     if (valid && il == 0) {
-        meta[u].tref[mu.copy ^ 1] = t_last;
-        meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
+        publish_meta(meta + u, mu.copy ^ 1, t_last, bid);
     }
 }
 
@@ -874,7 +885,7 @@ __device__ __forceinline__ void update_item_narrow(const tpnet_state& S, const i
 // slice of the contribution list; the slices' partial sums are added in slice order through LDS (fixed order:
 // reproducible run to run, but the association differs from the strictly sequential sum -- TPNET_FLAG_SEQUENTIAL
 // turns heavy items off).  `layer` = i-1 in 0..L-1; the layer-0 workgroup publishes the new version.
-template <int LPP, int VPL, int W, int L, bool FULL>
+template <int LPP, int VPL, int W, int L, bool FULL, bool NT>
 __device__ __forceinline__ void update_item_block(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                                   const float* __restrict__ s_coef, int32_t u, uint32_t j0,
                                                   uint32_t cnt, int layer, uint32_t bid, double t_last, double lambda,
@@ -962,14 +973,13 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const int vi = c0 + j * LPP + gl;
-                if (FULL || vi < nvec) stv<W>(qnew, vi, &tot[j * W]);
+                if (FULL || vi < nvec) stv<W, NT>(qnew, vi, &tot[j * W]);
             }
         }
         __syncthreads();
     }
     if (layer == 0 && threadIdx.x == 0) {
-        meta[u].tref[mu.copy ^ 1] = t_last;
-        meta[u].ver = (bid << 1) | (uint32_t)(mu.copy ^ 1);
+        publish_meta(meta + u, mu.copy ^ 1, t_last, bid);
     }
 }
 
@@ -978,7 +988,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
 // Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target and layer); the others walk a work index
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L, bool FULL>
+template <int LPP, int VPL, int W, int L, bool FULL, bool NT>
 // The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
 // first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
 // -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
@@ -1010,7 +1020,7 @@ __global__ __launch_bounds__(BLOCK, min_waves_per_simd(LPP, VPL, W)) void k_step
                 const double t_last = Dp->t_last;
                 if (h / L >= n_heavy) break;
                 if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
-                update_item_block<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, (int)(h % L),
+                update_item_block<LPP, VPL, W, L, FULL, NT>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, (int)(h % L),
                                                         bid, t_last, lambda, part);
                 STAMP(7);
             }
@@ -1075,7 +1085,7 @@ __global__ __launch_bounds__(BLOCK, min_waves_per_simd(LPP, VPL, W)) void k_step
             if constexpr (ISL > 1)
                 update_item_narrow<LPP, L>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, (int)(threadIdx.x % 16));
             else
-                update_item<LPP, VPL, W, L, FULL>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, gl);
+                update_item<LPP, VPL, W, L, FULL, NT>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, gl);
             STAMP(6);
         }
     }
@@ -1468,7 +1478,7 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
     TPNET_DISPATCH_G(geom, ({
         constexpr int GPB = BLOCK / LPP;
         constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
-        static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL>);
+        static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL, false>);
         static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
         const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : ne <= 2048 ? HEAVY_BLOCKS_MEDIUM : HEAVY_BLOCKS_LARGE);
         // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
@@ -1482,8 +1492,16 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
         if (item_blocks > room) item_blocks = room > item_min ? room : item_min;
         int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
         if (grid > HEAVY_BLOCKS + 256 * 8) grid = HEAVY_BLOCKS + 256 * 8;
-        hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, a.src, a.dst,
-                           a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
+        // streamed state stores for mid-size batches on the two geometries that serve them (see stv)
+        static const char* nt_env = getenv("TPNET_DEV_NT_STATE");          // developer override: "0" / "1"
+        constexpr bool NT_GEOM = W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
+        const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
+        if (nt_state)
+            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM>), dim3(grid), dim3(BLOCK), 0, s, a.src, a.dst,
+                               a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
+        else
+            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, false>), dim3(grid), dim3(BLOCK), 0, s, a.src, a.dst,
+                               a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
