@@ -359,7 +359,7 @@ def test_shared_first_node_readout(d, L):
     a = np.repeat(np.tile(src[s], 2), K); b_ = np.repeat(np.tile(dst[s], 2), K)
     g1, g2 = rp.pair_gram_shared(w, a, b_)
     r1, r2 = rp.pair_gram(w, a), rp.pair_gram(w, b_)
-    if d in (64, 128, 256, 512):                      # one chunk: the very same fma chains
+    if d in (64, 128):                                # one chunk of 4 floats per lane: the very same fma chains
         assert torch.equal(g1, r1) and torch.equal(g2, r2)
     else:
         np.testing.assert_allclose(g1.cpu().numpy(), r1.cpu().numpy(), rtol=1e-5, atol=1e-5)

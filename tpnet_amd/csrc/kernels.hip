@@ -170,6 +170,31 @@ struct Halve<C, 0> {
     static __device__ __forceinline__ void run(float*, int) {}
 };
 
+// <x, y> over the F floats a lane holds of two rows.  F >= 8: even and odd elements are summed separately so that each
+// step is ONE packed v_pk_fma_f32 on a register pair (half the issue slots of scalar FMAs: the readout of long pair
+// lists is VALU-bound); F = 4 would pay the two extra adds with the two saved FMAs, so it keeps the scalar chain.
+// (TPNET_NO_PKFMA: scalar everywhere, for A/B runs.)  PK = false for the shared-first-node kernel: its 62 slots plus
+// register pairs cost it a wave of occupancy (128 -> 166 VGPRs, 800 000 pairs at d=256: 351 -> 382 us, measured), so its
+// sums equal the generic kernel's bit for bit only where that one is scalar too (F = 4: d <= 128).
+template <int F, bool PK = true>
+__device__ __forceinline__ float dot_chunk(const float* x, const float* y) {
+#ifndef TPNET_NO_PKFMA
+    if constexpr (PK && F >= 8 && F % 2 == 0) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f s2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < F; k += 2) s2 = __builtin_elementwise_fma(v2f{x[k], x[k + 1]}, v2f{y[k], y[k + 1]}, s2);
+        return s2.x + s2.y;
+    } else
+#endif
+    {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < F; ++k) s = fmaf(x[k], y[k], s);
+        return s;
+    }
+}
+
 template <int LPP, int L>
 struct GramCfg {
     static constexpr int NR = L + 1;
@@ -255,12 +280,7 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
 #pragma unroll
         for (int a = 0; a < NN; ++a) {
 #pragma unroll
-            for (int b = a; b < NN; ++b) {
-                float s = acc[a * NN + b];
-#pragma unroll
-                for (int k = 0; k < F; ++k) s = fmaf(f[a][k], f[b][k], s);
-                acc[a * NN + b] = s;
-            }
+            for (int b = a; b < NN; ++b) acc[a * NN + b] = acc[a * NN + b] + dot_chunk<F>(f[a], f[b]);
         }
     }
 #pragma unroll
@@ -446,28 +466,14 @@ __device__ __forceinline__ void gram_shared(const tpnet_state& S, int64_t u, int
         for (int a = 0; a < NR; ++a) {
 #pragma unroll
             for (int b = a; b < NR; ++b) {
-                float s0 = acc[SC::O_UU + SC::tri(a, b)], s1 = acc[SC::O_V1 + SC::tri(a, b)],
-                      s2 = acc[SC::O_V2 + SC::tri(a, b)];
-#pragma unroll
-                for (int k = 0; k < F; ++k) {
-                    s0 = fmaf(f[0][a][k], f[0][b][k], s0);
-                    s1 = fmaf(f[1][a][k], f[1][b][k], s1);
-                    s2 = fmaf(f[2][a][k], f[2][b][k], s2);
-                }
-                acc[SC::O_UU + SC::tri(a, b)] = s0;
-                acc[SC::O_V1 + SC::tri(a, b)] = s1;
-                acc[SC::O_V2 + SC::tri(a, b)] = s2;
+                acc[SC::O_UU + SC::tri(a, b)] = acc[SC::O_UU + SC::tri(a, b)] + dot_chunk<F, false>(f[0][a], f[0][b]);
+                acc[SC::O_V1 + SC::tri(a, b)] = acc[SC::O_V1 + SC::tri(a, b)] + dot_chunk<F, false>(f[1][a], f[1][b]);
+                acc[SC::O_V2 + SC::tri(a, b)] = acc[SC::O_V2 + SC::tri(a, b)] + dot_chunk<F, false>(f[2][a], f[2][b]);
             }
 #pragma unroll
             for (int b = 0; b < NR; ++b) {
-                float s1 = acc[SC::O_UV1 + a * NR + b], s2 = acc[SC::O_UV2 + a * NR + b];
-#pragma unroll
-                for (int k = 0; k < F; ++k) {
-                    s1 = fmaf(f[0][a][k], f[1][b][k], s1);
-                    s2 = fmaf(f[0][a][k], f[2][b][k], s2);
-                }
-                acc[SC::O_UV1 + a * NR + b] = s1;
-                acc[SC::O_UV2 + a * NR + b] = s2;
+                acc[SC::O_UV1 + a * NR + b] = acc[SC::O_UV1 + a * NR + b] + dot_chunk<F, false>(f[0][a], f[1][b]);
+                acc[SC::O_UV2 + a * NR + b] = acc[SC::O_UV2 + a * NR + b] + dot_chunk<F, false>(f[0][a], f[2][b]);
             }
         }
     }
