@@ -1060,15 +1060,19 @@ __global__ __launch_bounds__(BLOCK, min_waves_per_simd(LPP, VPL, W)) void k_step
             int64_t e = 0, u = 0, v = 0;
             float* out = nullptr;
             if (valid) {
-                if (w < npos) {
-                    e = e0 + w;
-                    v = a_dst[e];
-                    out = a.out_pos + e * ostride;
-                } else {
-                    e = e0 + (w - npos);
-                    v = a_neg[e];
-                    out = a.out_neg + e * ostride;
-                }
+                // (src,dst) and (src,neg) of one edge sit in ADJACENT lane groups (work index 2e, 2e+1): the two groups
+                // load the src node's meta record and rows with the same instructions and the same addresses, which the
+                // load unit coalesces -- one fetch from the memory side instead of two in different workgroups/XCDs
+#ifndef TPNET_NO_INTERLEAVE
+                const bool both = npos != 0 && nneg != 0;
+#else
+                const bool both = false;
+#endif
+                const int64_t idx = both ? (w >> 1) : (w < npos ? w : w - npos);
+                const bool isneg = both ? (w & 1) != 0 : (w >= npos);
+                e = e0 + idx;
+                v = isneg ? a_neg[e] : a_dst[e];
+                out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
                 u = a_src[e];
             }
             const double now = Dp->now;
