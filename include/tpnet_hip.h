@@ -105,6 +105,12 @@ int tpnet_decay(const tpnet_state* st, const float* factors, double t_new, void*
 int tpnet_gather_rows(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda,
                       float* out, void* stream);
 
+/* Single elements of every layer: out[k][i] = P[i][rows[k]][cols[k]] at now_time, i = 0..L (out: device float[n][L+1]).
+ * With a square table (d = N) this is the readout of the reference's sibling walk-matrix state, PINT's
+ * MatrixMemory.get_memory before its normalisation (models/MemoryModel.py:396-405: `matrix[src, dst]`). */
+int tpnet_gather_elems(const tpnet_state* st, const int64_t* rows, const int64_t* cols, int64_t n, double now_time,
+                       double lambda, float* out, void* stream);
+
 /* get_pair_wise_feature up to (not including) self.mlp (models/TPNet.py:112-128):
  * out[p][(2L+2)*a + b] = <R_a, R_b>, R = [P0[u_p]..PL[u_p], P0[v_p]..PL[v_p]] at now_time; then, unless
  * TPNET_FLAG_NOT_SCALE, x<0 -> 0 and log(x+1).  u, v: device int64[n]; out: device float[n][(2L+2)^2]. */

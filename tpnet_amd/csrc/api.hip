@@ -170,6 +170,14 @@ int tpnet_gather_rows(const tpnet_state* st, const int64_t* ids, int64_t n, doub
     return launch_gather_rows(*st, ids, n, now_time, lambda, out, (hipStream_t)stream);
 }
 
+int tpnet_gather_elems(const tpnet_state* st, const int64_t* rows, const int64_t* cols, int64_t n, double now_time,
+                       double lambda, float* out, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!rows || !cols || !out))) return TPNET_ERR_BAD_ARG;
+    return launch_gather_elems(*st, rows, cols, n, now_time, lambda, out, (hipStream_t)stream);
+}
+
 int tpnet_pair_gram(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
                     double lambda, uint32_t flags, float* out, void* stream) {
     int rc = check_state(st);

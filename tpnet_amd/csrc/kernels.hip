@@ -1231,6 +1231,39 @@ __global__ void k_gather_rows(tpnet_state S, const int64_t* __restrict__ ids, in
     }
 }
 
+// single elements of the layers: out[k][i] = P[i][rows[k]][cols[k]] at `now`, i = 0..L (the walk-matrix readout of
+// models/MemoryModel.py:396-405, `matrix[src, dst]`, when the table is square: tpnet_amd/matrix_memory.py)
+__global__ void k_gather_elems(tpnet_state S, const int64_t* __restrict__ rows, const int64_t* __restrict__ cols,
+                               int64_t n, double now, double lambda, float* __restrict__ out) {
+    const int64_t d = S.d, L = S.L;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        int64_t r = rows[k], c = cols[k];
+        const bool ok = (uint64_t)r < (uint64_t)S.N && (uint64_t)c < (uint64_t)d;
+        if (!ok) {
+            atomicAdd(S.err, 1u);
+            r = 0; c = 0;
+        }
+        const MetaView m = read_meta(meta, r, READER_BID, now, lambda);
+        const float* qb = S.q + ((int64_t)m.copy * S.N + r) * (L * d);
+        float g = 1.0f;
+        out[k * (L + 1)] = ok ? S.p0[r * d + c] : __builtin_nanf("");
+        for (int64_t i = 1; i <= L; ++i) {
+            g *= m.g;
+            out[k * (L + 1) + i] = ok ? qb[(i - 1) * d + c] * g : __builtin_nanf("");
+        }
+    }
+}
+
+int launch_gather_elems(const tpnet_state& st, const int64_t* rows, const int64_t* cols, int64_t n, double now,
+                        double lambda, float* out, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_gather_elems, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, st, rows, cols, n, now, lambda, out);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 // row exchange of the sharded state: out[k][i][:] = P[i+1][ids[k]] at `now` (decay applied), i = 0..L-1
 __global__ void k_pack_rows(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now, double lambda,
                             float* __restrict__ out) {

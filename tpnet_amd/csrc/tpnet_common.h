@@ -110,6 +110,8 @@ int launch_state_init(const tpnet_state& st, double t0, hipStream_t s);
 int launch_import(const tpnet_state& st, const float* const* layers_dev, double now, hipStream_t s);
 int launch_export(const tpnet_state& st, float* const* layers_dev, double now, double lambda, hipStream_t s);
 int launch_decay(const tpnet_state& st, const float* factors_host, double t_new, hipStream_t s);
+int launch_gather_elems(const tpnet_state& st, const int64_t* rows, const int64_t* cols, int64_t n, double now,
+                        double lambda, float* out, hipStream_t s);
 int launch_gram_finish(float* x, int64_t n, hipStream_t s);
 int launch_gram_unpack(const float* packed, int64_t n, int L, uint32_t flags, float* out, hipStream_t s);
 int launch_gather_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
