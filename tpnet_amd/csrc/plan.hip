@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace tpnet {
 
@@ -20,13 +23,40 @@ static inline int ceil_log2_u64(uint64_t x) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static size_t sort_tmp_bytes(size_t n) {
-    size_t bytes = 0;
+// A batch's 2*B keys are contiguous (k_make_keys), so grouping by target is a SEGMENTED sort on the node bits alone, one
+// segment per batch: rocPRIM sorts a segment of a few thousand keys inside one workgroup's LDS, all batches in one
+// launch, instead of several device-wide passes over (batch, node) keys.  Very long segments (one workgroup would walk
+// them alone) keep the device-wide sort.
+static constexpr int64_t SEGSORT_MAX_KEYS = 32768;
+struct SegOffset {   // offset of segment boundary (i + shift): begin iterator = shift 0, end iterator = shift 1
+    unsigned per, total, shift;
+    __host__ __device__ unsigned operator()(unsigned i) const {
+        const unsigned long long e = (unsigned long long)(i + shift) * per;
+        return e < total ? (unsigned)e : total;
+    }
+};
+static bool use_segmented_sort(int64_t batch, size_t nc) {
+    static const char* env = getenv("TPNET_DEV_SEGSORT");       // developer override: "0" / "1"
+    if (nc >= (1ull << 32)) return false;
+    if (env) return env[0] == '1';
+    return 2 * batch <= SEGSORT_MAX_KEYS;
+}
+
+static size_t sort_tmp_bytes(size_t n, int64_t batch) {
+    size_t bytes = 0, bytes_seg = 0;
     uint64_t* kn = nullptr;
     uint32_t* vn = nullptr;
-    // size query only: no kernel is launched
+    // size queries only: no kernel is launched
     (void)rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, n, 0, 64, (hipStream_t)0, false);
-    return bytes;
+    if (n < (1ull << 32)) {
+        const unsigned nseg = (unsigned)((n + 2 * (size_t)batch - 1) / (2 * (size_t)batch));
+        auto cnt = rocprim::counting_iterator<unsigned>(0);
+        auto b = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)n, 0u});
+        auto e = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)n, 1u});
+        (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes_seg, kn, kn, vn, vn, (unsigned)n, nseg, b, e, 0u, 64u,
+                                                  (hipStream_t)0, false);
+    }
+    return bytes > bytes_seg ? bytes : bytes_seg;
 }
 
 size_t plan_bytes(int64_t max_edges, int64_t batch) {
@@ -41,7 +71,7 @@ size_t plan_bytes(int64_t max_edges, int64_t batch) {
     tot += align_up(nc * sizeof(float), 256);          // s_coef
     tot += align_up(nc * sizeof(Item), 256) * 2;       // light, heavy
     tot += align_up(nb * sizeof(BatchDesc), 256);
-    tot += align_up(sort_tmp_bytes(nc), 256) + 256;
+    tot += align_up(sort_tmp_bytes(nc, batch), 256) + 256;
     return tot;
 }
 
@@ -68,7 +98,7 @@ int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out) 
     out->light = (Item*)take(nc * sizeof(Item));
     out->heavy = (Item*)take(nc * sizeof(Item));
     out->desc = (BatchDesc*)take(nb * sizeof(BatchDesc));
-    out->sort_tmp_bytes = sort_tmp_bytes(nc);
+    out->sort_tmp_bytes = sort_tmp_bytes(nc, batch);
     out->sort_tmp = take(out->sort_tmp_bytes);
     if (p > end) return TPNET_ERR_WORKSPACE;
     return TPNET_OK;
@@ -238,8 +268,17 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
                        node_bits, st.err);
     TPNET_HIP_TRY(hipGetLastError());
     size_t tmp = p.sort_tmp_bytes;
-    TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
-                                            (size_t)nc, 0u, (unsigned)(node_bits + batch_bits), s, false));
+    if (use_segmented_sort(batch, (size_t)nc)) {
+        const unsigned nseg = (unsigned)((nc + 2 * batch - 1) / (2 * batch));
+        auto cnt = rocprim::counting_iterator<unsigned>(0);
+        auto sb = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)nc, 0u});
+        auto se = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)nc, 1u});
+        TPNET_HIP_TRY(rocprim::segmented_radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
+                                                          (unsigned)nc, nseg, sb, se, 0u, (unsigned)node_bits, s, false));
+    } else {
+        TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
+                                                (size_t)nc, 0u, (unsigned)(node_bits + batch_bits), s, false));
+    }
     // heavy threshold: a target with more contributions than this gets L workgroups (one per layer).  Small batches are
     // bound by the longest dependent chain, so the bar is low (8); big batches are bound by throughput and by the serial
     // loop of the reserved heavy workgroups, so only real hubs qualify (measured optimum ~B/300 on Reddit- and
