@@ -1,0 +1,296 @@
+// Pairwise readout (models/TPNet.py:112-128 before self.mlp) as device functions: one pair per group of LPP lanes
+// (gram_pair) and two pairs that share their first node (gram_shared).  Used by readout.hip and by the fused step.
+#pragma once
+#include "device_common.hpp"
+
+namespace tpnet {
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairwise readout of ONE pair by one group of LPP lanes (models/TPNet.py:119-128)
+// ---------------------------------------------------------------------------------------------------------------
+// PACKED (TPNET_FLAG_PACKED): only the NT distinct entries a <= b are written, raw, row-major upper triangle.
+// `stage`: LDS, GramCfg::STAGE floats per workgroup, used by the narrow geometries (LPP < 16) only: there a lane ends up
+// with 8 or 16 consecutive outputs, so a direct store touches one 64-byte line per lane and instruction; the values go
+// through LDS instead and leave as whole lines (measured at d=16, B=8000: the store phase of a readout wave 5.6 -> 0.7 us).
+template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED = false>
+__device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
+                                          double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
+                                          unsigned long long* dbg = nullptr, float* __restrict__ stage = nullptr) {
+    using C = GramCfg<LPP, L>;
+    constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
+    const int d = S.d;
+    const int nvec = d / W;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+
+    bool idok = valid && (uint64_t)u < (uint64_t)S.N && (uint64_t)v < (uint64_t)S.N;
+    if (valid && !idok && gl == 0) atomicAdd(S.err, 1u);
+    if (!idok) { u = 0; v = 0; }
+
+    STAMP(1);
+    const float* rowp[NN];
+    float rs[NN];
+    {
+        const int64_t ids[2] = {u, v};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const MetaView m = read_meta(meta, ids[s], bid, now, lambda);
+            rowp[s * NR] = S.p0 + ids[s] * (int64_t)d;
+            rs[s * NR] = 1.0f;
+            const float* qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
+            float g = 1.0f;
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+                g *= m.g;
+                rowp[s * NR + i] = qb + (int64_t)(i - 1) * d;
+                rs[s * NR + i] = g;
+            }
+        }
+    }
+
+    float acc[C::MP];
+#pragma unroll
+    for (int i = 0; i < C::MP; ++i) acc[i] = 0.0f;
+    STAMP(2);
+
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
+        float f[NN][F];
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int vi = c0 + j * LPP + gl;
+                ldv_maybe<W, FULL>(rowp[a], vi, vi < nvec, &f[a][j * W]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+            if (a % NR != 0) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) f[a][k] *= rs[a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+#pragma unroll
+            for (int b = a; b < NN; ++b) acc[a * NN + b] = acc[a * NN + b] + dot_chunk<F>(f[a], f[b]);
+        }
+    }
+#pragma unroll
+    for (int a = 1; a < NN; ++a) {
+#pragma unroll
+        for (int b = 0; b < a; ++b) acc[a * NN + b] = acc[b * NN + a];
+    }
+
+    STAMP(3);
+    Halve<C::MP, LPP / 2>::run(acc, gl);
+    STAMP(4);
+
+    if constexpr (LPP < 16) {
+        // finished values -> this group's LDS row (full or packed layout) -> whole-line stores
+        constexpr int NOUT = PACKED ? C::NT : C::NG;
+        float* sg = stage + (threadIdx.x / LPP) * C::NG;
+#pragma unroll
+        for (int k = 0; k < C::PER; ++k) {
+            const int idx = gl * C::PER + k;
+            if (idx < C::NG) {
+                float x = acc[k];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (:127)
+                    x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
+                }
+                if (!idok) x = __builtin_nanf("");
+                if constexpr (PACKED) {
+                    const int a = idx / NN, b = idx - a * NN;
+                    if (a <= b) sg[a * NN - (a * (a - 1)) / 2 + (b - a)] = x;
+                } else {
+                    sg[idx] = x;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // the group's lanes are in one wave: LDS executes in issue order
+        if constexpr (NOUT % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j * LPP < NOUT / 4; ++j) {
+                const int c = j * LPP + gl;
+                if (valid && c < NOUT / 4) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));   // rows are 16-byte aligned (checked by the launchers)
+                    const v4f q = reinterpret_cast<const v4f*>(sg)[c];
+                    __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(out) + c);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j * LPP < NOUT; ++j) {
+                const int c = j * LPP + gl;
+                if (valid && c < NOUT) __builtin_nontemporal_store(sg[c], out + c);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // the row is reused by the next pair of this group
+    } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < C::PER; ++k) {
+            const int idx = gl * C::PER + k;
+            if (idx < C::NG) {
+                float x = acc[k];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (:127)
+                    x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
+                }
+                if (!idok) x = __builtin_nanf("");
+                if constexpr (PACKED) {
+                    const int a = idx / NN, b = idx - a * NN;
+                    if (a <= b) __builtin_nontemporal_store(x, out + (a * NN - (a * (a - 1)) / 2 + (b - a)));
+                } else {
+                    __builtin_nontemporal_store(x, out + idx);   // features are consumed by another kernel: stream them out
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairwise readout of TWO pairs that share their first node: out1 = G(u, v1), out2 = G(u, v2).  u's rows are loaded
+// once.  This is the shape of both callers of the readout: the decoder's (src,dst) / (src,neg) pairs
+// (models/modules.py:112, train_link_prediction.py:359-368) and the encoder's relative encodings, where every
+// neighbour w is paired with the edge's src AND dst (models/TPNet.py:311-316: first half of the pair list =
+// G(w, src), second half = G(w, dst)).
+// ---------------------------------------------------------------------------------------------------------------
+// Only the distinct inner products are formed and reduced, in ONE recursive-halving pass for both outputs:
+//   slots = [ u.u (tri) | u.v1 (R*R) | u.v2 (R*R) | v1.v1 (tri) | v2.v2 (tri) ],  R = L+1, tri = R(R+1)/2
+// = 62 slots at L = 3 (one 64-value reduction instead of two, 62 dot products instead of 72, 12 row loads instead of
+// 16); afterwards every lane picks the (at most two per output) slots its output elements mirror from by shuffles.
+template <int LPP, int L>
+struct SharedCfg {
+    static constexpr int R = L + 1;
+    static constexpr int TRI = R * (R + 1) / 2;
+    static constexpr int O_UU = 0, O_UV1 = TRI, O_UV2 = TRI + R * R, O_V1 = TRI + 2 * R * R, O_V2 = 2 * TRI + 2 * R * R;
+    static constexpr int NS = 3 * TRI + 2 * R * R;
+    static constexpr int MPS = ((NS + LPP - 1) / LPP) * LPP;
+    static constexpr int PERS = MPS / LPP;
+    static constexpr __host__ __device__ int tri(int i, int j) { return i * R - i * (i - 1) / 2 + (j - i); }   // i <= j
+};
+
+template <int LPP, int VPL, int W, int L, bool FULL>
+__device__ __forceinline__ void gram_shared(const tpnet_state& S, int64_t u, int64_t v1, int64_t v2, bool valid,
+                                            uint32_t bid, double now, double lambda, bool do_scale,
+                                            float* __restrict__ out1, float* __restrict__ out2, int gl) {
+    using C = GramCfg<LPP, L>;
+    using SC = SharedCfg<LPP, L>;
+    constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
+    const int d = S.d;
+    const int nvec = d / W;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+
+    bool idok = valid && (uint64_t)u < (uint64_t)S.N && (uint64_t)v1 < (uint64_t)S.N && (uint64_t)v2 < (uint64_t)S.N;
+    if (valid && !idok && gl == 0) atomicAdd(S.err, 1u);
+    if (!idok) { u = 0; v1 = 0; v2 = 0; }
+
+    const float* rowp[3][NR];
+    float rs[3][NR];
+    {
+        const int64_t ids[3] = {u, v1, v2};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const MetaView m = read_meta(meta, ids[s], bid, now, lambda);
+            rowp[s][0] = S.p0 + ids[s] * (int64_t)d;
+            rs[s][0] = 1.0f;
+            const float* qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
+            float g = 1.0f;
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+                g *= m.g;
+                rowp[s][i] = qb + (int64_t)(i - 1) * d;
+                rs[s][i] = g;
+            }
+        }
+    }
+    float acc[SC::MPS];
+#pragma unroll
+    for (int i = 0; i < SC::MPS; ++i) acc[i] = 0.0f;
+
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
+        float f[3][NR][F];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const int vi = c0 + j * LPP + gl;
+                    ldv_maybe<W, FULL>(rowp[s][a], vi, vi < nvec, &f[s][a][j * W]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int a = 1; a < NR; ++a) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) f[s][a][k] *= rs[s][a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+#pragma unroll
+            for (int b = a; b < NR; ++b) {
+                acc[SC::O_UU + SC::tri(a, b)] = acc[SC::O_UU + SC::tri(a, b)] + dot_chunk<F, false>(f[0][a], f[0][b]);
+                acc[SC::O_V1 + SC::tri(a, b)] = acc[SC::O_V1 + SC::tri(a, b)] + dot_chunk<F, false>(f[1][a], f[1][b]);
+                acc[SC::O_V2 + SC::tri(a, b)] = acc[SC::O_V2 + SC::tri(a, b)] + dot_chunk<F, false>(f[2][a], f[2][b]);
+            }
+#pragma unroll
+            for (int b = 0; b < NR; ++b) {
+                acc[SC::O_UV1 + a * NR + b] = acc[SC::O_UV1 + a * NR + b] + dot_chunk<F, false>(f[0][a], f[1][b]);
+                acc[SC::O_UV2 + a * NR + b] = acc[SC::O_UV2 + a * NR + b] + dot_chunk<F, false>(f[0][a], f[2][b]);
+            }
+        }
+    }
+    Halve<SC::MPS, LPP / 2>::run(acc, gl);        // lane gl now holds the complete sums of slots [gl*PERS, ...)
+
+    // output element idx = a*NN + b of the two Gram matrices -> the slot it comes from
+#pragma unroll
+    for (int k = 0; k < C::PER; ++k) {
+        int idx = gl * C::PER + k;
+        const bool in = idx < C::NG;
+        idx = in ? idx : 0;
+        const int a = idx / NN, b = idx - a * NN;
+        int s1, s2;
+        if (a < NR && b < NR) {
+            const int i = a < b ? a : b, j = a < b ? b : a;
+            s1 = s2 = SC::O_UU + SC::tri(i, j);
+        } else if (a < NR) {                       // (u row a, v row b-NR)
+            s1 = SC::O_UV1 + a * NR + (b - NR);
+            s2 = SC::O_UV2 + a * NR + (b - NR);
+        } else if (b < NR) {                       // mirrored
+            s1 = SC::O_UV1 + b * NR + (a - NR);
+            s2 = SC::O_UV2 + b * NR + (a - NR);
+        } else {
+            const int x = a - NR, y = b - NR;
+            const int i = x < y ? x : y, j = x < y ? y : x;
+            s1 = SC::O_V1 + SC::tri(i, j);
+            s2 = SC::O_V2 + SC::tri(i, j);
+        }
+        float x1 = 0.0f, x2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SC::PERS; ++j) {
+            const float t1 = __shfl(acc[j], s1 / SC::PERS, LPP);
+            const float t2 = __shfl(acc[j], s2 / SC::PERS, LPP);
+            x1 = (s1 % SC::PERS == j) ? t1 : x1;
+            x2 = (s2 % SC::PERS == j) ? t2 : x2;
+        }
+        if (do_scale) {
+            x1 = (x1 < 0.0f) ? 0.0f : x1;          // NaN < 0 is false: NaN passes through (:127)
+            x2 = (x2 < 0.0f) ? 0.0f : x2;
+            x1 = logf(x1 + 1.0f);                  // log(x + 1), not log1p (:128)
+            x2 = logf(x2 + 1.0f);
+        }
+        if (!idok) { x1 = __builtin_nanf(""); x2 = x1; }
+        if (valid && in) {
+            out1[idx] = x1;
+            out2[idx] = x2;
+        }
+    }
+}
+
+
+}  // namespace tpnet

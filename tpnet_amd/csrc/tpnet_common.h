@@ -105,7 +105,7 @@ inline Geom pick_geom(int d, bool many = false) {
     return {64, 2, 4};                                        // d = 512 (and chunks of 512 beyond): C5 is 1.6x faster so
 }
 
-// host-side launchers implemented in kernels.hip / plan.hip
+// host-side launchers implemented in step.hip / readout.hip / tables.hip / plan.hip
 int launch_state_init(const tpnet_state& st, double t0, hipStream_t s);
 int launch_import(const tpnet_state& st, const float* const* layers_dev, double now, hipStream_t s);
 int launch_export(const tpnet_state& st, float* const* layers_dev, double now, double lambda, hipStream_t s);
