@@ -19,7 +19,7 @@ namespace tpnet {
 #define STAMP(slot)                                                                                        \
     do {                                                                                                   \
         if (dbg && (threadIdx.x & 63) == 0) {                                                              \
-            const size_t wv = ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));                    \
+            const size_t wv = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));                    \
             if (wv < 4000) {                                                                               \
                 dbg[(wv * 8 + (slot)) * 2 + 0] = __builtin_amdgcn_s_memtime();                             \
                 dbg[(wv * 8 + (slot)) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                         \
@@ -34,7 +34,13 @@ static constexpr uint32_t READER_BID = 0xFFFFFFFFu;  // never equals a stored (v
 #ifndef TPNET_BLOCK
 #define TPNET_BLOCK 512
 #endif
-static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the pair/step kernels
+static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the step kernel for one-pass (small) batches
+// Workgroups of 256 threads for everything that is many passes deep (large batches, long pair lists): with 146-175 VGPRs a
+// CU holds 8-12 waves, i.e. ONE 512-thread workgroup, whose slots only free up when its slowest wave is done (measured mean
+// occupancy at C3: 4.2 of 8 waves per CU); two 256-thread workgroups refill independently (C3 49 -> 37 us per batch,
+// C5 -6 %, C1 -9 %).  A batch that fits one pass of 512-thread workgroups (500..2500 edges) keeps them: fewer workgroups
+// to dispatch, 6 % faster at C2.
+static constexpr int BLOCK_SMALL = 256;
 // workgroups of a step launch reserved for heavy (item, layer) units: measured optima on MI355X (C2: 36-42, the
 // one-pass grid leaves the rest to pairs and light items; B = 10 000: >= 128, the grid is multi-pass anyway)
 // __launch_bounds__'s second argument in HIP-Clang = minimum waves per SIMD the kernel must fit (4 -> at most 128 VGPRs ->
@@ -202,7 +208,9 @@ struct GramCfg {
     static constexpr int NT = NN * (NN + 1) / 2;   // distinct entries of the symmetric Gram (TPNET_FLAG_PACKED rows)
     static constexpr int MP = ((NG + LPP - 1) / LPP) * LPP;
     static constexpr int PER = MP / LPP;
-    static constexpr int STAGE = (LPP < 16) ? NG * (BLOCK / LPP) : 1;   // LDS floats of the staged store (narrow rows)
+    // LDS floats of the staged store (narrow rows) for a workgroup of BS threads
+    template <int BS>
+    static constexpr int stage_floats() { return (LPP < 16) ? NG * (BS / LPP) : 1; }
 };
 
 // FULL = the row is exactly one chunk (d == LPP*VPL*W): no tail predicate, no chunk loop; callers guarantee that an

@@ -4,18 +4,20 @@
 
 namespace tpnet {
 
+static constexpr int RB = BLOCK_SMALL;   // threads per workgroup of the standalone readout kernels
+
 template <int LPP, int VPL, int W, int L, bool FULL>
-__global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_t* __restrict__ u,
+__global__ __launch_bounds__(RB) void k_pair_gram(tpnet_state S, const int64_t* __restrict__ u,
                                                      const int64_t* __restrict__ v, int64_t n, double now,
                                                      double lambda, uint32_t flags, float* __restrict__ out) {
-    constexpr int GPB = BLOCK / LPP;
+    constexpr int GPB = RB / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
     const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
     const int stride = packed ? GramCfg<LPP, L>::NT : NG;
-    __shared__ float stage[GramCfg<LPP, L>::STAGE];
+    __shared__ float stage[GramCfg<LPP, L>::template stage_floats<RB>()];
     for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
         const int64_t p = base + g;
         const bool valid = p < n;
@@ -31,12 +33,12 @@ __global__ __launch_bounds__(BLOCK) void k_pair_gram(tpnet_state S, const int64_
 
 
 template <int LPP, int VPL, int W, int L, bool FULL>
-__global__ __launch_bounds__(BLOCK) void k_pair_gram_shared(tpnet_state S, const int64_t* __restrict__ u,
+__global__ __launch_bounds__(RB) void k_pair_gram_shared(tpnet_state S, const int64_t* __restrict__ u,
                                                             const int64_t* __restrict__ v1,
                                                             const int64_t* __restrict__ v2, int64_t n, double now,
                                                             double lambda, uint32_t flags, float* __restrict__ out1,
                                                             float* __restrict__ out2) {
-    constexpr int GPB = BLOCK / LPP;
+    constexpr int GPB = RB / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
@@ -56,8 +58,8 @@ int launch_pair_gram(const tpnet_state& st, const int64_t* u, const int64_t* v, 
     if (n == 0) return TPNET_OK;
     if (reinterpret_cast<uintptr_t>(out) & 15) return TPNET_ERR_BAD_ARG;   // feature rows leave as 16-byte vectors
     TPNET_DISPATCH_G(pick_geom(st.d, n >= 16384), ({
-        const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
-        hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, u, v, n, now, lambda,
+        const int grid = grid_for(n, RB / LPP, 256 * 16);
+        hipLaunchKernelGGL((k_pair_gram<LPP, VPL, W, L, FULL>), dim3(grid), dim3(RB), 0, s, st, u, v, n, now, lambda,
                            flags, out);
     }));
     TPNET_HIP_TRY(hipGetLastError());
@@ -70,8 +72,8 @@ int launch_pair_gram_shared(const tpnet_state& st, const int64_t* u, const int64
                             double now, double lambda, uint32_t flags, float* out1, float* out2, hipStream_t s) {
     if (n == 0) return TPNET_OK;
     TPNET_DISPATCH(({
-        const int grid = grid_for(n, BLOCK / LPP, 256 * 16);
-        hipLaunchKernelGGL((k_pair_gram_shared<LPP, VPL, W, L, FULL>), dim3(grid), dim3(BLOCK), 0, s, st, u, v1, v2, n,
+        const int grid = grid_for(n, RB / LPP, 256 * 16);
+        hipLaunchKernelGGL((k_pair_gram_shared<LPP, VPL, W, L, FULL>), dim3(grid), dim3(RB), 0, s, st, u, v1, v2, n,
                            now, lambda, flags, out1, out2);
     }));
     TPNET_HIP_TRY(hipGetLastError());

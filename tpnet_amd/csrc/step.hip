@@ -1,175 +1,22 @@
-// gfx950 kernel of the fused per-batch step (tpnet_update / tpnet_run_stream / tpnet_step_batch): the readout of
-// (src,dst) and (src,neg) on the pre-batch state and the update of the batch's targets in ONE launch
-// (train_link_prediction.py:325-373 order; models/TPNet.py:67-99, :112-128).
-#include "readout.hpp"
-#include "update.hpp"
+// gfx950 fused per-batch step (tpnet_update / tpnet_run_stream / tpnet_step_batch): the 512-thread instantiation of
+// step_impl.hpp and the choice of the workgroup size per batch.
+#include "step_impl.hpp"
 
 namespace tpnet {
 
-// ---------------------------------------------------------------------------------------------------------------
-// fused per-batch step: readout (src,dst) and (src,neg) on the pre-batch state + update, ONE launch.
-// Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target and layer); the others walk a work index
-// space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
-// ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L, bool FULL, bool NT>
-// The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
-// first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
-// -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
-__global__ __launch_bounds__(BLOCK, min_waves_per_simd(LPP, VPL, W)) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
-                                                const int64_t* __restrict__ a_neg, int64_t e0, int32_t ne_,
-                                                uint32_t flags, uint32_t bid, int HEAVY_BLOCKS, double lambda,
-                                                tpnet_state S, StreamArgs a, Plan p, int64_t b) {
-    constexpr int GPB = BLOCK / LPP;
-    constexpr int GPW = 64 / LPP;
-    constexpr int NG = GramCfg<LPP, L>::NG;
-    constexpr int STG = GramCfg<LPP, L>::STAGE;
-    __shared__ float part[(VPL * W * BLOCK > STG) ? VPL * W * BLOCK : STG];   // heavy items' partial sums / readout staging
-    unsigned long long* dbg = p.dbg;
-    (void)dbg;
-    STAMP(0);
-    // e0/ne come with the launch and the item records are fetched speculatively (their slots always exist), so neither
-    // the id loads nor the item loads wait for the batch descriptor (clocks, item counts).  The descriptor is read
-    // AFTER those vector loads have been issued: it is a scalar load whose wait (lgkmcnt) would otherwise sit in front
-    // of them and put one more memory round trip on every wave's critical path.
-    const BatchDesc* __restrict__ Dp = p.desc + b;
-    if ((int)blockIdx.x < HEAVY_BLOCKS) {
-        if (flags & ROLE_UPDATE) {
-            // heavy work unit = (item, layer): L consecutive workgroups share an item
-            const Item* heavy = p.heavy + 2 * e0;
-            const uint32_t cap = 2u * (uint32_t)ne_ * (uint32_t)L;
-            for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
-                const Item I = heavy[h / L];
-                const uint32_t n_heavy = Dp->n_heavy;
-                const double t_last = Dp->t_last;
-                if (h / L >= n_heavy) break;
-                if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
-                update_item_block<LPP, VPL, W, L, FULL, NT>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, (int)(h % L),
-                                                        bid, t_last, lambda, part);
-                STAMP(7);
-            }
-        }
-        return;
-    }
-    const int gl = threadIdx.x % LPP;
-    const int g = threadIdx.x / LPP;
-    const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
-    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
-    const int ostride = packed ? GramCfg<LPP, L>::NT : NG;
-    const int64_t ne = ne_;
-    const int64_t npos = ((flags & ROLE_READOUT) && a.out_pos) ? ne : 0;
-    const int64_t nneg = ((flags & ROLE_READOUT) && a.out_neg) ? ne : 0;
-    // (a shared-src unit per edge -- gram_shared -- was measured here: it halves the readout waves but doubles each
-    // wave's VALU chain: C1 +30 %, C2 +5 % slower, C3/C5 +1 % faster; the pair stays the unit)
-    const int64_t npairs = npos + nneg;
-    const int64_t RP = (npairs + GPW - 1) / GPW * GPW;
-    const int64_t cap_items = (flags & ROLE_UPDATE) ? 2 * ne : 0;   // upper bound of the light items (slots exist)
-    // narrow rows: an item takes 16 lanes = ISL group slots of the work index space (update_item_narrow)
-    constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
-    const int64_t total = RP + cap_items * ISL;
-    const Item* items = p.light + 2 * e0;
-    const int64_t nblk = (int64_t)gridDim.x - HEAVY_BLOCKS;
-
-    for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total; base += nblk * GPB) {
-        const int64_t w = base + g;
-        const int64_t wave0 = base + (g / GPW) * GPW;  // first work index of this wave: decides the wave's role
-        if (wave0 < RP) {
-            const bool valid = w < npairs;
-            int64_t e = 0, u = 0, v = 0;
-            float* out = nullptr;
-            if (valid) {
-                // (src,dst) and (src,neg) of one edge sit in ADJACENT lane groups (work index 2e, 2e+1): the two groups
-                // load the src node's meta record and rows with the same instructions and the same addresses, which the
-                // load unit coalesces -- one fetch from the memory side instead of two in different workgroups/XCDs
-#ifndef TPNET_NO_INTERLEAVE
-                const bool both = npos != 0 && nneg != 0;
-#else
-                const bool both = false;
-#endif
-                const int64_t idx = both ? (w >> 1) : (w < npos ? w : w - npos);
-                const bool isneg = both ? (w & 1) != 0 : (w >= npos);
-                e = e0 + idx;
-                v = isneg ? a_neg[e] : a_dst[e];
-                out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
-                u = a_src[e];
-            }
-            const double now = Dp->now;
-            // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
-            const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
-            if (!__any(mine)) continue;
-            if (packed)
-                gram_pair<LPP, VPL, W, L, FULL, true>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part);
-            else
-                gram_pair<LPP, VPL, W, L, FULL, false>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part);
-            STAMP(5);
-        } else {
-            const int64_t it = (w - RP) / ISL;
-            Item I = items[it < cap_items ? it : 0];
-            const int64_t n_light = (int64_t)Dp->n_light;
-            const double t_last = Dp->t_last;
-            if ((wave0 - RP) / ISL >= n_light) break;   // wave-uniform: no item of this wave exists (and none later)
-            const bool valid = it < n_light &&
-                               (a.own_mod <= 1 || (I.target % a.own_mod) == a.own_rem);   // targets belong to their owner
-            if constexpr (ISL > 1)
-                update_item_narrow<LPP, L>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, (int)(threadIdx.x % 16));
-            else
-                update_item<LPP, VPL, W, L, FULL, NT>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, gl);
-            STAMP(6);
-        }
-    }
-}
-
-
-// resident workgroups of a kernel on this device: occupancy (per CU, from the runtime) x CU count
-template <typename K>
-static int resident_blocks(K kernel) {
-    int dev = 0, cus = 256, per_cu = 1;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    return cus * per_cu;
-}
-
+template int launch_step_bs<BLOCK>(const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t, int32_t, double,
+                                   uint32_t, uint32_t, hipStream_t);
+extern template int launch_step_bs<BLOCK_SMALL>(const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t,
+                                                int32_t, double, uint32_t, uint32_t, hipStream_t);
 
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
-    // narrow rows (d <= 32): 4 / 8 lanes per row with 16-lane items, whose sums are not in index order -- a
-    // TPNET_FLAG_SEQUENTIAL launch keeps the 16-lane geometry
-    if ((reinterpret_cast<uintptr_t>(a.out_pos) | reinterpret_cast<uintptr_t>(a.out_neg)) & 15) return TPNET_ERR_BAD_ARG;
-    Geom geom = pick_geom(st.d);
-    if ((flags & TPNET_FLAG_SEQUENTIAL) && geom.w == 4 && geom.lpp < 16) geom = Geom{16, 1, 4};
-    TPNET_DISPATCH_G(geom, ({
-        constexpr int GPB = BLOCK / LPP;
-        constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
-        static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL, false>);
-        static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
-        const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : ne <= 2048 ? HEAVY_BLOCKS_MEDIUM : HEAVY_BLOCKS_LARGE);
-        // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
-        // chain of dependent memory round trips, so every workgroup should be resident at once (a workgroup that
-        // starts after another one has finished doubles the chain) -- the item slots give way first (a batch
-        // rarely has more than ne distinct light targets; the grid-stride loop covers the rest).
-        const int pair_blocks = grid_for(2 * (int64_t)ne, GPB, 1 << 20);
-        int item_blocks = grid_for(2 * (int64_t)ne * ISL, GPB, 1 << 20);
-        const int room = resident - HEAVY_BLOCKS - pair_blocks;
-        const int item_min = grid_for((((int64_t)ne * 3) / 4 + 1) * ISL, GPB, 1 << 20);
-        if (item_blocks > room) item_blocks = room > item_min ? room : item_min;
-        int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
-        if (grid > HEAVY_BLOCKS + 256 * 8) grid = HEAVY_BLOCKS + 256 * 8;
-        // streamed state stores for mid-size batches on the two geometries that serve them (see stv)
-        static const char* nt_env = getenv("TPNET_DEV_NT_STATE");          // developer override: "0" / "1"
-        constexpr bool NT_GEOM = W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
-        const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
-        if (nt_state)
-            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM>), dim3(grid), dim3(BLOCK), 0, s, a.src, a.dst,
-                               a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
-        else
-            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, false>), dim3(grid), dim3(BLOCK), 0, s, a.src, a.dst,
-                               a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
-    }));
-    TPNET_HIP_TRY(hipGetLastError());
-    return TPNET_OK;
+    // 512-thread workgroups for a batch that is one pass of them (see BLOCK_SMALL in device_common.hpp for the
+    // measurements): 500..2500 edges; 256-thread ones for larger (many passes) and for tiny batches
+    static const char* env = getenv("TPNET_DEV_BLOCK");                  // developer override: "256" / "512"
+    const bool small_wg = env ? env[0] == '2' : (ne > 2500 || ne < 400);
+    return small_wg ? launch_step_bs<BLOCK_SMALL>(st, a, p, b, batch, ne, lambda, launch_id, flags, s)
+                    : launch_step_bs<BLOCK>(st, a, p, b, batch, ne, lambda, launch_id, flags, s);
 }
-
 
 }  // namespace tpnet

@@ -352,13 +352,13 @@ __device__ __forceinline__ void update_item_narrow(const tpnet_state& S, const i
 // slice of the contribution list; the slices' partial sums are added in slice order through LDS (fixed order:
 // reproducible run to run, but the association differs from the strictly sequential sum -- TPNET_FLAG_SEQUENTIAL
 // turns heavy items off).  `layer` = i-1 in 0..L-1; the layer-0 workgroup publishes the new version.
-template <int LPP, int VPL, int W, int L, bool FULL, bool NT>
+template <int LPP, int VPL, int W, int L, bool FULL, bool NT, int BS>
 __device__ __forceinline__ void update_item_block(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                                   const float* __restrict__ s_coef, int32_t u, uint32_t j0,
                                                   uint32_t cnt, int layer, uint32_t bid, double t_last, double lambda,
-                                                  float* __restrict__ part /* LDS [F][BLOCK] */) {
+                                                  float* __restrict__ part /* LDS [F][BS] */) {
     constexpr int F = VPL * W;
-    constexpr int G = BLOCK / LPP;
+    constexpr int G = BS / LPP;
     constexpr int U = 8;
     const int d = S.d;
     const int nvec = d / W;
@@ -427,7 +427,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
             }
         }
 #pragma unroll
-        for (int k = 0; k < F; ++k) part[k * BLOCK + threadIdx.x] = acc[k];
+        for (int k = 0; k < F; ++k) part[k * BS + threadIdx.x] = acc[k];
         __syncthreads();
         if (g == 0) {
             float tot[F];
@@ -435,7 +435,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
             for (int k = 0; k < F; ++k) tot[k] = old[k] * gu;
             for (int q = 0; q < G; ++q) {
 #pragma unroll
-                for (int k = 0; k < F; ++k) tot[k] = tot[k] + part[k * BLOCK + q * LPP + gl];
+                for (int k = 0; k < F; ++k) tot[k] = tot[k] + part[k * BS + q * LPP + gl];
             }
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
