@@ -55,9 +55,16 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
         Plan p{};
         int rc = plan_carve(ws, ws_bytes, Ec, batch, &p);
         if (rc) return rc;
+        // edge-fused updates: every launch of this chunk must run BOTH roles with the (src,dst) readout on, and the sums
+        // must not be order-sensitive by contract; worth it where the batch is bound by bytes, not by its longest chain
+        static const int fuse_env = env_int("TPNET_DEV_FUSE", -1);       // developer override: 0 / 1
+        static const int role_mask0 = env_int("TPNET_DEV_ROLE_MASK", 3);
+        const bool fuse = out_pos && p.fuse_src && role_mask0 == 3 &&
+                          !(flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL)) &&
+                          (fuse_env >= 0 ? fuse_env == 1 : batch > 2500);
         // the clock before a later chunk is t[c0-1], read on device (no host copy of the timestamps is needed)
         rc = plan_build(st, p, src + c0, dst + c0, t + c0, Ec, batch, now_time, c0 > 0 ? t + c0 - 1 : nullptr, lambda,
-                        flags, s);
+                        flags | (fuse ? PLAN_FUSE : 0u), s);
         if (rc) return rc;
         StreamArgs a;
         a.src = src + c0;
@@ -88,7 +95,7 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
                 static const int role_mask = env_int("TPNET_DEV_ROLE_MASK", 3);
                 const uint32_t roles = ((role_mask & 2) ? ROLE_UPDATE : 0u) |
                                        ((have_readout && (role_mask & 1)) ? ROLE_READOUT : 0u);
-                rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | roles, s);
+                rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | roles | (fuse ? STEP_FUSE : 0u), s);
                 if (rc) return rc;
             }
         }

@@ -40,7 +40,10 @@ static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the step
 // occupancy at C3: 4.2 of 8 waves per CU); two 256-thread workgroups refill independently (C3 49 -> 37 us per batch,
 // C5 -6 %, C1 -9 %).  A batch that fits one pass of 512-thread workgroups (500..2500 edges) keeps them: fewer workgroups
 // to dispatch, 6 % faster at C2.
-static constexpr int BLOCK_SMALL = 256;
+#ifndef TPNET_BLOCK_SMALL
+#define TPNET_BLOCK_SMALL 256
+#endif
+static constexpr int BLOCK_SMALL = TPNET_BLOCK_SMALL;
 // workgroups of a step launch reserved for heavy (item, layer) units: measured optima on MI355X (C2: 36-42, the
 // one-pass grid leaves the rest to pairs and light items; B = 10 000: >= 128, the grid is multi-pass anyway)
 // __launch_bounds__'s second argument in HIP-Clang = minimum waves per SIMD the kernel must fit (4 -> at most 128 VGPRs ->
@@ -109,11 +112,8 @@ struct MetaView {
     float g;   // exp(-lambda * (now - tref[copy])): pending decay of layer 1 (layer i: g^i)
 };
 
-__device__ __forceinline__ MetaView read_meta(const NodeMeta* __restrict__ meta, int64_t n, uint32_t bid, double now,
-                                              double lambda) {
-    const uint4* p = reinterpret_cast<const uint4*>(meta + n);
-    const uint4 a = p[0];
-    const uint4 b = p[1];
+// (a, b) = the two 16-byte halves of a node's meta record
+__device__ __forceinline__ MetaView meta_view(const uint4 a, const uint4 b, uint32_t bid, double now, double lambda) {
     int c = (int)(a.x & 1u);
     if ((a.x >> 1) == bid) c ^= 1;  // rewritten by a concurrent group of THIS launch: the pre-batch copy is the other one
     const double t0 = __hiloint2double((int)a.w, (int)a.z);
@@ -124,6 +124,11 @@ __device__ __forceinline__ MetaView read_meta(const NodeMeta* __restrict__ meta,
     m.copy = c;
     m.g = (x == 0.0f) ? 1.0f : expf(x);
     return m;
+}
+__device__ __forceinline__ MetaView read_meta(const NodeMeta* __restrict__ meta, int64_t n, uint32_t bid, double now,
+                                              double lambda) {
+    const uint4* p = reinterpret_cast<const uint4*>(meta + n);
+    return meta_view(p[0], p[1], bid, now, lambda);
 }
 
 // Recursive halving: MP partial sums per lane over a group of 2*M lanes -> lane gl ends with the MP/(2M) complete sums

@@ -100,6 +100,16 @@ int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out) 
     out->desc = (BatchDesc*)take(nb * sizeof(BatchDesc));
     out->sort_tmp_bytes = sort_tmp_bytes(nc, batch);
     out->sort_tmp = take(out->sort_tmp_bytes);
+    // edge-fused update flags alias keys_in (dead after the sort): 2*Ec bytes + Ec floats <= 16*Ec bytes for Ec >= 26
+    const size_t fw_off = align_up(2 * (size_t)Ec, 256);
+    if (fw_off + 4 * (size_t)Ec <= nc * sizeof(uint64_t)) {
+        out->fuse_src = reinterpret_cast<uint8_t*>(out->keys_in);
+        out->fuse_dst = out->fuse_src + Ec;
+        out->fuse_w = reinterpret_cast<float*>(reinterpret_cast<char*>(out->keys_in) + fw_off);
+    } else {
+        out->fuse_src = out->fuse_dst = nullptr;
+        out->fuse_w = nullptr;
+    }
     if (p > end) return TPNET_ERR_WORKSPACE;
     return TPNET_OK;
 }
@@ -194,7 +204,7 @@ __device__ __forceinline__ uint32_t agg_append(BatchDesc* __restrict__ desc, int
 
 __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
                          const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N, int node_bits, double lambda,
-                         uint32_t heavy_threshold, uint32_t* err) {
+                         uint32_t heavy_threshold, int fuse, uint32_t* err) {
     const int64_t nc = 2 * Ec;
     const uint64_t node_mask = (1ull << node_bits) - 1;
     for (int64_t jb = (int64_t)blockIdx.x * blockDim.x; jb < nc; jb += (int64_t)gridDim.x * blockDim.x) {
@@ -242,8 +252,18 @@ __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t*
                     contribution(p, src, dst, t, Ec, B, N, lambda, p.vals_out[j + 1], it.p1, it.w1, nullptr);
             }
         }
+        // a lone contribution rides with its edge's readout pair instead of becoming an item (see Plan::fuse_*)
+        bool fused = false;
+        if (fuse && head && it.cnt == 1) {
+            int64_t fb, fe;
+            int side;
+            decode((int64_t)p.vals_out[j], B, Ec, fb, side, fe);
+            (side ? p.fuse_dst : p.fuse_src)[fe] = 1;
+            p.fuse_w[fe] = it.w0;
+            fused = true;
+        }
         const bool is_heavy = head && it.cnt > heavy_threshold;
-        const bool is_light = head && !is_heavy;
+        const bool is_light = head && !is_heavy && !fused;
         const uint32_t il = agg_append(p.desc, b, is_light, false);
         const uint32_t ih = agg_append(p.desc, b, is_heavy, true);
         if (is_light) p.light[c0 + il] = it;
@@ -288,8 +308,10 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     thr = thr < HEAVY_THRESHOLD ? HEAVY_THRESHOLD : (thr > 128u ? 128u : thr);
     if (thr_env) thr = (uint32_t)atoi(thr_env);
     if (flags & TPNET_FLAG_SEQUENTIAL) thr = 0xFFFFFFFFu;
+    const int fuse = ((flags & PLAN_FUSE) && p.fuse_src) ? 1 : 0;
+    if (fuse) TPNET_HIP_TRY(hipMemsetAsync(p.fuse_src, 0, 2 * (size_t)Ec, s));   // after the sort: the bytes were keys_in
     hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, s, p, src, dst, t, Ec, batch, st.N, node_bits, lambda, thr,
-                       st.err);
+                       fuse, st.err);
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }

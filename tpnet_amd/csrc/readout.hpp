@@ -12,10 +12,16 @@ namespace tpnet {
 // `stage`: LDS, GramCfg::STAGE floats per workgroup, used by the narrow geometries (LPP < 16) only: there a lane ends up
 // with 8 or 16 consecutive outputs, so a direct store touches one 64-byte line per lane and instruction; the values go
 // through LDS instead and leave as whole lines (measured at d=16, B=8000: the store phase of a readout wave 5.6 -> 0.7 us).
-template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED = false>
+template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED = false, bool FUSE = false>
 __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
                                           double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
-                                          unsigned long long* dbg = nullptr, float* __restrict__ stage = nullptr) {
+                                          unsigned long long* dbg = nullptr, float* __restrict__ stage = nullptr,
+                                          uint32_t fuse = 0, float fuse_w = 0.0f, double t_last = 0.0) {
+    // FUSE / fuse (bit 0: u, bit 1: v; only the fused step sets it, and only for an edge's (src,dst) pair): this group also
+    // writes the new bundle of that endpoint -- it is the target's ONLY contribution in the batch (Plan::fuse_*), and
+    // both operands, old[i][target] and P[i-1][partner], are among the rows loaded for the Gram:
+    //   new[i][target] = old[i][target] * g_t^i + (P[i-1][partner] * g_p^(i-1)) * w,   g = decay to the batch's LAST time
+    // (the same operations in the same order as update_item, so the result does not depend on which path ran)
     using C = GramCfg<LPP, L>;
     constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
     const int d = S.d;
@@ -29,11 +35,20 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
     STAMP(1);
     const float* rowp[NN];
     float rs[NN];
+    float gl_last[2] = {1.0f, 1.0f};     // decay of layer 1 to t_last (fused update only)
+    int cur[2] = {0, 0};
+    const int64_t ids[2] = {u, v};
+    if (!FUSE || !idok) fuse = 0;
     {
-        const int64_t ids[2] = {u, v};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const MetaView m = read_meta(meta, ids[s], bid, now, lambda);
+            const uint4* mp = reinterpret_cast<const uint4*>(meta + ids[s]);
+            const uint4 ma = mp[0], mb = mp[1];
+            const MetaView m = meta_view(ma, mb, bid, now, lambda);
+            if constexpr (FUSE) {
+                if (fuse) gl_last[s] = meta_view(ma, mb, bid, t_last, lambda).g;
+            }
+            cur[s] = m.copy;
             rowp[s * NR] = S.p0 + ids[s] * (int64_t)d;
             rs[s * NR] = 1.0f;
             const float* qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
@@ -62,6 +77,31 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
                 ldv_maybe<W, FULL>(rowp[a], vi, vi < nvec, &f[a][j * W]);
             }
         }
+        if constexpr (FUSE) if (fuse) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (fuse & (1u << s)) {
+                    float* qnew = S.q + ((int64_t)(cur[s] ^ 1) * S.N + ids[s]) * ((int64_t)L * d);
+                    float gt = 1.0f, gp = 1.0f;
+#pragma unroll
+                    for (int i = 1; i <= L; ++i) {
+                        gt *= gl_last[s];                            // g_t^i
+                        float nw[F];
+#pragma unroll
+                        for (int k = 0; k < F; ++k) {
+                            const float m = (f[(1 - s) * NR + i - 1][k] * gp) * fuse_w;
+                            nw[k] = f[s * NR + i][k] * gt + m;
+                        }
+                        gp *= gl_last[1 - s];                        // g_p^(i-1) for the next layer
+#pragma unroll
+                        for (int j = 0; j < VPL; ++j) {
+                            const int vi = c0 + j * LPP + gl;
+                            if (FULL || vi < nvec) stv<W>(qnew + (int64_t)(i - 1) * d, vi, &nw[j * W]);
+                        }
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int a = 0; a < NN; ++a) {
             if (a % NR != 0) {
@@ -74,6 +114,12 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
 #pragma unroll
             for (int b = a; b < NN; ++b) acc[a * NN + b] = acc[a * NN + b] + dot_chunk<F>(f[a], f[b]);
         }
+    }
+    if constexpr (FUSE) if (fuse && gl == 0) {
+        NodeMeta* wm = reinterpret_cast<NodeMeta*>(S.meta);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (fuse & (1u << s)) publish_meta(wm + ids[s], cur[s] ^ 1, t_last, bid);
     }
 #pragma unroll
     for (int a = 1; a < NN; ++a) {

@@ -1,22 +1,26 @@
 // gfx950 fused per-batch step (tpnet_update / tpnet_run_stream / tpnet_step_batch): the 512-thread instantiation of
-// step_impl.hpp and the choice of the workgroup size per batch.
+// step_impl.hpp and the choice of the kernel variant per batch.
 #include "step_impl.hpp"
 
 namespace tpnet {
 
-template int launch_step_bs<BLOCK>(const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t, int32_t, double,
-                                   uint32_t, uint32_t, hipStream_t);
-extern template int launch_step_bs<BLOCK_SMALL>(const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t,
-                                                int32_t, double, uint32_t, uint32_t, hipStream_t);
+#define TPNET_STEP_ARGS const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t, int32_t, double, uint32_t, \
+                        uint32_t, hipStream_t
+template int launch_step_bs<BLOCK, false>(TPNET_STEP_ARGS);
+extern template int launch_step_bs<BLOCK_SMALL, false>(TPNET_STEP_ARGS);
+extern template int launch_step_bs<BLOCK_SMALL, true>(TPNET_STEP_ARGS);
 
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
+    // a launch of a fused plan (STEP_FUSE: api.hip turns it on for batches > 2500 edges) takes the variant that carries
+    // the edge-fused update path
+    if (flags & STEP_FUSE) return launch_step_bs<BLOCK_SMALL, true>(st, a, p, b, batch, ne, lambda, launch_id, flags, s);
     // 512-thread workgroups for a batch that is one pass of them (see BLOCK_SMALL in device_common.hpp for the
-    // measurements): 500..2500 edges; 256-thread ones for larger (many passes) and for tiny batches
+    // measurements): 400..2500 edges; 256-thread ones for larger (many passes) and for tiny batches
     static const char* env = getenv("TPNET_DEV_BLOCK");                  // developer override: "256" / "512"
     const bool small_wg = env ? env[0] == '2' : (ne > 2500 || ne < 400);
-    return small_wg ? launch_step_bs<BLOCK_SMALL>(st, a, p, b, batch, ne, lambda, launch_id, flags, s)
-                    : launch_step_bs<BLOCK>(st, a, p, b, batch, ne, lambda, launch_id, flags, s);
+    return small_wg ? launch_step_bs<BLOCK_SMALL, false>(st, a, p, b, batch, ne, lambda, launch_id, flags, s)
+                    : launch_step_bs<BLOCK, false>(st, a, p, b, batch, ne, lambda, launch_id, flags, s);
 }
 
 }  // namespace tpnet

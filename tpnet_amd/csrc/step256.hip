@@ -3,7 +3,7 @@
 
 namespace tpnet {
 
-template int launch_step_bs<BLOCK_SMALL>(const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t, int32_t,
-                                         double, uint32_t, uint32_t, hipStream_t);
+template int launch_step_bs<BLOCK_SMALL, false>(const tpnet_state&, const StreamArgs&, const Plan&, int64_t, int64_t,
+                                                int32_t, double, uint32_t, uint32_t, hipStream_t);
 
 }  // namespace tpnet

@@ -1,5 +1,6 @@
-// The fused per-batch step kernel and its launcher as templates over the workgroup size BS (instantiated for 512 in
-// step.hip and for 256 in step256.hip, two translation units that build in parallel): the readout of (src,dst) and
+// The fused per-batch step kernel and its launcher as templates over the workgroup size BS and the edge-fused update path
+// (instantiated as <512, false> in step.hip, <256, false> in step256.hip, <256, true> in step256f.hip: translation units
+// that build in parallel): the readout of (src,dst) and
 // (src,neg) on the pre-batch state and the update of the batch's targets in ONE launch
 // (train_link_prediction.py:325-373 order; models/TPNet.py:67-99, :112-128).
 #pragma once
@@ -13,7 +14,7 @@ namespace tpnet {
 // Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target and layer); the others walk a work index
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int W, int L, bool FULL, bool NT, int BS>
+template <int LPP, int VPL, int W, int L, bool FULL, bool NT, int BS, bool FUSE>
 // The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
 // first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
 // -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
             const bool valid = w < npairs;
             int64_t e = 0, u = 0, v = 0;
             float* out = nullptr;
+            bool a_dst_pair = false;
             if (valid) {
                 // (src,dst) and (src,neg) of one edge sit in ADJACENT lane groups (work index 2e, 2e+1): the two groups
                 // load the src node's meta record and rows with the same instructions and the same addresses, which the
@@ -91,17 +93,30 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
                 const bool isneg = both ? (w & 1) != 0 : (w >= npos);
                 e = e0 + idx;
                 v = isneg ? a_neg[e] : a_dst[e];
+                a_dst_pair = !isneg;
                 out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
                 u = a_src[e];
             }
+            // edge-fused update: the (src,dst) pair of an edge also writes the bundles of those endpoints whose only
+            // contribution in this batch is this edge (Plan::fuse_*)
+            constexpr bool CAN_FUSE = FUSE;                // a kernel variant of its own: the unfused ones stay lean
+            uint32_t fbits = 0;
+            float fw = 0.0f;
+            if (CAN_FUSE && (flags & STEP_FUSE) && valid && a_dst_pair) {
+                fbits = (uint32_t)p.fuse_src[e] | ((uint32_t)p.fuse_dst[e] << 1);
+                fw = p.fuse_w[e];
+            }
             const double now = Dp->now;
+            const double t_last_p = Dp->t_last;
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
             const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
             if (!__any(mine)) continue;
             if (packed)
-                gram_pair<LPP, VPL, W, L, FULL, true>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part);
+                gram_pair<LPP, VPL, W, L, FULL, true, CAN_FUSE>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
+                                                      fw, t_last_p);
             else
-                gram_pair<LPP, VPL, W, L, FULL, false>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part);
+                gram_pair<LPP, VPL, W, L, FULL, false, CAN_FUSE>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
+                                                       fw, t_last_p);
             STAMP(5);
         } else {
             const int64_t it = (w - RP) / ISL;
@@ -134,7 +149,7 @@ static int resident_blocks(K kernel, int block_threads) {
 }
 
 
-template <int BS>
+template <int BS, bool FUSE>
 int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                    double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
     // narrow rows (d <= 32): 4 / 8 lanes per row with 16-lane items, whose sums are not in index order -- a
@@ -145,7 +160,7 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
     TPNET_DISPATCH_G(geom, ({
         constexpr int GPB = BS / LPP;
         constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
-        static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL, false, BS>, BS);
+        static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL, false, BS, FUSE>, BS);
         static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
         const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : ne <= 2048 ? HEAVY_BLOCKS_MEDIUM : HEAVY_BLOCKS_LARGE);
         // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
@@ -166,10 +181,10 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         constexpr bool NT_GEOM = BS == BLOCK && W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
         const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
         if (nt_state)
-            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM, BS>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
+            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
                                a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
         else
-            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, false, BS>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
+            hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, false, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
                                a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
     }));
     TPNET_HIP_TRY(hipGetLastError());

@@ -57,6 +57,13 @@ struct Plan {
     Item* light;          // [2*Ec] batch b owns [2*e0(b), 2*e0(b)+n_light)
     Item* heavy;          // [2*Ec]
     BatchDesc* desc;      // [nb]
+    // edge-fused updates (plan_build with PLAN_FUSE): a target with exactly ONE contribution in its batch is not put on the
+    // light list; the readout group of that edge's (src,dst) pair, which has both bundles in registers anyway, writes the
+    // target's new bundle.  Per edge of the chunk: does the src / dst endpoint take its update this way, and the edge's
+    // time weight.  The arrays live in keys_in, which is dead once the sort has run.
+    uint8_t* fuse_src;    // [Ec]
+    uint8_t* fuse_dst;    // [Ec]
+    float* fuse_w;        // [Ec]
     void* sort_tmp;
     size_t sort_tmp_bytes;
     unsigned long long* dbg;  // first TPNET_DBG_BYTES of the workspace: in-kernel stamps of diagnostic builds (-DTPNET_STAMPS)
@@ -139,6 +146,8 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
 // internal flag bits of launch_step (above the public TPNET_FLAG_* bits)
 static constexpr uint32_t ROLE_READOUT = 1u << 16;
 static constexpr uint32_t ROLE_UPDATE = 1u << 17;
+static constexpr uint32_t STEP_FUSE = 1u << 18;     // launch_step: the plan was built with PLAN_FUSE and this launch has both roles
+static constexpr uint32_t PLAN_FUSE = 1u << 19;     // plan_build: divert single-contribution targets to the edge-fused path
 
 extern thread_local int g_last_hip_error;
 #define TPNET_HIP_TRY(expr)                                   \
