@@ -552,14 +552,15 @@ def test_internal_chunking_with_a_small_workspace():
 # ---------------------------------------------------------------------------------------------------------
 # packed raw readout (the wire format of the column-sharded table) + tpnet_gram_unpack / tpnet_gram_finish
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,L", [(128, 3), (16, 3), (64, 2), (30, 1), (256, 4)])
-def test_packed_readout_unpacks_to_the_full_features(d, L):
+@pytest.mark.parametrize("d,L,N,B", [(128, 3, 150, 64), (16, 3, 150, 64), (64, 2, 150, 64), (30, 1, 150, 64),
+                                     (256, 4, 150, 64), (32, 3, 5000, 2600), (128, 3, 7000, 2600)])
+def test_packed_readout_unpacks_to_the_full_features(d, L, N, B):
+    """(B = 2600: the plan diverts lone contributions to the edge-fused path, which must work with packed rows too)"""
     _need_gpu()
     import ctypes as C
     from tpnet_amd import _lib
     rng = np.random.RandomState(d + L)
-    N, B = 150, 64
-    E = 3 * B + 5
+    E = 3 * B + 5 if B < 1000 else 2 * B + 300
     src, dst, neg, t = _random_stream(rng, N, E, 2.0e5)
     P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
     dev = lambda x: torch.from_numpy(x).to(DEV)
