@@ -27,7 +27,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // segment per batch: rocPRIM sorts a segment of a few thousand keys inside one workgroup's LDS, all batches in one
 // launch, instead of several device-wide passes over (batch, node) keys.  Very long segments (one workgroup would walk
 // them alone) keep the device-wide sort.
-static constexpr int64_t SEGSORT_MAX_KEYS = 32768;
+static constexpr int64_t SEGSORT_MAX_KEYS = 8192;   // (20 000-key segments on 24 node bits: 363 us per 1.2 M keys, the device-wide sort ~250)
 struct SegOffset {   // offset of segment boundary (i + shift): begin iterator = shift 0, end iterator = shift 1
     unsigned per, total, shift;
     __host__ __device__ unsigned operator()(unsigned i) const {
