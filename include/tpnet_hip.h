@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 1
+#define TPNET_ABI_VERSION 2 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, TPNET_FLAG_PACKED */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
