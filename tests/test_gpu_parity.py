@@ -361,17 +361,18 @@ def test_shared_first_node_readout(d, L):
     a = np.repeat(np.tile(src[s], 2), K); b_ = np.repeat(np.tile(dst[s], 2), K)
     g1, g2 = rp.pair_gram_shared(w, a, b_)
     r1, r2 = rp.pair_gram(w, a), rp.pair_gram(w, b_)
-    if d in (64, 128):                                # one chunk of 4 floats per lane: the very same fma chains
-        assert torch.equal(g1, r1) and torch.equal(g2, r2)
-    else:
-        np.testing.assert_allclose(g1.cpu().numpy(), r1.cpu().numpy(), rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(g2.cpu().numpy(), r2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # (the two kernels add the lanes' partial sums in different orders -- LDS rows vs recursive halving)
+    np.testing.assert_allclose(g1.cpu().numpy(), r1.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(g2.cpu().numpy(), r2.cpu().numpy(), rtol=1e-5, atol=1e-5)
     _assert_features(g1.cpu().numpy(), st, w, a)
     _assert_features(g2.cpu().numpy(), st, w, b_)
     # the reference's call: src = tile(neigh, 2), dst = [repeat(tile(src,2),K); repeat(tile(dst,2),K)]
     rp.mlp = torch.nn.Identity()
     full = rp.get_pair_wise_feature(np.tile(w, 2), np.concatenate([a, b_]))
-    assert torch.equal(full, torch.cat([g1, g2], dim=0))
+    if d > 128:                                       # the shared-first-node kernel itself served the call
+        assert torch.equal(full, torch.cat([g1, g2], dim=0))
+    else:                                             # the generic kernel did (16-lane x 2-vector geometry)
+        np.testing.assert_allclose(full.cpu().numpy(), torch.cat([g1, g2], dim=0).cpu().numpy(), rtol=1e-5, atol=1e-5)
     # a pair list that only looks similar must take the generic path and still be right
     odd = rp.get_pair_wise_feature(np.concatenate([w, w[::-1]]), np.concatenate([a, b_]))
     _assert_features(odd.cpu().numpy()[len(w):], st, w[::-1], b_)

@@ -213,9 +213,24 @@ struct GramCfg {
     static constexpr int NT = NN * (NN + 1) / 2;   // distinct entries of the symmetric Gram (TPNET_FLAG_PACKED rows)
     static constexpr int MP = ((NG + LPP - 1) / LPP) * LPP;
     static constexpr int PER = MP / LPP;
-    // LDS floats of the staged store (narrow rows) for a workgroup of BS threads
+    // Cross-lane reduction THROUGH LDS (LPP >= 16, 256-thread workgroups, L <= 3): every lane parks its NT distinct
+    // partial sums in a [NT][LPP+4] tile of its group, lane v then adds row v (LPP values, float4 reads) and writes the
+    // result to both mirrored positions of an [NG] output tile, from which every lane takes its PER consecutive outputs:
+    // ~100 instructions and two LDS round trips instead of ~150 dependent DPP / permlane operations (measured on the
+    // VALU-bound readout of long pair lists).  Wider workgroups would need more than 64 KB of LDS: they keep Halve.
+    static constexpr int RSTRIDE = LPP + 4;
+    static constexpr int RED = NT * RSTRIDE + NG;                      // floats per group
     template <int BS>
-    static constexpr int stage_floats() { return (LPP < 16) ? NG * (BS / LPP) : 1; }
+    static constexpr bool lds_reduce() {
+#ifdef TPNET_NO_LDSRED
+        return false;
+#else
+        return LPP >= 16 && (BS / LPP) * RED * 4 <= 64 * 1024;
+#endif
+    }
+    // LDS floats a workgroup of BS threads needs for the readout: the staged store of the narrow rows, or the reduction
+    template <int BS>
+    static constexpr int stage_floats() { return (LPP < 16) ? NG * (BS / LPP) : lds_reduce<BS>() ? RED * (BS / LPP) : 1; }
 };
 
 // FULL = the row is exactly one chunk (d == LPP*VPL*W): no tail predicate, no chunk loop; callers guarantee that an

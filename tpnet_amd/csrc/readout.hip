@@ -18,16 +18,17 @@ __global__ __launch_bounds__(RB) void k_pair_gram(tpnet_state S, const int64_t* 
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
     const int stride = packed ? GramCfg<LPP, L>::NT : NG;
     __shared__ float stage[GramCfg<LPP, L>::template stage_floats<RB>()];
+    constexpr bool LR = GramCfg<LPP, L>::template lds_reduce<RB>();
     for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
         const int64_t p = base + g;
         const bool valid = p < n;
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
         if (packed)
-            gram_pair<LPP, VPL, W, L, FULL, true>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * stride,
-                                                  gl, nullptr, stage);
+            gram_pair<LPP, VPL, W, L, FULL, true, false, LR>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
+                                                             out + p * stride, gl, nullptr, stage);
         else
-            gram_pair<LPP, VPL, W, L, FULL, false>(S, uu, vv, valid, READER_BID, now, lambda, do_scale, out + p * stride,
-                                                   gl, nullptr, stage);
+            gram_pair<LPP, VPL, W, L, FULL, false, false, LR>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
+                                                              out + p * stride, gl, nullptr, stage);
     }
 }
 

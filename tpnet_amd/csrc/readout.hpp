@@ -12,7 +12,7 @@ namespace tpnet {
 // `stage`: LDS, GramCfg::STAGE floats per workgroup, used by the narrow geometries (LPP < 16) only: there a lane ends up
 // with 8 or 16 consecutive outputs, so a direct store touches one 64-byte line per lane and instruction; the values go
 // through LDS instead and leave as whole lines (measured at d=16, B=8000: the store phase of a readout wave 5.6 -> 0.7 us).
-template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED = false, bool FUSE = false>
+template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED = false, bool FUSE = false, bool LDSRED = false>
 __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64_t v, bool valid, uint32_t bid,
                                           double now, double lambda, bool do_scale, float* __restrict__ out, int gl,
                                           unsigned long long* dbg = nullptr, float* __restrict__ stage = nullptr,
@@ -120,6 +120,70 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             if (fuse & (1u << s)) publish_meta(wm + ids[s], cur[s] ^ 1, t_last, bid);
+    }
+    if constexpr (LDSRED) {
+        // reduction through LDS (GramCfg::lds_reduce): park the NT distinct partials, sum row v, mirror into the output tile
+        STAMP(3);
+        constexpr int RS = C::RSTRIDE;
+        float* red = stage + (threadIdx.x / LPP) * C::RED;
+        float* so = red + C::NT * RS;
+        {
+            int tix = 0;
+#pragma unroll
+            for (int a = 0; a < NN; ++a) {
+#pragma unroll
+                for (int b = a; b < NN; ++b) {
+                    red[tix * RS + gl] = acc[a * NN + b];
+                    ++tix;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // a group's lanes are in one wave: LDS executes in issue order
+#pragma unroll
+        for (int it = 0; it * LPP < C::NT; ++it) {
+            const int v = it * LPP + gl;
+            if (v < C::NT) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f* row = reinterpret_cast<const v4f*>(red + v * RS);
+                float sum = 0.0f;
+#pragma unroll
+                for (int l = 0; l < LPP / 4; ++l) {
+                    const v4f q = row[l];
+                    sum = (((sum + q.x) + q.y) + q.z) + q.w;
+                }
+                if constexpr (PACKED) {
+                    so[v] = sum;
+                } else {
+                    int a = 0, off = 0;                          // v -> (a, b): row a of the upper triangle starts at off
+#pragma unroll
+                    for (int r = 1; r < NN; ++r) {
+                        const int o = r * NN - (r * (r - 1)) / 2;
+                        if (v >= o) { a = r; off = o; }
+                    }
+                    const int b = a + (v - off);
+                    so[a * NN + b] = sum;
+                    so[b * NN + a] = sum;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        STAMP(4);
+        constexpr int NOUT = PACKED ? C::NT : C::NG;
+#pragma unroll
+        for (int j = 0; j * LPP < NOUT; ++j) {                    // lane gl takes outputs gl, gl+LPP, ...: whole lines
+            const int c = j * LPP + gl;
+            if (valid && c < NOUT) {
+                float x = so[c];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (:127)
+                    x = logf(x + 1.0f);          // log(x + 1), not log1p (:128)
+                }
+                if (!idok) x = __builtin_nanf("");
+                __builtin_nontemporal_store(x, out + c);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();            // the tiles are reused by the next pair of this group
+        return;
     }
 #pragma unroll
     for (int a = 1; a < NN; ++a) {
@@ -291,6 +355,8 @@ __device__ __forceinline__ void gram_shared(const tpnet_state& S, int64_t u, int
             }
         }
     }
+    // (a reduction through LDS like gram_pair's was measured here: 62 slots x (LPP+4) floats per unit cost the kernel its
+    // occupancy -- 800 000 units at d=256: 348 -> 414 us)
     Halve<SC::MPS, LPP / 2>::run(acc, gl);        // lane gl now holds the complete sums of slots [gl*PERS, ...)
 
     // output element idx = a*NN + b of the two Gram matrices -> the slot it comes from

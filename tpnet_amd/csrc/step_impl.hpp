@@ -99,6 +99,7 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
             }
             // edge-fused update: the (src,dst) pair of an edge also writes the bundles of those endpoints whose only
             // contribution in this batch is this edge (Plan::fuse_*)
+            constexpr bool LR = GramCfg<LPP, L>::template lds_reduce<BS>();
             constexpr bool CAN_FUSE = FUSE;                // a kernel variant of its own: the unfused ones stay lean
             uint32_t fbits = 0;
             float fw = 0.0f;
@@ -112,10 +113,10 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
             const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
             if (!__any(mine)) continue;
             if (packed)
-                gram_pair<LPP, VPL, W, L, FULL, true, CAN_FUSE>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
+                gram_pair<LPP, VPL, W, L, FULL, true, CAN_FUSE, LR>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
                                                       fw, t_last_p);
             else
-                gram_pair<LPP, VPL, W, L, FULL, false, CAN_FUSE>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
+                gram_pair<LPP, VPL, W, L, FULL, false, CAN_FUSE, LR>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
                                                        fw, t_last_p);
             STAMP(5);
         } else {
