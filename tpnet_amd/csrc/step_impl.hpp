@@ -37,17 +37,23 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     const BatchDesc* __restrict__ Dp = p.desc + b;
     if ((int)blockIdx.x < HEAVY_BLOCKS) {
         if (flags & ROLE_UPDATE) {
-            // heavy work unit = (item, layer): L consecutive workgroups share an item
+            // heavy work unit = (item, layer, column part): the layers of the update are independent sums and so are the
+            // columns of a row.  In the 256-thread kernels (large batches: one item of a C3 / C5 batch has ~1 000
+            // contributions) a row group of 32 / 64 lanes is cut into parts of 16 lanes, so that 16 slices instead of 8 / 4
+            // share the hub's list inside a workgroup and 2 / 4 times as many workgroups share the hub.
+            constexpr int CP = (BS == BLOCK_SMALL && FULL && W == 4 && LPP > 16) ? LPP / 16 : 1;
+            constexpr int LPH = LPP / CP;
             const Item* heavy = p.heavy + 2 * e0;
-            const uint32_t cap = 2u * (uint32_t)ne_ * (uint32_t)L;
+            const uint32_t cap = 2u * (uint32_t)ne_ * (uint32_t)(L * CP);
             for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
-                const Item I = heavy[h / L];
+                const Item I = heavy[h / (L * CP)];
                 const uint32_t n_heavy = Dp->n_heavy;
                 const double t_last = Dp->t_last;
-                if (h / L >= n_heavy) break;
+                if (h / (L * CP) >= n_heavy) break;
                 if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
-                update_item_block<LPP, VPL, W, L, FULL, NT, BS>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt, (int)(h % L),
-                                                        bid, t_last, lambda, part);
+                update_item_block<LPH, VPL, W, L, FULL, NT, BS>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt,
+                                                                (int)((h / CP) % L), bid, t_last, lambda, part,
+                                                                (int)(h % CP) * LPH * VPL);
                 STAMP(7);
             }
         }

@@ -356,7 +356,10 @@ template <int LPP, int VPL, int W, int L, bool FULL, bool NT, int BS>
 __device__ __forceinline__ void update_item_block(const tpnet_state& S, const int32_t* __restrict__ s_partner,
                                                   const float* __restrict__ s_coef, int32_t u, uint32_t j0,
                                                   uint32_t cnt, int layer, uint32_t bid, double t_last, double lambda,
-                                                  float* __restrict__ part /* LDS [F][BS] */) {
+                                                  float* __restrict__ part /* LDS [F][BS] */, int vbase = 0) {
+    // `vbase`: first 16-byte vector of the COLUMN PART this call covers.  The columns of a row are independent, so a hub at
+    // wide rows is cut into parts of LPP*VPL vectors (LPP here = the lanes of one part, fewer than the kernel's row group):
+    // more slices per workgroup share its contribution list and more workgroups share the hub, with nothing to combine.
     constexpr int F = VPL * W;
     constexpr int G = BS / LPP;
     constexpr int U = 8;
@@ -382,7 +385,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
         for (int k = 0; k < F; ++k) acc[k] = 0.0f;
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {                 // the target's pre-batch row: fetched up front by group 0
-            const int vi = c0 + j * LPP + gl;
+            const int vi = vbase + c0 + j * LPP + gl;
             ldv_pred<W>(qold, vi, g == 0 && vi < nvec, &old[j * W]);
         }
         for (uint32_t r0 = jb; __any(r0 < je); r0 += LPP) {
@@ -410,7 +413,7 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
                                                    : S.q + ((int64_t)cp * S.N + pv) * ((int64_t)L * d) + (int64_t)(layer - 1) * d;
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) {
-                        const int vi = c0 + j * LPP + gl;
+                        const int vi = vbase + c0 + j * LPP + gl;
                         ldv_maybe<W, FULL>(rp, vi, ok[k] && vi < nvec, &r[k][j * W]);
                     }
                 }
@@ -439,13 +442,13 @@ __device__ __forceinline__ void update_item_block(const tpnet_state& S, const in
             }
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
-                const int vi = c0 + j * LPP + gl;
+                const int vi = vbase + c0 + j * LPP + gl;
                 if (FULL || vi < nvec) stv<W, NT>(qnew, vi, &tot[j * W]);
             }
         }
         __syncthreads();
     }
-    if (layer == 0 && threadIdx.x == 0) {
+    if (layer == 0 && vbase == 0 && threadIdx.x == 0) {
         publish_meta(meta + u, mu.copy ^ 1, t_last, bid);
     }
 }
