@@ -78,9 +78,24 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     const Item* items = p.light + 2 * e0;
     const int64_t nblk = (int64_t)gridDim.x - HEAVY_BLOCKS;
 
-    for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total; base += nblk * GPB) {
-        const int64_t w = base + g;
-        const int64_t wave0 = base + (g / GPW) * GPW;  // first work index of this wave: decides the wave's role
+    // STEP_ITEMS_FIRST (large batches): the light items lead the work index space instead of trailing it.  An item is a
+    // longer chain of dependent round trips than a pair (up to heavy_threshold contributions, a few rows in flight), so
+    // it should start first and leave the short pairs to fill the end of the launch.  Needs the batch's item count up
+    // front: one scalar load that a small, latency-bound batch does not want to wait for.
+    int64_t lead = 0, total_w = total;
+    if (flags & STEP_ITEMS_FIRST) {
+        lead = (((int64_t)Dp->n_light * ISL + GPW - 1) / GPW) * GPW;
+        total_w = lead + RP;
+    }
+
+    for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total_w; base += nblk * GPB) {
+        int64_t w = base + g;
+        int64_t wave0 = base + (g / GPW) * GPW;        // first work index of this wave: decides the wave's role
+        if (flags & STEP_ITEMS_FIRST) {                // positions [0, lead) are the items, [lead, lead + RP) the pairs
+            const int64_t sh = (wave0 < lead) ? RP : -lead;
+            w += sh;
+            wave0 += sh;
+        }
         if (wave0 < RP) {
             const bool valid = w < npairs;
             int64_t e = 0, u = 0, v = 0;
@@ -187,12 +202,15 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         static const char* nt_env = getenv("TPNET_DEV_NT_STATE");          // developer override: "0" / "1"
         constexpr bool NT_GEOM = BS == BLOCK && W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
         const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
+        static const char* if_env = getenv("TPNET_DEV_ITEMS_FIRST");        // developer override: "0" / "1"
+        const bool items_first = (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 2500);
+        const uint32_t kflags = flags | (items_first ? STEP_ITEMS_FIRST : 0u);
         if (nt_state)
             hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
-                               a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
+                               a.neg, b * batch, ne, kflags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
         else
             hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, false, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
-                               a.neg, b * batch, ne, flags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
+                               a.neg, b * batch, ne, kflags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
