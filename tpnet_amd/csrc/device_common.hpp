@@ -218,6 +218,9 @@ struct GramCfg {
     // result to both mirrored positions of an [NG] output tile, from which every lane takes its PER consecutive outputs:
     // ~100 instructions and two LDS round trips instead of ~150 dependent DPP / permlane operations (measured on the
     // VALU-bound readout of long pair lists).  Wider workgroups would need more than 64 KB of LDS: they keep Halve.
+#ifndef TPNET_LDSRED_MAX_KB
+#define TPNET_LDSRED_MAX_KB 64
+#endif
     static constexpr int RSTRIDE = LPP + 4;
     static constexpr int RED = NT * RSTRIDE + NG;                      // floats per group
     template <int BS>
@@ -225,7 +228,7 @@ struct GramCfg {
 #ifdef TPNET_NO_LDSRED
         return false;
 #else
-        return LPP >= 16 && (BS / LPP) * RED * 4 <= 64 * 1024;
+        return LPP >= 16 && (BS / LPP) * RED * 4 <= TPNET_LDSRED_MAX_KB * 1024;
 #endif
     }
     // LDS floats a workgroup of BS threads needs for the readout: the staged store of the narrow rows, or the reduction
