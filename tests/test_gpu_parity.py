@@ -171,7 +171,8 @@ def _random_stream(rng, N, E, span, hub_frac=0.2):
 @pytest.mark.parametrize("d,L,N,B", [(64, 3, 300, 50), (128, 3, 500, 128), (256, 3, 200, 96), (512, 2, 150, 64),
                                      (120, 3, 260, 40), (140, 1, 90, 33), (30, 4, 64, 20), (1024, 1, 80, 16),
                                      (128, 4, 333, 77), (64, 2, 1000, 500), (16, 3, 400, 200), (32, 3, 300, 150),
-                                     (24, 2, 200, 64), (8, 4, 128, 100)])
+                                     (24, 2, 200, 64), (8, 4, 128, 100), (512, 4, 100, 40), (256, 4, 120, 500),
+                                     (64, 4, 150, 450), (128, 1, 90, 30)])
 @pytest.mark.parametrize("exact", [True, False])
 def test_stream_matches_oracle(d, L, N, B, exact):
     """run_stream (fused readout + update per batch, ragged last batch) == oracle loop readout, readout, update."""
@@ -591,7 +592,8 @@ def test_packed_readout_unpacks_to_the_full_features(d, L, N, B):
 # ---------------------------------------------------------------------------------------------------------
 # edge-fused updates (batches > 2500 edges: a target's lone contribution is applied by its edge's readout group)
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,L,N", [(64, 3, 6000), (128, 2, 3000), (256, 3, 9000), (16, 3, 5000), (36, 1, 4000)])
+@pytest.mark.parametrize("d,L,N", [(64, 3, 6000), (128, 2, 3000), (256, 3, 9000), (16, 3, 5000), (36, 1, 4000),
+                                   (512, 4, 3000), (128, 4, 5000)])
 def test_large_batches_with_edge_fused_updates_match_oracle(d, L, N):
     """B = 2600 on a sparse graph: most targets have exactly one contribution per batch and take the fused path, hubs
     and duplicates stay on the item lists; features and state must still equal the oracle's."""
