@@ -543,6 +543,20 @@ def test_internal_chunking_with_a_small_workspace():
     b._params_valid = False
     assert torch.equal(fa, fb) and torch.equal(na, nb_)
     np.testing.assert_array_equal(_layers(a), _layers(b))
+    # packed feature rows through the same chunked path (a chunk's outputs start at c0 * 36 floats, not c0 * 64)
+    c = _module(N, d, L, 2e-6, t[0], P0=P0)
+    c._ensure_engine()
+    NT = c.packed_feature_dim
+    pp = torch.empty((E, NT), dtype=torch.float32, device=DEV); pn = torch.empty_like(pp)
+    st_c = c._state()
+    rc = lib.tpnet_run_stream(C.byref(st_c), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, float(t[0]),
+                              2e-6, 1, _lib.FLAG_PACKED | _lib.FLAG_NOT_SCALE, pp.data_ptr(), pn.data_ptr(), ws.data_ptr(),
+                              small, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    for full_rows, pk in ((fa, pp), (na, pn)):
+        out = torch.empty_like(full_rows)
+        _lib.check(lib.tpnet_gram_unpack(pk.data_ptr(), E, L, 0, out.data_ptr(), c._stream()), "gram_unpack")
+        assert torch.equal(out, full_rows)
     # and a workspace that cannot hold even one batch is refused, not overrun
     tiny = torch.empty(1024, dtype=torch.uint8, device=DEV)
     rc = lib.tpnet_run_stream(C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, float(t[0]),
@@ -555,7 +569,7 @@ def test_internal_chunking_with_a_small_workspace():
 # packed raw readout (the wire format of the column-sharded table) + tpnet_gram_unpack / tpnet_gram_finish
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("d,L,N,B", [(128, 3, 150, 64), (16, 3, 150, 64), (64, 2, 150, 64), (30, 1, 150, 64),
-                                     (256, 4, 150, 64), (32, 3, 5000, 2600), (128, 3, 7000, 2600)])
+                                     (256, 4, 150, 64), (32, 3, 5000, 2600), (128, 3, 7000, 2600), (64, 3, 300, 11)])
 def test_packed_readout_unpacks_to_the_full_features(d, L, N, B):
     """(B = 2600: the plan diverts lone contributions to the edge-fused path, which must work with packed rows too)"""
     _need_gpu()
@@ -563,6 +577,8 @@ def test_packed_readout_unpacks_to_the_full_features(d, L, N, B):
     from tpnet_amd import _lib
     rng = np.random.RandomState(d + L)
     E = 3 * B + 5 if B < 1000 else 2 * B + 300
+    if B == 11:
+        E = 150 * B + 3                                    # a longer stream of small batches
     src, dst, neg, t = _random_stream(rng, N, E, 2.0e5)
     P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
     dev = lambda x: torch.from_numpy(x).to(DEV)
@@ -627,3 +643,4 @@ def test_large_batches_with_edge_fused_updates_match_oracle(d, L, N):
     # (the ragged tail runs on 256-thread workgroups in the fused stream and on 512-thread ones here: the hub's partial sums
     # associate differently)
     _assert_state(_layers(rp2), _layers(rp), 1e-5, "update-only vs fused")
+

@@ -48,7 +48,8 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
     if (E == 0) return TPNET_OK;
     const int64_t chunk = max_chunk(ws_bytes, E, batch);
     if (chunk < 1) return TPNET_ERR_WORKSPACE;
-    const int NG = (2 * st.L + 2) * (2 * st.L + 2);
+    const int NN = 2 * st.L + 2;
+    const int NG = (flags & TPNET_FLAG_PACKED) ? NN * (NN + 1) / 2 : NN * NN;   // floats per feature row of a chunk's outputs
     uint32_t lid = launch_id_base;
     for (int64_t c0 = 0; c0 < E; c0 += chunk) {
         const int64_t Ec = (E - c0 < chunk) ? (E - c0) : chunk;
