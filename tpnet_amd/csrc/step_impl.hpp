@@ -82,19 +82,26 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     // longer chain of dependent round trips than a pair (up to heavy_threshold contributions, a few rows in flight), so
     // it should start first and leave the short pairs to fill the end of the launch.  Needs the batch's item count up
     // front: one scalar load that a small, latency-bound batch does not want to wait for.
+    // (compiled into the fused-plan variant only -- the same batches take both -- so that the other variants keep their
+    // prologue of ONE scalar-load round trip: with this block present the compiler splits the kernel-argument loads over
+    // two waits, +0.3 us on every wave of a small batch)
     int64_t lead = 0, total_w = total;
-    if (flags & STEP_ITEMS_FIRST) {
-        lead = (((int64_t)Dp->n_light * ISL + GPW - 1) / GPW) * GPW;
-        total_w = lead + RP;
+    if constexpr (FUSE) {
+        if (flags & STEP_ITEMS_FIRST) {
+            lead = (((int64_t)Dp->n_light * ISL + GPW - 1) / GPW) * GPW;
+            total_w = lead + RP;
+        }
     }
 
     for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total_w; base += nblk * GPB) {
         int64_t w = base + g;
         int64_t wave0 = base + (g / GPW) * GPW;        // first work index of this wave: decides the wave's role
-        if (flags & STEP_ITEMS_FIRST) {                // positions [0, lead) are the items, [lead, lead + RP) the pairs
-            const int64_t sh = (wave0 < lead) ? RP : -lead;
-            w += sh;
-            wave0 += sh;
+        if constexpr (FUSE) {
+            if (flags & STEP_ITEMS_FIRST) {            // positions [0, lead) are the items, [lead, lead + RP) the pairs
+                const int64_t sh = (wave0 < lead) ? RP : -lead;
+                w += sh;
+                wave0 += sh;
+            }
         }
         if (wave0 < RP) {
             const bool valid = w < npairs;
@@ -203,7 +210,7 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         constexpr bool NT_GEOM = BS == BLOCK && W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
         const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
         static const char* if_env = getenv("TPNET_DEV_ITEMS_FIRST");        // developer override: "0" / "1"
-        const bool items_first = (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 2500);
+        const bool items_first = FUSE && (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 2500);
         const uint32_t kflags = flags | (items_first ? STEP_ITEMS_FIRST : 0u);
         if (nt_state)
             hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
