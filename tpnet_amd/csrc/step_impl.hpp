@@ -15,13 +15,16 @@ namespace tpnet {
 // space: [0, RP) readout pairs (RP rounded up to whole waves so that a wave has one role), then the light items.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, int W, int L, bool FULL, bool NT, int BS, bool FUSE>
-// The arguments every wave needs FIRST (the id arrays, e0/ne, the role flags) lead the signature as plain scalars: the
-// first 16 SGPRs of kernel arguments are preloaded by the command processor at wave launch (-mllvm
-// -amdgpu-kernarg-preload-count=16), so the id loads can be issued without waiting for a kernarg fetch.
+// The arguments every wave needs FIRST (the id arrays, this batch's item lists, e0/ne, the role flags incl. which outputs
+// exist) lead the signature as plain scalars: the first 16 SGPRs of kernel arguments are preloaded by the command
+// processor at wave launch (-mllvm -amdgpu-kernarg-preload-count=16), so the role of a wave is decided and its id / item
+// loads are issued without waiting for a kernarg fetch.
 __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
-                                                const int64_t* __restrict__ a_neg, int64_t e0, int32_t ne_,
-                                                uint32_t flags, uint32_t bid, int HEAVY_BLOCKS, double lambda,
+                                                const int64_t* __restrict__ a_neg, const Item* __restrict__ items,
+                                                const Item* __restrict__ heavy, uint32_t e0_, int32_t ne_,
+                                                uint32_t flags, int HEAVY_BLOCKS, uint32_t bid, double lambda,
                                                 tpnet_state S, StreamArgs a, Plan p, int64_t b) {
+    const int64_t e0 = e0_;     // first edge of the batch inside the chunk (< 2^30: api.hip caps a chunk there); 14 SGPRs so far
     constexpr int GPB = BS / LPP;
     constexpr int GPW = 64 / LPP;
     constexpr int NG = GramCfg<LPP, L>::NG;
@@ -43,7 +46,6 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
             // share the hub's list inside a workgroup and 2 / 4 times as many workgroups share the hub.
             constexpr int CP = (BS == BLOCK_SMALL && FULL && W == 4 && LPP > 16) ? LPP / 16 : 1;
             constexpr int LPH = LPP / CP;
-            const Item* heavy = p.heavy + 2 * e0;
             const uint32_t cap = 2u * (uint32_t)ne_ * (uint32_t)(L * CP);
             for (uint32_t h = blockIdx.x; h < cap; h += HEAVY_BLOCKS) {
                 const Item I = heavy[h / (L * CP)];
@@ -65,8 +67,8 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
     const int ostride = packed ? GramCfg<LPP, L>::NT : NG;
     const int64_t ne = ne_;
-    const int64_t npos = ((flags & ROLE_READOUT) && a.out_pos) ? ne : 0;
-    const int64_t nneg = ((flags & ROLE_READOUT) && a.out_neg) ? ne : 0;
+    const int64_t npos = ((flags & ROLE_READOUT) && (flags & STEP_HAS_POS)) ? ne : 0;
+    const int64_t nneg = ((flags & ROLE_READOUT) && (flags & STEP_HAS_NEG)) ? ne : 0;
     // (a shared-src unit per edge -- gram_shared -- was measured here: it halves the readout waves but doubles each
     // wave's VALU chain: C1 +30 %, C2 +5 % slower, C3/C5 +1 % faster; the pair stays the unit)
     const int64_t npairs = npos + nneg;
@@ -75,7 +77,6 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     // narrow rows: an item takes 16 lanes = ISL group slots of the work index space (update_item_narrow)
     constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
     const int64_t total = RP + cap_items * ISL;
-    const Item* items = p.light + 2 * e0;
     const int64_t nblk = (int64_t)gridDim.x - HEAVY_BLOCKS;
 
     // STEP_ITEMS_FIRST (large batches): the light items lead the work index space instead of trailing it.  An item is a
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
                 const int64_t idx = both ? (w >> 1) : (w < npos ? w : w - npos);
                 const bool isneg = both ? (w & 1) != 0 : (w >= npos);
                 e = e0 + idx;
-                v = isneg ? a_neg[e] : a_dst[e];
                 a_dst_pair = !isneg;
                 out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
+                v = isneg ? a_neg[e] : a_dst[e];
                 u = a_src[e];
             }
             // edge-fused update: the (src,dst) pair of an edge also writes the bundles of those endpoints whose only
@@ -211,13 +212,16 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
         static const char* if_env = getenv("TPNET_DEV_ITEMS_FIRST");        // developer override: "0" / "1"
         const bool items_first = FUSE && (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 2500);
-        const uint32_t kflags = flags | (items_first ? STEP_ITEMS_FIRST : 0u);
+        const uint32_t kflags = flags | (items_first ? STEP_ITEMS_FIRST : 0u) | (a.out_pos ? STEP_HAS_POS : 0u) |
+                                (a.out_neg ? STEP_HAS_NEG : 0u);
+        const Item* light0 = p.light + 2 * (b * batch);
+        const Item* heavy0 = p.heavy + 2 * (b * batch);
         if (nt_state)
             hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, NT_GEOM, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
-                               a.neg, b * batch, ne, kflags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
+                               a.neg, light0, heavy0, (uint32_t)(b * batch), ne, kflags, HEAVY_BLOCKS, launch_id, lambda, st, a, p, b);
         else
             hipLaunchKernelGGL((k_step<LPP, VPL, W, L, FULL, false, BS, FUSE>), dim3(grid), dim3(BS), 0, s, a.src, a.dst,
-                               a.neg, b * batch, ne, kflags, launch_id, HEAVY_BLOCKS, lambda, st, a, p, b);
+                               a.neg, light0, heavy0, (uint32_t)(b * batch), ne, kflags, HEAVY_BLOCKS, launch_id, lambda, st, a, p, b);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;

@@ -148,6 +148,8 @@ static constexpr uint32_t ROLE_READOUT = 1u << 16;
 static constexpr uint32_t ROLE_UPDATE = 1u << 17;
 static constexpr uint32_t STEP_FUSE = 1u << 18;     // launch_step: the plan was built with PLAN_FUSE and this launch has both roles
 static constexpr uint32_t STEP_ITEMS_FIRST = 1u << 20;   // launch_step -> k_step: light items lead the work index space
+static constexpr uint32_t STEP_HAS_POS = 1u << 21;   // launch_step -> k_step: out_pos / out_neg exist (decides the roles from
+static constexpr uint32_t STEP_HAS_NEG = 1u << 22;   // preloaded kernel arguments alone)
 static constexpr uint32_t PLAN_FUSE = 1u << 19;     // plan_build: divert single-contribution targets to the edge-fused path
 
 extern thread_local int g_last_hip_error;
