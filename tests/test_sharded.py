@@ -316,3 +316,21 @@ def test_column_sharded_stream_equals_single_gpu(cfg):
     # the ranks' own draws of P[0] are independent and scaled for the FULL width
     assert not np.array_equal(p0s[0], p0s[1])
     assert abs(np.std(np.concatenate([p0s[0], p0s[1]])) * np.sqrt(cfg[1]) - 1.0) < 0.05
+
+
+@pytest.mark.parametrize("E,B,kw", [(8_000_000, 2000, {}), (4_100_000, 1000, {}), (7, 3, {}), (530, 64, {"chunk_steps": 3}),
+                                    (1, 1, {}), (2_000_001, 1000, {}), (130_000, 1000, {"chunk_edges": 50_000}),
+                                    (999, 1000, {}), (64 * 2000, 2000, {"chunk_edges": 10**9})])
+def test_column_runner_chunk_bounds_properties(E, B, kw):
+    """Chunks tile [0, E) in order, every chunk but the last is a whole number of batches, and without an explicit
+    chunk_steps the tail is split so that the last collective (which nothing can hide) covers < 2 * 64 batches."""
+    from tpnet_amd.sharded import ColumnShardedRunner
+    bounds = ColumnShardedRunner.chunk_bounds(E, B, **kw)
+    assert bounds[0][0] == 0 and bounds[-1][1] == E
+    for (a, b), (c, d) in zip(bounds, bounds[1:]):
+        assert b == c and a < b
+    for a, b in bounds[:-1]:
+        assert a % B == 0 and (b - a) % B == 0
+    if "chunk_steps" not in kw:
+        a, b = bounds[-1]
+        assert (b - a + B - 1) // B < 2 * 64
