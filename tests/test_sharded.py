@@ -219,18 +219,18 @@ def _col_cpu_worker(rank, world, port, E, B, chunk_steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("E,B,chunk_steps", [(530, 64, 3), (96, 16, 2), (7, 3, 1)])
-def test_column_runner_merge_logic_gloo_world2(E, B, chunk_steps):
+@pytest.mark.parametrize("E,B,chunk_steps,world", [(530, 64, 3, 2), (96, 16, 2, 2), (7, 3, 1, 2), (531, 64, 3, 3)])
+def test_column_runner_merge_logic_gloo(E, B, chunk_steps, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_col_cpu_worker, args=(r, 2, port, E, B, chunk_steps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_col_cpu_worker, args=(r, world, port, E, B, chunk_steps, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def _col_gpu_worker(rank, world, port, cfg, q):
