@@ -38,8 +38,8 @@ static constexpr int BLOCK = TPNET_BLOCK;   // threads per workgroup of the step
 // Workgroups of 256 threads for everything that is many passes deep (large batches, long pair lists): with 146-175 VGPRs a
 // CU holds 8-12 waves, i.e. ONE 512-thread workgroup, whose slots only free up when its slowest wave is done (measured mean
 // occupancy at C3: 4.2 of 8 waves per CU); two 256-thread workgroups refill independently (C3 49 -> 37 us per batch,
-// C5 -6 %, C1 -9 %).  A batch that fits one pass of 512-thread workgroups (500..2500 edges) keeps them: fewer workgroups
-// to dispatch, 6 % faster at C2.
+// C5 -6 %, C1 -9 %).  A batch that fits ONE pass of 512-thread workgroups (400..1024 edges) keeps them: fewer
+// workgroups to dispatch, 6 % faster at C2.
 #ifndef TPNET_BLOCK_SMALL
 #define TPNET_BLOCK_SMALL 256
 #endif
@@ -57,7 +57,7 @@ static constexpr int BLOCK_SMALL = TPNET_BLOCK_SMALL;
 constexpr int min_waves_per_simd(int lpp, int vpl, int w) {
     return (w != 4) ? 2 : (lpp < 16) ? 4 : (lpp == 16 && vpl == 1) ? TPNET_MINW16 : (lpp == 32 && vpl == 1) ? TPNET_MINW32 : 2;
 }
-static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_MEDIUM = 64, HEAVY_BLOCKS_LARGE = 128;
+static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_LARGE = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
 // helpers

@@ -192,7 +192,7 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
         static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL, false, BS, FUSE>, BS);
         static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
-        const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : ne <= 2048 ? HEAVY_BLOCKS_MEDIUM : HEAVY_BLOCKS_LARGE);
+        const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : HEAVY_BLOCKS_LARGE);
         // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
         // chain of dependent memory round trips, so every workgroup should be resident at once (a workgroup that
         // starts after another one has finished doubles the chain) -- the item slots give way first (a batch
