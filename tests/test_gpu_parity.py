@@ -606,16 +606,16 @@ def test_packed_readout_unpacks_to_the_full_features(d, L, N, B):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# edge-fused updates (batches > 2500 edges: a target's lone contribution is applied by its edge's readout group)
+# edge-fused updates (batches > 1024 edges: a target's lone contribution is applied by its edge's readout group)
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,L,N", [(64, 3, 6000), (128, 2, 3000), (256, 3, 9000), (16, 3, 5000), (36, 1, 4000),
-                                   (512, 4, 3000), (128, 4, 5000)])
-def test_large_batches_with_edge_fused_updates_match_oracle(d, L, N):
-    """B = 2600 on a sparse graph: most targets have exactly one contribution per batch and take the fused path, hubs
+@pytest.mark.parametrize("d,L,N,B", [(64, 3, 6000, 2600), (128, 2, 3000, 2600), (256, 3, 9000, 2600), (16, 3, 5000, 2600),
+                                     (36, 1, 4000, 2600), (512, 4, 3000, 2600), (128, 4, 5000, 2600),
+                                     (128, 3, 2500, 1100), (64, 3, 1500, 1025)])
+def test_large_batches_with_edge_fused_updates_match_oracle(d, L, N, B):
+    """B > 1024 on a sparse graph: most targets have exactly one contribution per batch and take the fused path, hubs
     and duplicates stay on the item lists; features and state must still equal the oracle's."""
     _need_gpu()
     rng = np.random.RandomState(d + N)
-    B = 2600
     E = 2 * B + 700                                           # ragged third batch (below the threshold: unfused)
     src = rng.randint(1, N, E).astype(np.int64)
     dst = rng.randint(1, N, E).astype(np.int64)

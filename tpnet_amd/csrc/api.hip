@@ -62,7 +62,7 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
         static const int role_mask0 = env_int("TPNET_DEV_ROLE_MASK", 3);
         const bool fuse = out_pos && p.fuse_src && role_mask0 == 3 &&
                           !(flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL)) &&
-                          (fuse_env >= 0 ? fuse_env == 1 : batch > 2500);
+                          (fuse_env >= 0 ? fuse_env == 1 : batch > 1024);
         // the clock before a later chunk is t[c0-1], read on device (no host copy of the timestamps is needed)
         rc = plan_build(st, p, src + c0, dst + c0, t + c0, Ec, batch, now_time, c0 > 0 ? t + c0 - 1 : nullptr, lambda,
                         flags | (fuse ? PLAN_FUSE : 0u), s);

@@ -12,7 +12,7 @@ extern template int launch_step_bs<BLOCK_SMALL, true>(TPNET_STEP_ARGS);
 
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s) {
-    // a launch of a fused plan (STEP_FUSE: api.hip turns it on for batches > 2500 edges) takes the variant that carries
+    // a launch of a fused plan (STEP_FUSE: api.hip turns it on for batches > 1024 edges) takes the variant that carries
     // the edge-fused update path
     if (flags & STEP_FUSE) return launch_step_bs<BLOCK_SMALL, true>(st, a, p, b, batch, ne, lambda, launch_id, flags, s);
     // 512-thread workgroups for a batch that is ONE pass of them -- 256 resident workgroups hold the pairs, the items and

@@ -1,5 +1,5 @@
 // gfx950 fused per-batch step: the 256-thread instantiation of step_impl.hpp WITH the edge-fused update path (plans of
-// batches > 2500 edges: a target's lone contribution is applied by its edge's readout group).
+// batches > 1024 edges: a target's lone contribution is applied by its edge's readout group).
 #include "step_impl.hpp"
 
 namespace tpnet {

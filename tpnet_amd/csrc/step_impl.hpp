@@ -211,7 +211,7 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         constexpr bool NT_GEOM = BS == BLOCK && W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
         const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
         static const char* if_env = getenv("TPNET_DEV_ITEMS_FIRST");        // developer override: "0" / "1"
-        const bool items_first = FUSE && (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 2500);
+        const bool items_first = FUSE && (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 1024);
         const uint32_t kflags = flags | (items_first ? STEP_ITEMS_FIRST : 0u) | (a.out_pos ? STEP_HAS_POS : 0u) |
                                 (a.out_neg ? STEP_HAS_NEG : 0u);
         const Item* light0 = p.light + 2 * (b * batch);
