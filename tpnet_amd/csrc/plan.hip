@@ -43,17 +43,20 @@ static bool use_segmented_sort(int64_t batch, size_t nc) {
 }
 
 static size_t sort_tmp_bytes(size_t n, int64_t batch) {
-    size_t bytes = 0, bytes_seg = 0;
-    uint64_t* kn = nullptr;
+    size_t bytes = 0, bytes32 = 0, bytes_seg = 0;
+    uint64_t* kn64 = nullptr;
+    uint32_t* kn = nullptr;
     uint32_t* vn = nullptr;
-    // size queries only: no kernel is launched
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, n, 0, 64, (hipStream_t)0, false);
+    // size queries only: no kernel is launched (keys are 32-bit whenever (batch, node) fits, else 64-bit: plan_build)
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, kn64, kn64, vn, vn, n, 0, 64, (hipStream_t)0, false);
+    (void)rocprim::radix_sort_pairs(nullptr, bytes32, kn, kn, vn, vn, n, 0, 32, (hipStream_t)0, false);
+    if (bytes32 > bytes) bytes = bytes32;
     if (n < (1ull << 32)) {
         const unsigned nseg = (unsigned)((n + 2 * (size_t)batch - 1) / (2 * (size_t)batch));
         auto cnt = rocprim::counting_iterator<unsigned>(0);
         auto b = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)n, 0u});
         auto e = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)n, 1u});
-        (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes_seg, kn, kn, vn, vn, (unsigned)n, nseg, b, e, 0u, 64u,
+        (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes_seg, kn, kn, vn, vn, (unsigned)n, nseg, b, e, 0u, 32u,
                                                   (hipStream_t)0, false);
     }
     return bytes > bytes_seg ? bytes : bytes_seg;
@@ -148,9 +151,12 @@ __device__ __forceinline__ void decode(int64_t j, int64_t B, int64_t Ec, int64_t
     e = e0 + (side ? r - ne : r);
 }
 
-__global__ void k_make_keys(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+// K = uint32_t whenever the key fits: the node alone for the segmented sort (the batch is the segment), (batch, node) in
+// 32 bits for the device-wide sort of short chunks; uint64_t otherwise.  Half the key bytes through the sort.
+template <typename K>
+__global__ void k_make_keys(K* __restrict__ keys, uint32_t* __restrict__ vals,
                             const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t Ec, int64_t B,
-                            int64_t N, int node_bits, uint32_t* err) {
+                            int64_t N, int node_bits, int with_batch, uint32_t* err) {
     const int64_t nc = 2 * Ec;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
         int64_t b, e;
@@ -158,7 +164,7 @@ __global__ void k_make_keys(uint64_t* __restrict__ keys, uint32_t* __restrict__ 
         decode(j, B, Ec, b, side, e);
         int64_t tgt = side ? dst[e] : src[e];
         if ((uint64_t)tgt >= (uint64_t)N) tgt = 0;  // counted (once per edge) in k_finish
-        keys[j] = ((uint64_t)b << node_bits) | (uint64_t)tgt;
+        keys[j] = with_batch ? (K)(((uint64_t)b << node_bits) | (uint64_t)tgt) : (K)tgt;
         vals[j] = (uint32_t)j;
     }
 }
@@ -202,9 +208,10 @@ __device__ __forceinline__ uint32_t agg_append(BatchDesc* __restrict__ desc, int
     return idx;
 }
 
-__global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
-                         const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N, int node_bits, double lambda,
-                         uint32_t heavy_threshold, int fuse, uint32_t* err) {
+template <typename K>
+__global__ void k_finish(Plan p, const K* __restrict__ keys_out, const int64_t* __restrict__ src,
+                         const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N,
+                         int node_bits, double lambda, uint32_t heavy_threshold, int fuse, uint32_t* err) {
     const int64_t nc = 2 * Ec;
     const uint64_t node_mask = (1ull << node_bits) - 1;
     for (int64_t jb = (int64_t)blockIdx.x * blockDim.x; jb < nc; jb += (int64_t)gridDim.x * blockDim.x) {
@@ -215,9 +222,9 @@ __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t*
         Item it;
         it.j0 = 0; it.cnt = 0; it.target = 0; it.p0 = 0; it.w0 = 0.f; it.p1 = 0; it.w1 = 0.f; it.pad = 0;
         if (active) {
-            const uint64_t key = p.keys_out[j];
+            const K key = keys_out[j];
             const uint32_t val = p.vals_out[j];
-            b = (int64_t)(key >> node_bits);
+            b = j / (2 * B);                            // a batch's contributions stay in its range of positions
             int32_t partner;
             float w;
             contribution(p, src, dst, t, Ec, B, N, lambda, val, partner, w, err);
@@ -228,20 +235,20 @@ __global__ void k_finish(Plan p, const int64_t* __restrict__ src, const int64_t*
             c0 = 2 * b * B;
             const int64_t ne = (Ec - b * B < B) ? (Ec - b * B) : B;
             const int64_t cend = c0 + 2 * ne;
-            head = (j == c0) || (p.keys_out[j - 1] != key);
+            head = (j == c0) || (keys_out[j - 1] != key);
             if (head) {
                 // run length by galloping + binary search on the sorted keys
                 int64_t lo = j, hi, step = 1;
                 for (;;) {
                     const int64_t nx = lo + step;
                     if (nx >= cend) { hi = cend; break; }
-                    if (p.keys_out[nx] != key) { hi = nx; break; }
+                    if (keys_out[nx] != key) { hi = nx; break; }
                     lo = nx;
                     step <<= 1;
                 }
                 while (hi - lo > 1) {
                     const int64_t mid = (lo + hi) >> 1;
-                    if (p.keys_out[mid] == key) lo = mid; else hi = mid;
+                    if (keys_out[mid] == key) lo = mid; else hi = mid;
                 }
                 it.j0 = (uint32_t)j;
                 it.cnt = (uint32_t)(hi - j);
@@ -284,17 +291,28 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
                        now_time, t_prev_dev, lambda, (int)st.L);
     int grid = (int)((nc + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_make_keys, dim3(grid), dim3(256), 0, s, p.keys_in, p.vals_in, src, dst, Ec, batch, st.N,
-                       node_bits, st.err);
+    const bool seg = use_segmented_sort(batch, (size_t)nc);
+    const bool narrow = seg || node_bits + batch_bits <= 32;
+    uint32_t* k32_in = reinterpret_cast<uint32_t*>(p.keys_in);
+    uint32_t* k32_out = reinterpret_cast<uint32_t*>(p.keys_out);
+    if (narrow)
+        hipLaunchKernelGGL(k_make_keys<uint32_t>, dim3(grid), dim3(256), 0, s, k32_in, p.vals_in, src, dst, Ec, batch,
+                           st.N, node_bits, seg ? 0 : 1, st.err);
+    else
+        hipLaunchKernelGGL(k_make_keys<uint64_t>, dim3(grid), dim3(256), 0, s, p.keys_in, p.vals_in, src, dst, Ec, batch,
+                           st.N, node_bits, 1, st.err);
     TPNET_HIP_TRY(hipGetLastError());
     size_t tmp = p.sort_tmp_bytes;
-    if (use_segmented_sort(batch, (size_t)nc)) {
+    if (seg) {
         const unsigned nseg = (unsigned)((nc + 2 * batch - 1) / (2 * batch));
         auto cnt = rocprim::counting_iterator<unsigned>(0);
         auto sb = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)nc, 0u});
         auto se = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)(2 * batch), (unsigned)nc, 1u});
-        TPNET_HIP_TRY(rocprim::segmented_radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
+        TPNET_HIP_TRY(rocprim::segmented_radix_sort_pairs(p.sort_tmp, tmp, k32_in, k32_out, p.vals_in, p.vals_out,
                                                           (unsigned)nc, nseg, sb, se, 0u, (unsigned)node_bits, s, false));
+    } else if (narrow) {
+        TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, k32_in, k32_out, p.vals_in, p.vals_out, (size_t)nc, 0u,
+                                                (unsigned)(node_bits + batch_bits), s, false));
     } else {
         TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.sort_tmp, tmp, p.keys_in, p.keys_out, p.vals_in, p.vals_out,
                                                 (size_t)nc, 0u, (unsigned)(node_bits + batch_bits), s, false));
@@ -310,8 +328,12 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     if (flags & TPNET_FLAG_SEQUENTIAL) thr = 0xFFFFFFFFu;
     const int fuse = ((flags & PLAN_FUSE) && p.fuse_src) ? 1 : 0;
     if (fuse) TPNET_HIP_TRY(hipMemsetAsync(p.fuse_src, 0, 2 * (size_t)Ec, s));   // after the sort: the bytes were keys_in
-    hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, s, p, src, dst, t, Ec, batch, st.N, node_bits, lambda, thr,
-                       fuse, st.err);
+    if (narrow)
+        hipLaunchKernelGGL(k_finish<uint32_t>, dim3(grid), dim3(256), 0, s, p, k32_out, src, dst, t, Ec, batch, st.N,
+                           node_bits, lambda, thr, fuse, st.err);
+    else
+        hipLaunchKernelGGL(k_finish<uint64_t>, dim3(grid), dim3(256), 0, s, p, p.keys_out, src, dst, t, Ec, batch, st.N,
+                           node_bits, lambda, thr, fuse, st.err);
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }
