@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 2 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, TPNET_FLAG_PACKED */
+#define TPNET_ABI_VERSION 2 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -198,6 +198,17 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
  * k' = 16 s + 8 h + j  <-  k = 16 s + 8 (j>>2) + 4 h + (j&3)   (s in 0..1, h in 0..1, j in 0..7). */
 int tpnet_mlp64_bf16(const float* x, int64_t n, const void* w1_bf16, const float* b1, const void* w2p_bf16,
                      const float* b2, float* y, void* stream);
+
+/* LinkPredictor_v1 (models/modules.py:73-117): out[p] = fc2(relu(fc1(concat[src_emb[p], dst_emb[p], feat[p]]))) with ONE
+ * output unit, both layers in one bf16 matrix-core kernel (fp32 accumulate); neither the concatenation nor the hidden
+ * layer touches memory.  src_emb, dst_emb: device f32 [n][D] (D % 4 == 0; both NULL = the reference's not_encode mode,
+ * zeros); feat: device f32 [n][F] (F % 16 == 0; NULL if the decoder has no pairwise feature).  w1p: bf16
+ * [32*hidden_tiles][2*DP + F], DP = 16*ceil(D/16): fc1.weight with its input axis laid out [src | pad | dst | pad | feat]
+ * and zero rows beyond the hidden width; b1p, w2p: f32 [32*hidden_tiles] (fc1.bias, fc2.weight[0], zero-padded); b2 =
+ * fc2.bias[0].  hidden_tiles in 1..8 (hidden width <= 256).  out: device f32 [n]. */
+int tpnet_decoder_bf16(const float* src_emb, const float* dst_emb, int32_t D, const float* feat, int32_t F, int64_t n,
+                       const void* w1p_bf16, const float* b1p, const float* w2p, float b2, int32_t hidden_tiles,
+                       float* out, void* stream);
 
 /* The readout's element-wise tail, in place on x[n]: x<0 -> 0, then log(x + 1) (models/TPNet.py:126-128).  For callers
  * that ran the readout with TPNET_FLAG_NOT_SCALE because the raw Gram entries still had to be summed across GPUs

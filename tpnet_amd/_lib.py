@@ -61,6 +61,7 @@ SIGNATURES = {
     "tpnet_sample_recent": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "tpnet_mlp64_bf16": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "tpnet_gather_elems": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
+    "tpnet_decoder_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_float, C.c_int32, _P, _P]),
     "tpnet_gram_finish": (C.c_int, [_P, C.c_int64, _P]),
     "tpnet_gram_unpack": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_uint32, _P, _P]),
     "tpnet_check_errors": (C.c_int, [_SP, _P]),

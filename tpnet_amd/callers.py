@@ -31,16 +31,23 @@ class LinkPredictor_v1(nn.Module):
         self.fc1 = nn.Linear(input_dim1 + input_dim2 + self.random_feature_dim, hidden_dim)
         self.fc2 = nn.Linear(hidden_dim, output_dim)
         self.act = nn.ReLU()
+        self.fused = False      # opt-in: both layers in one bf16 matrix-core kernel (tpnet_amd/fused_decoder.py)
 
     def forward(self, src_node_ids: np.ndarray, dst_node_ids: np.ndarray, src_node_embeddings: torch.Tensor,
                 dst_node_embeddings: torch.Tensor):
         if self.not_encode:                                        # modules.py:106-108
             src_node_embeddings = torch.zeros_like(src_node_embeddings)
             dst_node_embeddings = torch.zeros_like(dst_node_embeddings)
-        parts = [src_node_embeddings, dst_node_embeddings]
+        feat = None
         if self.random_projections is not None:                    # modules.py:112-114
-            parts.append(self.random_projections.get_pair_wise_feature(src_node_ids=src_node_ids,
-                                                                       dst_node_ids=dst_node_ids))
+            feat = self.random_projections.get_pair_wise_feature(src_node_ids=src_node_ids, dst_node_ids=dst_node_ids)
+        if self.fused and src_node_embeddings.is_cuda:
+            from . import fused_decoder as fd
+            D, F = src_node_embeddings.shape[1], (0 if feat is None else feat.shape[1])
+            if dst_node_embeddings.shape[1] == D and fd.supported(self.fc1, self.fc2, D, F):
+                return fd.fused_decoder(self, self.fc1, self.fc2, src_node_embeddings, dst_node_embeddings, feat,
+                                        self.not_encode)
+        parts = [src_node_embeddings, dst_node_embeddings] + ([feat] if feat is not None else [])
         return self.fc2(self.act(self.fc1(torch.cat(parts, dim=1))))
 
 
