@@ -644,3 +644,25 @@ def test_large_batches_with_edge_fused_updates_match_oracle(d, L, N, B):
     # associate differently)
     _assert_state(_layers(rp2), _layers(rp), 1e-5, "update-only vs fused")
 
+
+
+@pytest.mark.parametrize("d,B,N", [(64, 1500, 2000), (128, 3000, 1200), (32, 1100, 5000)])
+def test_module_api_with_batches_above_1024_edges(d, B, N):
+    """update() / get_pair_wise_feature() with batches of more than 1024 edges: the update-only launch takes the 256-thread
+    step kernel with 128 hub workgroups (no readout in the launch: nothing is diverted to the edge-fused path)."""
+    _need_gpu()
+    rng = np.random.RandomState(d + B)
+    L, lam = 3, 2e-6
+    E = 3 * B
+    src, dst, neg, t = _random_stream(rng, N, E, 3.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    rp = _module(N, d, L, lam, t[0], P0=P0)
+    rp.mlp = torch.nn.Identity()
+    st = O.OracleState(P0, L, lam, t[0])
+    for b in range(3):
+        s = slice(b * B, (b + 1) * B)
+        f = rp.get_pair_wise_feature(src[s], neg[s]).cpu().numpy()
+        _assert_features(f, st, src[s], neg[s], f"batch {b}")
+        rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "final state")
+    rp.check_device_errors()
