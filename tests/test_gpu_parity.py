@@ -666,3 +666,108 @@ def test_module_api_with_batches_above_1024_edges(d, B, N):
         rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
     _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "final state")
     rp.check_device_errors()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json config C4: the 10 M-node table (d=256: 10 GB per layer, 72 GB of engine state), power-law stream
+# S(5 000 000, 5 000 000, E, ...).  The numpy oracle cannot hold a 10 M x 256 x 4 table, but rows are independent:
+# the touched node ids are relabelled to a dense range and the oracle runs on the compact graph with the gathered
+# P[0] rows; every readout and the touched rows of the final state of the REAL 10 M-row module are compared.
+# ---------------------------------------------------------------------------------------------------------
+def _c4_module(N, d, lam):
+    """The 10 M-row module built directly on the GPU (the reference builds it on the host and moves it: 41 GB of
+    host memory that the test box need not have), P[0] ~ N(0, 1/sqrt(d)) from the device generator."""
+    from tpnet_amd import RandomProjectionModule
+    torch.manual_seed(0)
+    rp = RandomProjectionModule(node_num=N, edge_num=200_000_000, dim_factor=10, num_layer=3, time_decay_weight=lam,
+                                device=DEV, use_matrix=False, beginning_time=np.float64(0.0), not_scale=False,
+                                enforce_dim=d, alloc_device=DEV).to(DEV)
+    assert rp.random_projections[0].device.type == "cuda" and rp.random_projections[0].shape == (N, d)
+    return rp
+
+
+def _compact(touched, *arrays):
+    return [np.searchsorted(touched, a).astype(np.int64) for a in arrays]
+
+
+def test_c4_ten_million_rows_against_compact_oracle():
+    """C4 (10 000 001 rows, d=256, lambda=1e-7): 8 batches of 10 000 edges + a ragged tail, then ONE call with batches of
+    100 000 edges (one full + a ragged one) on the same state.  Exercises the 64-bit row offsets
+    ((copy*N + node) * L*d floats: up to 1.5e10), 24-bit node keys in the plan, the edge-fused update path at this
+    sparsity (almost every target has a single contribution per batch) and HBM-miss-bound gathers."""
+    _need_gpu()
+    from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+    c = CONFIGS["C4"]
+    N, d, lam = c["U"] + c["I"] + 1, c["d"], c["lam"]
+    assert N == 10_000_001 and d == 256
+    B1, E1 = 10_000, 8 * 10_000 + 3_000
+    B2, E2 = 100_000, 100_000 + 20_000
+    E = E1 + E2
+    src, dst, t, N_ = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
+    assert N_ == N
+    neg = np.concatenate([synthetic_negatives(c["U"], N, E1, B1, 1), synthetic_negatives(c["U"], N, E2, B2, 2)])
+    rp = _c4_module(N, d, lam)
+    touched = np.unique(np.concatenate([[0], src, dst, neg]))
+    assert touched[-1] > 9_000_000 and len(touched) > 300_000          # ids really span the whole table
+    P0c = rp.random_projections[0][torch.from_numpy(touched).to(DEV)].cpu().numpy()
+    st = O.OracleState(P0c, 3, lam, 0.0)
+    cs, cd, cn = _compact(touched, src, dst, neg)
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    worst = 0.0
+    for (a, b, B) in ((0, E1, B1), (E1, E, B2)):
+        fp, fn = rp.run_stream(dev(src[a:b]), dev(dst[a:b]), dev(neg[a:b]), dev(t[a:b]), B, t_end=float(t[b - 1]))
+        fp = fp.cpu().numpy(); fn = fn.cpu().numpy()
+        for o in range(a, b, B):
+            s = slice(o, min(o + B, b))
+            for q in range(s.start, s.stop, 20_000):                      # (slices bound the oracle's [n, 8, d] temporaries)
+                s2 = slice(q, min(q + 20_000, s.stop))
+                r2 = slice(s2.start - a, s2.stop - a)
+                worst = max(worst, _assert_features(fp[r2], st, cs[s2], cd[s2], f"C4 pos batch at {o} (B={B})"))
+                worst = max(worst, _assert_features(fn[r2], st, cs[s2], cn[s2], f"C4 neg batch at {o} (B={B})"))
+            O.update(st, cs[s], cd[s], t[s])
+    rp.check_device_errors()
+    # touched rows of the final state, through the row gather (no 30 GB materialisation), all layers incl. layer 0
+    rows = rp.get_random_projections(touched)
+    got = np.stack([r.cpu().numpy() for r in rows])
+    np.testing.assert_array_equal(got[0], P0c)
+    _assert_state(got[1:], np.stack(st.P[1:]), 1e-4, "C4 touched rows")
+    assert float(np.abs(got[3]).max()) > 0                              # three-hop walks exist: layer 3 is populated
+    # untouched rows stayed zero (a sample next to touched ids and at the far end of the table)
+    cand = np.unique(np.concatenate([touched[:2000] + 1, touched[-2000:] - 1, [N - 1, N - 2, 1]]))
+    untouched = cand[(cand > 0) & (cand < N) & ~np.isin(cand, touched)]
+    z = rp.get_random_projections(untouched)
+    assert all(float(r.abs().max()) == 0.0 for r in z[1:])
+    assert float(rp.now_time.item()) == float(t[-1])
+    print(f"C4: {len(touched)} touched rows of {N}, worst |feature delta| = {worst:.3e}")
+
+
+def test_c4_wide_keys_chunked_equals_unchunked():
+    """10 M rows with MANY batches in one plan: 24 node bits + 10 batch bits exceed 32, so the plan sorts 64-bit
+    (batch, node) keys; the same stream cut into three calls (each plan then fits 32-bit keys) must give the same
+    features and the same touched rows -- the two key widths are two sorts of the same contributions -- and a second
+    one-call run must reproduce the first bit for bit."""
+    _need_gpu()
+    from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+    c = CONFIGS["C4"]
+    N, d, lam = c["U"] + c["I"] + 1, 64, c["lam"]                         # narrow rows: the keys are what is under test
+    B, nb = 4_500, 600                                                    # 2B > 8192: device-wide sort, 600 batches: 10 bits
+    E = nb * B - 777
+    src, dst, t, _ = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 3)
+    neg = synthetic_negatives(c["U"], N, E, B, 4)
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    touched = torch.unique(torch.cat([ds, dd, dn]))
+    outs = []
+    for cuts in ((0, E), (0, E), (0, 200 * B, 410 * B, E)):
+        rp = _c4_module(N, d, lam)
+        fps, fns = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            fp, fn = rp.run_stream(ds[a:b], dd[a:b], dn[a:b], dt[a:b], B, t_end=float(t[b - 1]))
+            fps.append(fp); fns.append(fn)
+        rp.check_device_errors()
+        rows = torch.stack(rp.get_random_projections(touched)[1:])
+        outs.append((torch.cat(fps), torch.cat(fns), rows))
+        del rp
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]) and torch.equal(outs[0][2], outs[2][2])
+    assert float(outs[0][2][2].abs().max()) > 0

@@ -29,10 +29,13 @@ _MAX_LAUNCH_ID = 0x7FFFFFFF - (1 << 24)
 class RandomProjectionModule(nn.Module):
     def __init__(self, node_num: int, edge_num: int, dim_factor: int, num_layer: int, time_decay_weight: float,
                  device: str, use_matrix: bool, beginning_time: np.float64, not_scale: bool, enforce_dim: int,
-                 exact: bool = False):
+                 exact: bool = False, alloc_device=None):
         """Arguments as in the reference (models/TPNet.py:10-26).  `exact=True` (extension, default off) selects
         the reference's literal arithmetic: an eager dense decay of every row per update (TPNet.py:83-85) and
-        strictly index-ordered sums -- used by the parity tests; the default carries the decay lazily per row."""
+        strictly index-ordered sums -- used by the parity tests; the default carries the decay lazily per row.
+        `alloc_device` (extension, default None = the host, like the reference, whose callers then move the module:
+        utils/utils.py:43) builds the tables directly on that device: a 10 M-node table is 41 GB that need not pass
+        through host memory; P[0] is then drawn from that device's generator."""
         super().__init__()
         if not 1 <= num_layer <= _lib.TPNET_MAX_LAYERS:
             raise ValueError(f"num_layer must be in 1..{_lib.TPNET_MAX_LAYERS} (got {num_layer})")
@@ -57,7 +60,8 @@ class RandomProjectionModule(nn.Module):
             self.dim = self.node_num
             for i in range(self.num_layer + 1):
                 if i == 0:
-                    self.random_projections.append(nn.Parameter(torch.eye(self.node_num), requires_grad=False))
+                    self.random_projections.append(nn.Parameter(torch.eye(self.node_num, device=alloc_device),
+                                                                requires_grad=False))
                 else:
                     self.random_projections.append(
                         nn.Parameter(torch.zeros_like(self.random_projections[i - 1]), requires_grad=False))
@@ -65,8 +69,8 @@ class RandomProjectionModule(nn.Module):
             for i in range(self.num_layer + 1):
                 if i == 0:
                     self.random_projections.append(
-                        nn.Parameter(torch.normal(0, 1 / math.sqrt(self.dim), (self.node_num, self.dim)),
-                                     requires_grad=False))
+                        nn.Parameter(torch.normal(0, 1 / math.sqrt(self.dim), (self.node_num, self.dim),
+                                                  device=alloc_device), requires_grad=False))
                 else:
                     self.random_projections.append(
                         nn.Parameter(torch.zeros_like(self.random_projections[i - 1]), requires_grad=False))
