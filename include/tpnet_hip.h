@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 2 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED */
+#define TPNET_ABI_VERSION 3 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
+                               3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -126,6 +127,13 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
 
 /* Workspace for tpnet_update / tpnet_run_stream with at most max_edges edges per call. */
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
+
+/* Workspace for tpnet_run_stream on a table of N rows x d columns x L layers: the larger of tpnet_workspace_bytes and
+ * what the WINDOWED schedule needs (plan + the version log of one window of batches).  With at least this much
+ * tpnet_run_stream runs a stream of small batches as L+1 launches per window of up to 64 batches (one launch per layer
+ * of the update, one for all readouts) instead of one launch per batch; with less it falls back to per-batch launches.
+ * Results do not depend on which schedule ran beyond f32 summation order (both within 1e-4 of the reference). */
+size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch);
 
 /* update (models/TPNet.py:67-99) for one batch: src, dst device int64[B], t device double[B] (absolute times,
  * chronological; t[B-1] is the new now_time).  now_time = the module's clock before the call; launch_id = a

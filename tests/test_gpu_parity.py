@@ -512,7 +512,8 @@ def test_odd_shapes_fuzz(d, L):
 def test_internal_chunking_with_a_small_workspace():
     """tpnet_run_stream plans the stream in chunks when the caller's workspace cannot hold it at once; the chunked
     run must equal the one-chunk run bit for bit (same launches, same clocks: the chunk's first batch reads the
-    previous chunk's last timestamp on the device)."""
+    previous chunk's last timestamp on the device).  Exact mode: the per-batch schedule (the windowed one has its own
+    test below)."""
     _need_gpu()
     import ctypes as C
     from tpnet_amd import _lib
@@ -523,9 +524,10 @@ def test_internal_chunking_with_a_small_workspace():
     P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
     dev = lambda x: torch.from_numpy(x).to(DEV)
     ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
-    a = _module(N, d, L, 2e-6, t[0], P0=P0)
+    XF = _lib.FLAG_EAGER_DECAY | _lib.FLAG_SEQUENTIAL
+    a = _module(N, d, L, 2e-6, t[0], P0=P0, exact=True)
     fa, na = a.run_stream(ds, dd, dn, dt, B)
-    b = _module(N, d, L, 2e-6, t[0], P0=P0)
+    b = _module(N, d, L, 2e-6, t[0], P0=P0, exact=True)
     b._ensure_engine()
     lib = _lib.load()
     full = lib.tpnet_workspace_bytes(E, B)
@@ -536,7 +538,7 @@ def test_internal_chunking_with_a_small_workspace():
     st = b._state()
     t_end = C.c_double(0.0)
     rc = lib.tpnet_run_stream(C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, float(t[0]),
-                              2e-6, 1, 0, fb.data_ptr(), nb_.data_ptr(), ws.data_ptr(), small, C.byref(t_end),
+                              2e-6, 1, XF, fb.data_ptr(), nb_.data_ptr(), ws.data_ptr(), small, C.byref(t_end),
                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0 and t_end.value == float(t[-1])
     b._now_host = t_end.value
@@ -544,13 +546,13 @@ def test_internal_chunking_with_a_small_workspace():
     assert torch.equal(fa, fb) and torch.equal(na, nb_)
     np.testing.assert_array_equal(_layers(a), _layers(b))
     # packed feature rows through the same chunked path (a chunk's outputs start at c0 * 36 floats, not c0 * 64)
-    c = _module(N, d, L, 2e-6, t[0], P0=P0)
+    c = _module(N, d, L, 2e-6, t[0], P0=P0, exact=True)
     c._ensure_engine()
     NT = c.packed_feature_dim
     pp = torch.empty((E, NT), dtype=torch.float32, device=DEV); pn = torch.empty_like(pp)
     st_c = c._state()
     rc = lib.tpnet_run_stream(C.byref(st_c), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, float(t[0]),
-                              2e-6, 1, _lib.FLAG_PACKED | _lib.FLAG_NOT_SCALE, pp.data_ptr(), pn.data_ptr(), ws.data_ptr(),
+                              2e-6, 1, XF | _lib.FLAG_PACKED | _lib.FLAG_NOT_SCALE, pp.data_ptr(), pn.data_ptr(), ws.data_ptr(),
                               small, None, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     for full_rows, pk in ((fa, pp), (na, pn)):
@@ -563,6 +565,92 @@ def test_internal_chunking_with_a_small_workspace():
                               2e-6, 100, 0, fb.data_ptr(), nb_.data_ptr(), tiny.data_ptr(), 1024, None,
                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == -2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the windowed schedule of tpnet_run_stream (L+1 launches per window of batches)
+# ---------------------------------------------------------------------------------------------------------
+def _raw_run_stream(rp, ds, dd, dn, dt, B, now, lam, ws, flags=0):
+    import ctypes as C
+    from tpnet_amd import _lib
+    E = ds.numel()
+    NG = rp.packed_feature_dim if (flags & _lib.FLAG_PACKED) else rp.pair_wise_feature_dim
+    fp = torch.empty((E, NG), dtype=torch.float32, device=DEV)
+    fn = torch.empty_like(fp)
+    rp._ensure_engine()
+    st = rp._state()
+    t_end = C.c_double(0.0)
+    rc = _lib.load().tpnet_run_stream(C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, now, lam,
+                                      rp._next_launch_ids((E + B - 1) // B), flags, fp.data_ptr(), fn.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), C.byref(t_end), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    rp._now_host = t_end.value
+    rp._params_valid = False
+    return fp, fn
+
+
+@pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 400, 64, 330), (64, 2, 3000, 200, 90), (256, 3, 500, 500, 40),
+                                        (120, 3, 260, 40, 200), (16, 4, 300, 100, 70), (512, 1, 200, 1000, 9)])
+def test_windowed_schedule_is_independent_of_how_the_stream_is_cut(d, L, N, B, nb):
+    """The arithmetic of a (node, batch) run is fixed (blocks of 8 contributions in index order), so the windowed
+    schedule gives the same bits whatever the windows are: one plan for the whole stream, a workspace that holds only two
+    windows per plan, and two separate calls cut at an arbitrary batch.  And it matches the oracle."""
+    _need_gpu()
+    from tpnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(d + B)
+    E = nb * B - B // 3
+    lam = 2e-6
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    a = _module(N, d, L, lam, t[0], P0=P0)
+    fa, na = a.run_stream(ds, dd, dn, dt, B)
+    # (1) against the oracle
+    st = O.OracleState(P0, L, lam, t[0])
+    fa_h, na_h = fa.cpu().numpy(), na.cpu().numpy()
+    for o in range(0, E, B):
+        s = slice(o, min(o + B, E))
+        _assert_features(fa_h[s], st, src[s], dst[s], f"pos batch {o // B}")
+        _assert_features(na_h[s], st, src[s], neg[s], f"neg batch {o // B}")
+        O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(a), np.stack(st.P[1:]), 1e-4, "final state")
+    a.check_device_errors()
+    # (2) a workspace for two windows per plan
+    K = min(64, 16384 // B)
+    full = lib.tpnet_stream_workspace_bytes(N, d, L, E, B)
+    small = lib.tpnet_stream_workspace_bytes(N, d, L, 2 * K * B, B)
+    if small < full:
+        b = _module(N, d, L, lam, t[0], P0=P0)
+        ws = torch.empty(small, dtype=torch.uint8, device=DEV)
+        fb, nb_ = _raw_run_stream(b, ds, dd, dn, dt, B, float(t[0]), lam, ws)
+        assert torch.equal(fa, fb) and torch.equal(na, nb_)
+        np.testing.assert_array_equal(_layers(a), _layers(b))
+    # (3) two calls, cut in the middle of a window
+    c = _module(N, d, L, lam, t[0], P0=P0)
+    cut = (nb // 2 + 1) * B
+    f1, n1 = c.run_stream(ds[:cut], dd[:cut], dn[:cut], dt[:cut], B)
+    f2, n2 = c.run_stream(ds[cut:], dd[cut:], dn[cut:], dt[cut:], B)
+    assert torch.equal(torch.cat([f1, f2]), fa) and torch.equal(torch.cat([n1, n2]), na)
+    np.testing.assert_array_equal(_layers(c), _layers(a))
+    # (4) packed rows and update-only streams through the same schedule
+    e = _module(N, d, L, lam, t[0], P0=P0)
+    pp, pn = e.run_stream(ds, dd, dn, dt, B, packed=True)
+    out = torch.empty_like(fa)
+    _lib.check(lib.tpnet_gram_unpack(pp.data_ptr(), E, L, 0, out.data_ptr(), e._stream()), "gram_unpack")
+    assert torch.equal(out, fa)
+    f = _module(N, d, L, lam, t[0], P0=P0)
+    f.run_stream(ds, dd, None, dt, B, want_pos=False, want_neg=False)
+    np.testing.assert_array_equal(_layers(f), _layers(a))
+    # (5) the per-batch schedule (a workspace without room for a version log) agrees within f32 summation order
+    g = _module(N, d, L, lam, t[0], P0=P0)
+    wsb = torch.empty(lib.tpnet_workspace_bytes(E, B), dtype=torch.uint8, device=DEV)
+    if wsb.numel() < lib.tpnet_stream_workspace_bytes(N, d, L, K * B, B):
+        fg, ng = _raw_run_stream(g, ds, dd, dn, dt, B, float(t[0]), lam, wsb)
+        _assert_state(_layers(g), _layers(a), 1e-5, "per-batch vs windowed")
+        # (features: all but the near-cancelling Gram entries of hub rows, whose f32 error scales with the rows' norms)
+        assert float(((fg - fa).abs() > 1e-4).float().mean()) < 2e-3
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -39,13 +39,92 @@ struct StepTimer {
     hipEvent_t* ev = nullptr;  // one pair per chunk, around its loop of step launches (plan kernels excluded)
     int64_t n = 0, cap = 0;    // pairs recorded / available
     int64_t launches = 0;      // step launches between the recorded pairs
+    int64_t batches = 0;       // batches those launches covered
+    // windowed path: L+2 events per timed window (before the first update launch, after each launch)
+    hipEvent_t* wev = nullptr;
+    int64_t wn = 0, wcap = 0;  // windows recorded / available
+    int64_t wedges = 0;        // edges of the recorded windows
 };
+
+// The windowed path (wstep.hip) serves a stream when its arithmetic contract allows it (no eager decay / strictly
+// sequential sums: those are the per-batch kernels' exact mode), the rows take 16-byte vectors, there are enough batches
+// for a window to pay, and the caller's workspace holds the plan of at least one window.  Returns the chunk (edges per
+// plan: whole windows of K batches, or all of E) and K; 0 = use the per-batch path.
+static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, int64_t batch, uint32_t flags, int* K_out) {
+    if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL)) return 0;
+    const int K = wplan_window_batches(batch, st.d, st.L);
+    const int64_t nb = (E + batch - 1) / batch;
+    if (K == 0 || nb < 4) return 0;
+    *K_out = K;
+    const int64_t Ew = (int64_t)K * batch;
+    const int64_t hard = (((int64_t)1 << 30) / Ew) * Ew;
+    const int64_t lim = (E < hard || hard < Ew) ? E : hard;
+    if (wplan_bytes(lim, batch, st.N, st.d, st.L) <= ws_bytes) return lim;
+    int64_t lo = 0, hi = (lim + Ew - 1) / Ew;       // in windows; lo fits (0), hi does not
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) / 2;
+        if (wplan_bytes(mid * Ew, batch, st.N, st.d, st.L) <= ws_bytes) lo = mid; else hi = mid;
+    }
+    return lo * Ew;
+}
+
+static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                               const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                               uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* ws,
+                               size_t ws_bytes, int64_t chunk, int Kmax, hipStream_t s, StepTimer* timer) {
+    const int NN = 2 * st.L + 2;
+    const int NG = (flags & TPNET_FLAG_PACKED) ? NN * (NN + 1) / 2 : NN * NN;
+    uint32_t lid = launch_id_base;
+    for (int64_t c0 = 0; c0 < E; c0 += chunk) {
+        const int64_t Ec = (E - c0 < chunk) ? (E - c0) : chunk;
+        // windows of equal length: a chunk of nb batches is cut into ceil(nb / Kmax) windows of ceil(nb / that) batches
+        const int64_t nb = (Ec + batch - 1) / batch;
+        const int64_t nw0 = (nb + Kmax - 1) / Kmax;
+        const int K = (int)((nb + nw0 - 1) / nw0);
+        WPlan p{};
+        int rc = wplan_carve(ws, ws_bytes, Ec, batch, st.d, st.L, K, &p);
+        if (rc) return rc;
+        const bool have_readout = out_pos || out_neg;
+        rc = wplan_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
+                         c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, s);
+        if (rc) return rc;
+        StreamArgs a;
+        a.src = src + c0;
+        a.dst = dst + c0;
+        a.neg = neg ? neg + c0 : nullptr;
+        a.t = t + c0;
+        a.out_pos = out_pos ? out_pos + c0 * NG : nullptr;
+        a.out_neg = out_neg ? out_neg + c0 * NG : nullptr;
+        a.own_mod = 1;
+        a.own_rem = 0;
+        const int64_t nw = (Ec + p.Ew - 1) / p.Ew;
+        for (int64_t w = 0; w < nw; ++w, ++lid) {
+            hipEvent_t* ev = nullptr;
+            if (timer && timer->wev && timer->wn < timer->wcap) {
+                ev = timer->wev + timer->wn * (TPNET_MAX_LAYERS + 2);
+                ++timer->wn;
+                const int64_t e0 = w * p.Ew;
+                timer->wedges += (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew;
+            }
+            rc = launch_window(st, a, p, w, Ec, batch, lambda, lid, flags, s, ev);
+            if (rc) return rc;
+        }
+    }
+    return TPNET_OK;
+}
 
 static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                            const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                            uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* ws,
                            size_t ws_bytes, hipStream_t s, StepTimer* timer) {
     if (E == 0) return TPNET_OK;
+    {
+        int Kw = 0;
+        const int64_t wchunk = window_chunk(st, ws_bytes, E, batch, flags, &Kw);
+        if (wchunk > 0)
+            return run_stream_windowed(st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos,
+                                       out_neg, ws, ws_bytes, wchunk, Kw, s, timer);
+    }
     const int64_t chunk = max_chunk(ws_bytes, E, batch);
     if (chunk < 1) return TPNET_ERR_WORKSPACE;
     const int NN = 2 * st.L + 2;
@@ -104,6 +183,7 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
             (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);
             ++timer->n;
             timer->launches += nb;
+            timer->batches += nb;
         }
     }
     return TPNET_OK;
@@ -204,6 +284,12 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
 }
 
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
+
+size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch) {
+    const size_t a = plan_bytes(max_edges, batch);
+    const size_t b = wplan_bytes(max_edges, batch, N, d, L);
+    return a > b ? a : b;
+}
 
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
                  double now_time, double lambda, uint32_t launch_id, uint32_t flags, void* workspace, size_t ws_bytes,

@@ -260,6 +260,174 @@ __device__ __forceinline__ void gram_pair(const tpnet_state& S, int64_t u, int64
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// pairwise readout of ONE pair whose 2(L+1) rows have already been located (windowed stream path, wstep.hip: a row
+// version is either a table bundle or a slot of the window's version log): the Gram, its reduction over the group and
+// the store, exactly as in gram_pair (same sums in the same order).
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int VPL, int W, int L, bool FULL, bool PACKED, bool LDSRED>
+__device__ __forceinline__ void gram_rows(const float* const (&rowp)[2 * (L + 1)], const float (&rs)[2 * (L + 1)], int d,
+                                          bool valid, bool idok, bool do_scale, float* __restrict__ out, int gl,
+                                          float* __restrict__ stage) {
+    using C = GramCfg<LPP, L>;
+    constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
+    const int nvec = d / W;
+    float acc[C::MP];
+#pragma unroll
+    for (int i = 0; i < C::MP; ++i) acc[i] = 0.0f;
+    for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
+        float f[NN][F];
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int vi = c0 + j * LPP + gl;
+                ldv_maybe<W, FULL>(rowp[a], vi, vi < nvec, &f[a][j * W]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+            if (a % NR != 0) {
+#pragma unroll
+                for (int k = 0; k < F; ++k) f[a][k] *= rs[a];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NN; ++a) {
+#pragma unroll
+            for (int b = a; b < NN; ++b) acc[a * NN + b] = acc[a * NN + b] + dot_chunk<F>(f[a], f[b]);
+        }
+    }
+    if constexpr (LDSRED) {
+        constexpr int RS = C::RSTRIDE;
+        float* red = stage + (threadIdx.x / LPP) * C::RED;
+        float* so = red + C::NT * RS;
+        {
+            int tix = 0;
+#pragma unroll
+            for (int a = 0; a < NN; ++a) {
+#pragma unroll
+                for (int b = a; b < NN; ++b) {
+                    red[tix * RS + gl] = acc[a * NN + b];
+                    ++tix;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it * LPP < C::NT; ++it) {
+            const int v = it * LPP + gl;
+            if (v < C::NT) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f* row = reinterpret_cast<const v4f*>(red + v * RS);
+                float sum = 0.0f;
+#pragma unroll
+                for (int l = 0; l < LPP / 4; ++l) {
+                    const v4f q = row[l];
+                    sum = (((sum + q.x) + q.y) + q.z) + q.w;
+                }
+                if constexpr (PACKED) {
+                    so[v] = sum;
+                } else {
+                    int a = 0, off = 0;
+#pragma unroll
+                    for (int r = 1; r < NN; ++r) {
+                        const int o = r * NN - (r * (r - 1)) / 2;
+                        if (v >= o) { a = r; off = o; }
+                    }
+                    const int b = a + (v - off);
+                    so[a * NN + b] = sum;
+                    so[b * NN + a] = sum;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int NOUT = PACKED ? C::NT : C::NG;
+#pragma unroll
+        for (int j = 0; j * LPP < NOUT; ++j) {
+            const int c = j * LPP + gl;
+            if (valid && c < NOUT) {
+                float x = so[c];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;  // NaN < 0 is false: NaN passes through, as in the reference (TPNet.py:127)
+                    x = logf(x + 1.0f);          // log(x + 1), not log1p (TPNet.py:128)
+                }
+                if (!idok) x = __builtin_nanf("");
+                __builtin_nontemporal_store(x, out + c);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+#pragma unroll
+    for (int a = 1; a < NN; ++a) {
+#pragma unroll
+        for (int b = 0; b < a; ++b) acc[a * NN + b] = acc[b * NN + a];
+    }
+    Halve<C::MP, LPP / 2>::run(acc, gl);
+    if constexpr (LPP < 16) {
+        constexpr int NOUT = PACKED ? C::NT : C::NG;
+        float* sg = stage + (threadIdx.x / LPP) * C::NG;
+#pragma unroll
+        for (int k = 0; k < C::PER; ++k) {
+            const int idx = gl * C::PER + k;
+            if (idx < C::NG) {
+                float x = acc[k];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;
+                    x = logf(x + 1.0f);
+                }
+                if (!idok) x = __builtin_nanf("");
+                if constexpr (PACKED) {
+                    const int a = idx / NN, b = idx - a * NN;
+                    if (a <= b) sg[a * NN - (a * (a - 1)) / 2 + (b - a)] = x;
+                } else {
+                    sg[idx] = x;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (NOUT % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j * LPP < NOUT / 4; ++j) {
+                const int c = j * LPP + gl;
+                if (valid && c < NOUT / 4) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f q = reinterpret_cast<const v4f*>(sg)[c];
+                    __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(out) + c);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j * LPP < NOUT; ++j) {
+                const int c = j * LPP + gl;
+                if (valid && c < NOUT) __builtin_nontemporal_store(sg[c], out + c);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < C::PER; ++k) {
+            const int idx = gl * C::PER + k;
+            if (idx < C::NG) {
+                float x = acc[k];
+                if (do_scale && !PACKED) {
+                    x = (x < 0.0f) ? 0.0f : x;
+                    x = logf(x + 1.0f);
+                }
+                if (!idok) x = __builtin_nanf("");
+                if constexpr (PACKED) {
+                    const int a = idx / NN, b = idx - a * NN;
+                    if (a <= b) __builtin_nontemporal_store(x, out + (a * NN - (a * (a - 1)) / 2 + (b - a)));
+                } else {
+                    __builtin_nontemporal_store(x, out + idx);
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
 // pairwise readout of TWO pairs that share their first node: out1 = G(u, v1), out2 = G(u, v2).  u's rows are loaded
 // once.  This is the shape of both callers of the readout: the decoder's (src,dst) / (src,neg) pairs
 // (models/modules.py:112, train_link_prediction.py:359-368) and the encoder's relative encodings, where every

@@ -152,6 +152,65 @@ static constexpr uint32_t STEP_HAS_POS = 1u << 21;   // launch_step -> k_step: o
 static constexpr uint32_t STEP_HAS_NEG = 1u << 22;   // preloaded kernel arguments alone)
 static constexpr uint32_t PLAN_FUSE = 1u << 19;     // plan_build: divert single-contribution targets to the edge-fused path
 
+// ---------------------------------------------------------------------------------------------------------------
+// Windowed stream path (wplan.hip, wstep.hip; DESIGN.md "windows"): K consecutive batches are executed as L+1 launches
+// -- one per layer of the update, then one for all readouts -- instead of K.  What makes it legal: layer i of a node
+// after batch b depends only on layer i-1 of its partners BEFORE batch b and on its own layer i after its previous
+// batch, and layer 0 never changes; so with every intermediate version of a row kept in a log (one slot per (node,
+// batch) run of the window), a whole layer of a whole window is one dependency-free launch.  The arithmetic per run
+// is the reference's (models/TPNet.py:83-96) and does not depend on how the stream is cut into windows.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int WIN_MAX_BATCHES = 64;          // batches per window (6 bits of the sort key and of a reference)
+static constexpr uint32_t WREF_TABLE = 1u << 31;    // the version to read is the table's pre-window row (resolved through meta)
+static constexpr uint32_t WREF_RUN_HEAD = 1u << 30; // first / last contribution of a (node, batch) run
+static constexpr uint32_t WREF_RUN_TAIL = 1u << 29;
+static constexpr uint32_t WREF_BLK_HEAD = 1u << 28; // first / last contribution of a block of WIN_BLOCK inside a run
+static constexpr uint32_t WREF_BLK_TAIL = 1u << 27;
+static constexpr uint32_t WREF_LAST_RUN = 1u << 26; // the run is its node's last one in the window: its result is the new table row
+static constexpr int WREF_BW_SHIFT = 20;            // bits 25..20: batch inside the window
+static constexpr uint32_t WREF_SLOT_MASK = (1u << 20) - 1;   // bits 19..0: log slot (= window-relative sorted position of a run's tail)
+static constexpr int WIN_BLOCK = 8;                 // contributions summed on their own before they join the row (fixed
+                                                    // association: the result of a run does not depend on who sums it)
+
+struct WinDesc {          // per window: lengths of its chain lists (filled by the plan)
+    uint32_t n_small;     // chains one lane group walks
+    uint32_t n_heavy;     // chains a workgroup per column part walks
+    uint32_t pad[2];
+};
+
+struct Chain {            // all contributions of ONE node inside ONE window: sorted positions [j0, j0 + cnt)
+    uint32_t j0;          // chunk-relative
+    uint32_t cnt;
+    int32_t target;
+    uint32_t pad;
+    double t_first;       // clock after the batch of the chain's first run (the first decay's end point)
+    double t_final;       // clock after the batch of its last run: the node's new reference time
+};
+static_assert(sizeof(Chain) == 32, "Chain must be 32 bytes");
+
+struct WPlan {
+    Plan base;            // desc, sorted keys / payload, s_partner, s_coef, sort temp; light / heavy hold the Chain lists
+    uint32_t* s_ref;      // [2*Ec] per sorted contribution: flags | batch in window | log slot of the partner's version
+    float* s_g;           // [2*Ec] decay of the partner's (log) version to the run's clock: exp(-lambda (T_b - T_version))
+    float* s_dec;         // [2*Ec] at run heads: decay of the node's own previous run to this run's clock
+    WinDesc* wdesc;       // [nw]
+    uint32_t* e_ref;      // [3][Ec] readout: version of src / dst / neg of every edge before its batch
+    float* e_g;           // [3][Ec]
+    float* log;           // [2*Ew][L][d] version log of ONE window (reused by the next)
+    int32_t K;            // batches per window
+    int64_t Ew;           // edges per full window = K * batch
+};
+
+size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L);
+int wplan_window_batches(int64_t batch, int d, int L);                 // 0 = the windowed path does not apply
+int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int L, int K, WPlan* out);   // K <= wplan_window_batches
+int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
+                bool want_readout, hipStream_t s);
+// one window: L update launches (+ one readout launch if out_pos / out_neg)
+int launch_window(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t w, int64_t Ec, int64_t batch,
+                  double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s, hipEvent_t* ev /* optional [L+2] */);
+
 extern thread_local int g_last_hip_error;
 #define TPNET_HIP_TRY(expr)                                   \
     do {                                                      \

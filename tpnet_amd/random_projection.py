@@ -139,9 +139,18 @@ class RandomProjectionModule(nn.Module):
         return _lib.State(p0=p0.data_ptr(), q=eng["q"].data_ptr(), meta=eng["meta"].data_ptr(), N=self.node_num,
                           d=self.dim, L=self.num_layer, err=eng["err"].data_ptr())
 
-    def _workspace(self, max_edges: int, batch: int):
+    _STREAM_CHUNK_EDGES = 2_000_000        # a plan covers at most about this many edges; the C side chunks longer streams
+
+    def _workspace(self, max_edges: int, batch: int, stream: bool = False):
+        """Plan workspace.  `stream`: sized for tpnet_run_stream's windowed schedule (plan + the version log of one window)
+        and capped at a fixed chunk of the stream -- the C side walks longer streams chunk by chunk."""
         eng = self._engine()
-        need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
+        if stream:
+            cap = max(batch, (self._STREAM_CHUNK_EDGES // batch) * batch)
+            need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer,
+                                                            min(max_edges, cap), batch)
+        else:
+            need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
         if eng["ws"] is None or eng["ws"].numel() < need:
             eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
         return eng["ws"]
@@ -465,7 +474,7 @@ class RandomProjectionModule(nn.Module):
             out_neg = torch.empty((E, NG), dtype=torch.float32, device=dev)
         if E == 0:
             return out_pos, out_neg
-        ws = self._workspace(E, batch_size)
+        ws = self._workspace(E, batch_size, stream=True)
         st = self._state()
         nb = (E + batch_size - 1) // batch_size
         lid = self._next_launch_ids(nb)
