@@ -643,7 +643,7 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     }
     TPNET_HIP_TRY(hipGetLastError());
     static const char* thr_env = getenv("TPNET_DEV_WIN_HEAVY");
-    const uint32_t thr = thr_env ? (uint32_t)atoi(thr_env) : 24u;   // contributions per (node, window) above which a workgroup per column part walks the chain
+    const uint32_t thr = thr_env ? (uint32_t)atoi(thr_env) : 64u;   // contributions per (node, window) above which a workgroup per column part walks the chain
     const int egrid = (int)(((want_readout ? 3 : 0) * Ec + 255) / 256) > 4096 ? 4096 : (int)(((want_readout ? 3 : 0) * Ec + 255) / 256);
     if (narrow) {
         hipLaunchKernelGGL(k_finish_w<uint32_t>, dim3(grid), dim3(256), 0, s, p, k32_out, src, dst, t, Ec, batch, st.N,

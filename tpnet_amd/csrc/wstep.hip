@@ -10,14 +10,13 @@
 // launch writes, and a whole layer of K batches is one dependency-free, bandwidth-bound launch.
 //
 // Arithmetic per run (node u, batch b), identical for the lane-group and the workgroup variant and independent of how
-// the stream is cut into windows:   new = old * g_u^i ;  then for every block of WIN_BLOCK contributions in index order
-// (src side, then dst side): s = c_0; s += c_1; ...; new += s,   c_j = (P[i-1][partner_j] * g_j^(i-1)) * w_j.
+// the stream is cut into windows:   new = old * g_u^i + S,   S = ((b_0 + b_1) + b_2) + ...,   b_k = the sum, in index order
+// (src side, then dst side), of the k-th block of WIN_BLOCK contributions c_j = (P[i-1][partner_j] * g_j^(i-1)) * w_j.
 #include "readout.hpp"
 
 namespace tpnet {
 
 static constexpr int WB = 256;            // threads per workgroup of both kernels
-static constexpr int WPART_FLOATS = 8192; // LDS floats for the partial sums of a workgroup-walked chain (32 KB)
 
 // g^n by repeated multiplication, as the per-batch kernels form the layers' decay (update.hpp: gu[i] = gu[i-1] * g)
 __device__ __forceinline__ float pow_rep(float g, int n) {
@@ -51,8 +50,10 @@ __device__ __forceinline__ const float* partner_row(const tpnet_state& S, const 
 template <int LPP, int VPL, bool FULL>
 __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P, Chain c, bool valid, int layer,
                                             uint32_t bid, double lambda, int gl, int64_t wc0,
-                                            const BatchDesc* __restrict__ wdesc0) {
-    constexpr int W = 4, F = VPL * W, U = 8;
+                                            const BatchDesc* __restrict__ wdesc0, unsigned long long* dbg) {
+    (void)dbg;
+    STAMP(5);
+    constexpr int W = 4, F = VPL * W, U = (F == 4) ? 8 : 4;   // rows in flight per group: 32 VGPRs
     const int d = S.d, L = S.L;
     const int nvec = d / W;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
@@ -66,15 +67,15 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
     const float* __restrict__ s_coef = P.base.s_coef;
 
     for (int c0 = 0; c0 < (FULL ? 1 : nvec); c0 += LPP * VPL) {
-        float acc[F], sblk[F];
+        float acc[F], sblk[F], srun[F];
 #pragma unroll
         for (int j = 0; j < VPL; ++j) {
             const int vi = c0 + j * LPP + gl;
             ldv_maybe<W, FULL>(qold, vi, valid && vi < nvec, &acc[j * W]);
         }
 #pragma unroll
-        for (int x = 0; x < F; ++x) sblk[x] = 0.0f;
-        bool first = false;
+        for (int x = 0; x < F; ++x) { sblk[x] = 0.0f; srun[x] = 0.0f; }
+        bool firstblk = false;
         float cur_dec = 1.0f;
         for (uint32_t r0 = 0; __any(r0 < c.cnt); r0 += LPP) {
             const uint32_t jm = c.j0 + r0 + (uint32_t)gl;
@@ -123,19 +124,20 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
                             sblk[x] = bh ? m : sblk[x] + m;             // scatter-add in index order (TPNet.py:93-96)
                         }
                         if (fl[k] & WREF_RUN_HEAD) {
-                            first = true;
+                            firstblk = true;
                             cur_dec = (pos == c.j0) ? g0 : dc[k];
                         }
                         if (fl[k] & WREF_BLK_TAIL) {
-                            if (first) {
 #pragma unroll
-                                for (int x = 0; x < F; ++x) acc[x] *= cur_dec;   // decay to the run's clock (TPNet.py:83-85)
-                            }
-#pragma unroll
-                            for (int x = 0; x < F; ++x) acc[x] = acc[x] + sblk[x];
-                            first = false;
+                            for (int x = 0; x < F; ++x) srun[x] = firstblk ? sblk[x] : srun[x] + sblk[x];
+                            firstblk = false;
                         }
                         if (fl[k] & WREF_RUN_TAIL) {
+#pragma unroll
+                            for (int x = 0; x < F; ++x) {
+                                acc[x] *= cur_dec;                       // decay to the run's clock (TPNet.py:83-85)
+                                acc[x] = acc[x] + srun[x];
+                            }
                             float* lrow = P.log + ((int64_t)(pos - (uint32_t)wc0) * L + (layer - 1)) * (int64_t)d;
 #pragma unroll
                             for (int j = 0; j < VPL; ++j) {
@@ -152,49 +154,96 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
         }
     }
     if (valid && gl == 0 && layer == 1) publish_meta(meta + u, mu.copy ^ 1, c.t_final, bid);
+    STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// a chain walked by a WORKGROUP, one column part (LPH lanes x 16 bytes) of the rows: hubs.  The chain's blocks of
-// WIN_BLOCK contributions are the tasks, dealt round-robin to the groups of LPH lanes; a task's rows are loaded together
-// and summed in order; the block sums wait in LDS and one group folds them into the row in task order (= run order,
-// block order), storing every run's result.  Same association as chain_light.
+// a chain walked by a WORKGROUP, one column part (LPH lanes x 16 bytes) of the rows: hubs.
+//   1. the runs of the chain (one per batch of the window the node is a target in) are tabled in LDS; the blocks of
+//      WIN_BLOCK contributions are the TASKS, numbered in run order; the chain is walked in segments of <= TSEG tasks;
+//   2. per segment: every thread resolves a few contributions (partner row address, weight, pending decay: the same
+//      memory round trips whatever the chain's length) and parks them in LDS;
+//   3. tasks are dealt round-robin to the groups of LPH lanes: rows loaded together, summed in order, block sum to LDS;
+//   4. the block sums of a run are added in order by one group per run (runs in parallel);
+//   5. one group walks the completed runs in order: row = row * decay + run sum, stores every run's result.
+// Same association as chain_light.  Every loop bound is uniform over the workgroup (barriers inside).
 // ---------------------------------------------------------------------------------------------------------------
+struct HRec {             // a resolved contribution (16 bytes, LDS)
+    const float* row;     // partner's row of layer (layer-1), this unit's column part NOT yet applied
+    float w, gp;          // time weight, pending decay g^(layer-1)
+};
+
+template <int LPH>
+struct HeavyCfg {
+    static constexpr int G = WB / LPH;                       // groups per workgroup
+    static constexpr int PW = LPH * 4;                       // floats of a row one part covers
+    static constexpr int TSEG = 128;                         // tasks per segment (<= 1024 contributions)
+    static constexpr int HT = (TSEG + G - 1) / G < 4 ? (TSEG + G - 1) / G : 4;   // tasks a group has in flight
+    // lds_u layout (32-bit words)
+    static constexpr int O_START = 0, O_END = 64, O_DECP = 128 /* rank-indexed decay^layer */, O_TOFF = 192 /* [65] by bw */,
+                         O_RLIST = 260 /* [64] */, O_NRUN = 324, O_RTOFF = 328 /* [65] by rank */, O_RSLOT = 396 /* [64] by rank */,
+                         O_RSUM = 460 /* [64][PW] floats by rank */, O_REC = O_RSUM + 64 * PW /* HRec[TSEG*8] */,
+                         O_PART = O_REC + TSEG * WIN_BLOCK * 4 /* [TSEG][PW] floats */, O_TPOS = O_PART + TSEG * PW /* [TSEG] */,
+                         O_TN = O_TPOS + TSEG /* [TSEG] */, WORDS = O_TN + TSEG;
+};
+
 template <int LPH>
 __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P, const Chain c, int part, int layer,
                                             uint32_t bid, double lambda, int64_t wc0,
-                                            const BatchDesc* __restrict__ wdesc0, float* __restrict__ lds_part,
-                                            uint32_t* __restrict__ lds_u) {
-    constexpr int G = WB / LPH;
-    constexpr int TMAX = WPART_FLOATS / (LPH * 4);
-    constexpr int NQ = (WIN_BLOCK + LPH - 1) / LPH;
+                                            const BatchDesc* __restrict__ wdesc0, uint32_t* __restrict__ lds_u,
+                                            unsigned long long* dbg) {
+    (void)dbg;
+    STAMP(0);
+    using H = HeavyCfg<LPH>;
+    constexpr int G = H::G, PW = H::PW, TSEG = H::TSEG, HT = H::HT;
     const int tid = threadIdx.x, g = tid / LPH, gl = tid % LPH;
     const int d = S.d, L = S.L;
     const int nvec = d / 4;
     const int vi = part * LPH + gl;
     const bool vok = vi < nvec;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
-    uint32_t* run_start = lds_u;            // [64] chain-relative position of the run of batch bw (0xFFFFFFFF: none)
-    uint32_t* run_end = lds_u + 64;         // [64]
-    float* run_dec = reinterpret_cast<float*>(lds_u + 128);   // [64]
-    uint32_t* task_off = lds_u + 192;       // [65]
-    uint32_t* tflag = lds_u + 272;          // [TMAX]
-    const int32_t* __restrict__ s_partner = P.base.s_partner;
-    const float* __restrict__ s_coef = P.base.s_coef;
+    uint32_t* run_start = lds_u + H::O_START;   // [64] by bw: chain-relative position of the run of batch bw (0xFFFFFFFF: none)
+    uint32_t* run_end = lds_u + H::O_END;       // [64] by bw
+    float* r_decp = reinterpret_cast<float*>(lds_u + H::O_DECP);   // [64] by rank: (decay from the node's previous run)^layer
+    uint32_t* task_off = lds_u + H::O_TOFF;     // [65] by bw: first task of the run
+    uint32_t* rlist = lds_u + H::O_RLIST;       // [64] the batches that have a run, ascending
+    uint32_t* nrun_p = lds_u + H::O_NRUN;
+    uint32_t* r_toff = lds_u + H::O_RTOFF;      // [65] by rank: first task of the run
+    uint32_t* r_slot = lds_u + H::O_RSLOT;      // [64] by rank: window-relative log slot of the run
+    float* r_sum = reinterpret_cast<float*>(lds_u + H::O_RSUM);    // [64][PW] by rank
+    HRec* rec = reinterpret_cast<HRec*>(lds_u + H::O_REC);         // [TSEG * WIN_BLOCK]
+    float* lds_part = reinterpret_cast<float*>(lds_u + H::O_PART); // [TSEG][PW]
+    uint32_t* t_pos = lds_u + H::O_TPOS;        // [TSEG] chain-relative first position of the segment's tasks
+    uint32_t* t_n = lds_u + H::O_TN;            // [TSEG] their lengths
 
     __syncthreads();                        // the previous unit of this workgroup is done with the tables
-    if (tid < 64) { run_start[tid] = 0xFFFFFFFFu; run_end[tid] = 0u; run_dec[tid] = 1.0f; }
+    if (tid < 64) { run_start[tid] = 0xFFFFFFFFu; run_end[tid] = 0u; r_decp[tid] = 1.0f; }
     __syncthreads();
-    for (uint32_t p = tid; p < c.cnt; p += WB) {
-        const uint32_t ref = P.s_ref[c.j0 + p];
-        const uint32_t bw = (ref >> WREF_BW_SHIFT) & 63u;
-        if (ref & WREF_RUN_HEAD) { run_start[bw] = p; run_dec[bw] = P.s_dec[c.j0 + p]; }
-        if (ref & WREF_RUN_TAIL) run_end[bw] = p;
+    // (the flags and decays of 8 positions per thread are fetched together: one memory round trip per 2048 contributions)
+    float* dec_bw = r_sum;                  // scratch until the runs are ranked: decay by bw
+    for (uint32_t p0 = 0; p0 < c.cnt; p0 += 8 * WB) {
+        uint32_t ref[8];
+        float dec[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t p = p0 + (uint32_t)(q * WB + tid);
+            const bool in = p < c.cnt;
+            ref[q] = in ? P.s_ref[c.j0 + p] : 0u;
+            dec[q] = in ? P.s_dec[c.j0 + p] : 1.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t p = p0 + (uint32_t)(q * WB + tid);
+            const uint32_t bw = (ref[q] >> WREF_BW_SHIFT) & 63u;
+            if (ref[q] & WREF_RUN_HEAD) { run_start[bw] = p; dec_bw[bw] = dec[q]; }
+            if (ref[q] & WREF_RUN_TAIL) run_end[bw] = p;
+        }
     }
     __syncthreads();
     if (tid < 64) {
         const uint32_t st = run_start[tid];
-        const uint32_t nt = (st == 0xFFFFFFFFu) ? 0u : (run_end[tid] - st + WIN_BLOCK) / WIN_BLOCK;
+        const bool has = st != 0xFFFFFFFFu;
+        const uint32_t nt = has ? (run_end[tid] - st + WIN_BLOCK) / WIN_BLOCK : 0u;
         uint32_t inc = nt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -203,9 +252,23 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
         }
         task_off[tid] = inc - nt;
         if (tid == 63) task_off[64] = inc;
+        const unsigned long long hm = __ballot(has);
+        const int rank = __popcll(hm & ((1ull << tid) - 1ull));
+        const int nrun = __popcll(hm);
+        const float dcp = has ? pow_rep(dec_bw[tid], layer) : 1.0f;     // (read before r_sum is reused: same wave, in order)
+        if (has) {
+            rlist[rank] = (uint32_t)tid;
+            r_toff[rank] = inc - nt;
+            r_slot[rank] = c.j0 + run_end[tid] - (uint32_t)wc0;
+            r_decp[rank] = dcp;
+        }
+        if (tid == 0) { *nrun_p = (uint32_t)nrun; }
+        if (tid == 63) r_toff[nrun] = inc;
     }
     __syncthreads();
     const uint32_t T = task_off[64];
+    const uint32_t R = *nrun_p;
+    STAMP(1);
 
     const int32_t u = c.target;
     const MetaView mu = read_meta(meta, u, bid, c.t_first, lambda);
@@ -214,113 +277,185 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
     float* qnew = S.q + (((int64_t)(mu.copy ^ 1) * S.N + u) * L + (layer - 1)) * (int64_t)d;
     float acc[4];
     ldv_pred<4>(qold, vi, g == 0 && vok, acc);
-    bool firstrun = true;
+    uint32_t next_run = 0;                  // rank of the first run the chain walk has not applied yet
 
-    for (uint32_t T0 = 0; T0 < T; T0 += TMAX) {
-        const uint32_t Tend = (T0 + TMAX < T) ? T0 + TMAX : T;
-        for (uint32_t tb = T0; tb < Tend; tb += G) {
-            const uint32_t tt = tb + (uint32_t)g;
-            const bool active = tt < Tend;
-            // the run of task tt: largest bw with task_off[bw] <= tt (runs without tasks share an offset with their successor)
-            uint32_t lo = 0, hi = 64;                       // invariant: task_off[lo] <= tt < task_off[hi]
-            const uint32_t ts = active ? tt : T0;
+    for (uint32_t T0 = 0; T0 < T; T0 += TSEG) {
+        const uint32_t Tend = (T0 + TSEG < T) ? T0 + TSEG : T;
+        // ---- 2. resolve the segment's contributions (task tt, element k) -> rec[(tt - T0) * 8 + k]
+        for (uint32_t tt = T0 + (uint32_t)tid; tt < Tend; tt += WB) {      // first position / length of every task: ONE search each
+            uint32_t lo = 0, hi = 64;                       // task_off[lo] <= tt < task_off[hi]: the run of task tt
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (task_off[mid] <= ts) lo = mid; else hi = mid;
+                if (task_off[mid] <= tt) lo = mid; else hi = mid;
             }
-            const uint32_t bw = lo;
-            const uint32_t kblk = ts - task_off[bw];
-            const uint32_t pstart = run_start[bw] + WIN_BLOCK * kblk;
-            const uint32_t rend = run_end[bw] + 1;
-            const uint32_t pend = (pstart + WIN_BLOCK < rend) ? pstart + WIN_BLOCK : rend;
-            const uint32_t n = active ? pend - pstart : 0u;
-            const float* my_row[NQ];
-            float my_w[NQ], my_gp[NQ];
+            const uint32_t ps = run_start[lo] + WIN_BLOCK * (tt - task_off[lo]);
+            const uint32_t left = run_end[lo] + 1 - ps;
+            t_pos[tt - T0] = ps;
+            t_n[tt - T0] = left < (uint32_t)WIN_BLOCK ? left : (uint32_t)WIN_BLOCK;
+        }
+        __syncthreads();
+        for (uint32_t x0 = 0; x0 < (Tend - T0) * WIN_BLOCK; x0 += 4 * WB) {
+            int32_t pv[4];
+            float w[4], glog[4];
+            uint32_t ref[4];
+            bool in[4];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const uint32_t idx = (uint32_t)(q * LPH + gl);
-                const bool mine = idx < n;
-                const uint32_t jm = c.j0 + pstart + idx;
-                const int32_t pv = mine ? s_partner[jm] : 0;
-                my_w[q] = mine ? s_coef[jm] : 0.0f;
-                const uint32_t ref = mine ? P.s_ref[jm] : 0u;
-                const float glog = mine ? P.s_g[jm] : 1.0f;
-                my_row[q] = partner_row(S, P, layer, pv, ref, glog, bid, lambda, wdesc0, my_gp[q]);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = x0 + (uint32_t)(q * WB + tid);
+                const uint32_t ti = x / WIN_BLOCK, k = x % WIN_BLOCK;
+                const bool ok = ti < Tend - T0 && k < t_n[ti < Tend - T0 ? ti : 0];
+                in[q] = ok;
+                const uint32_t jm = c.j0 + (ok ? t_pos[ti] + k : 0u);
+                pv[q] = ok ? P.base.s_partner[jm] : 0;
+                w[q] = ok ? P.base.s_coef[jm] : 0.0f;
+                ref[q] = ok ? P.s_ref[jm] : 0u;
+                glog[q] = ok ? P.s_g[jm] : 1.0f;
             }
-            float r[WIN_BLOCK][4], w[WIN_BLOCK], gp[WIN_BLOCK];
 #pragma unroll
-            for (int k = 0; k < WIN_BLOCK; ++k) {
-                const int q = k / LPH, sl = k % LPH;
-                const float* rp = reinterpret_cast<const float*>(__shfl((long long)reinterpret_cast<uintptr_t>(my_row[q]), sl, LPH));
-                w[k] = __shfl(my_w[q], sl, LPH);
-                gp[k] = __shfl(my_gp[q], sl, LPH);
-                const bool ok = (uint32_t)k < n;
-                ldv_pred<4>(ok ? rp : S.p0, vi, ok && vok, r[k]);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = x0 + (uint32_t)(q * WB + tid);
+                HRec r;
+                r.row = partner_row(S, P, layer, pv[q], ref[q], glog[q], bid, lambda, wdesc0, r.gp);
+                r.w = w[q];
+                if (!in[q]) { r.row = nullptr; r.w = 0.0f; r.gp = 0.0f; }
+                if (x < (Tend - T0) * WIN_BLOCK) rec[x] = r;
             }
-            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        __syncthreads();
+        // ---- 3. block sums: HT tasks per group at once
+        for (uint32_t tb = T0; tb < Tend; tb += G * HT) {
+            float sb[HT][4];
+            bool act[HT];
 #pragma unroll
-            for (int k = 0; k < WIN_BLOCK; ++k) {
-                if ((uint32_t)k < n) {
+            for (int h = 0; h < HT; ++h) {
+                const uint32_t tt = tb + (uint32_t)(h * G + g);
+                act[h] = tt < Tend;
+                const HRec* rr = rec + (size_t)((act[h] ? tt : T0) - T0) * WIN_BLOCK;
+                float r[WIN_BLOCK][4], w[WIN_BLOCK], gp[WIN_BLOCK];
+                bool ok[WIN_BLOCK];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const float m = (r[k][x] * gp[k]) * w[k];
-                        s[x] = (k == 0) ? m : s[x] + m;
+                for (int k = 0; k < WIN_BLOCK; ++k) {
+                    const HRec q = rr[k];
+                    ok[k] = act[h] && q.row != nullptr;
+                    w[k] = q.w;
+                    gp[k] = q.gp;
+                    ldv_pred<4>(ok[k] ? q.row : S.p0, vi, ok[k] && vok, r[k]);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) sb[h][x] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WIN_BLOCK; ++k) {
+                    if (ok[k]) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const float m = (r[k][x] * gp[k]) * w[k];
+                            sb[h][x] = (k == 0) ? m : sb[h][x] + m;
+                        }
                     }
                 }
             }
-            if (active) {
-                float* dst = lds_part + (size_t)(tt - T0) * (LPH * 4) + gl * 4;
 #pragma unroll
-                for (int x = 0; x < 4; ++x) dst[x] = s[x];
-                if (gl == 0) tflag[tt - T0] = (kblk == 0 ? 1u : 0u) | (pend == rend ? 2u : 0u) | (bw << 2);
+            for (int h = 0; h < HT; ++h) {
+                const uint32_t tt = tb + (uint32_t)(h * G + g);
+                if (act[h]) {
+                    float* dst = lds_part + (size_t)(tt - T0) * PW + gl * 4;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) dst[x] = sb[h][x];
+                }
             }
         }
         __syncthreads();
-        if (g == 0) {
-            for (uint32_t tt = T0; tt < Tend; ++tt) {
-                const uint32_t tf = tflag[tt - T0];
-                const uint32_t bw = tf >> 2;
-                if (tf & 1u) {
-                    const float dec = firstrun ? g0 : pow_rep(run_dec[bw], layer);
+        STAMP(2);
+        // ---- 4. run sums: group g adds the block sums of runs g, g+G, ... that have tasks in [T0, Tend)
+        for (uint32_t rr = (uint32_t)g; rr < R; rr += G) {
+            const uint32_t ta = r_toff[rr], tz = r_toff[rr + 1];              // tasks of the run
+            const uint32_t a = ta > T0 ? ta : T0, z = tz < Tend ? tz : Tend;
+            if (a < z) {
+                float sr[4];
+                float* rs_ = r_sum + (size_t)rr * PW + gl * 4;
+                if (a == ta) {
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) acc[x] *= dec;
-                    firstrun = false;
+                    for (int x = 0; x < 4; ++x) sr[x] = lds_part[(size_t)(a - T0) * PW + gl * 4 + x];
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) sr[x] = rs_[x] + lds_part[(size_t)(a - T0) * PW + gl * 4 + x];
                 }
-                const float* src = lds_part + (size_t)(tt - T0) * (LPH * 4) + gl * 4;
+                for (uint32_t tt = a + 1; tt < z; ++tt) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] = acc[x] + src[x];
-                if ((tf & 2u) && vok) {
-                    const uint32_t pos = c.j0 + run_end[bw];
-                    float* lrow = P.log + ((int64_t)(pos - (uint32_t)wc0) * L + (layer - 1)) * (int64_t)d;
-                    stv<4>(lrow, vi, acc);
-                    if (tt == T - 1) stv<4>(qnew, vi, acc);
+                    for (int x = 0; x < 4; ++x) sr[x] = sr[x] + lds_part[(size_t)(tt - T0) * PW + gl * 4 + x];
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x) rs_[x] = sr[x];
+            }
+        }
+        __syncthreads();
+        STAMP(3);
+        // ---- 5. the chain: runs whose last task is in, in order (rank-indexed tables: no dependent LDS reads)
+        if (g == 0) {
+            uint32_t last = next_run;
+            while (last < R && r_toff[last + 1] <= Tend) ++last;
+            for (uint32_t r0 = next_run; r0 < last; r0 += 4) {
+                float dec[4], rs[4][4];
+                uint32_t slot[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t rr = (r0 + q < last) ? r0 + q : last - 1;
+                    dec[q] = (rr == 0) ? g0 : r_decp[rr];
+                    slot[q] = r_slot[rr];
+                    const float* rs_ = r_sum + (size_t)rr * PW + gl * 4;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) rs[q][x] = rs_[x];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t rr = r0 + q;
+                    if (rr < last) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            acc[x] *= dec[q];                    // decay to the run's clock (TPNet.py:83-85)
+                            acc[x] = acc[x] + rs[q][x];
+                        }
+                        if (vok) {
+                            float* lrow = P.log + ((int64_t)slot[q] * L + (layer - 1)) * (int64_t)d;
+                            stv<4>(lrow, vi, acc);
+                            if (rr == R - 1) stv<4>(qnew, vi, acc);
+                        }
+                    }
                 }
             }
+            next_run = last;
         }
         __syncthreads();
     }
+    STAMP(4);
+#ifdef TPNET_STAMPS
+    if (dbg && (threadIdx.x & 63) == 0) {
+        const size_t wv = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        if (wv < 4000) dbg[(wv * 8 + 7) * 2 + 0] = c.cnt;
+    }
+#endif
     if (tid == 0 && part == 0 && layer == 1) publish_meta(meta + u, mu.copy ^ 1, c.t_final, bid);
 }
 
-template <int LPH>
-static constexpr int heavy_lds_words() { return 272 + WPART_FLOATS / (LPH * 4); }
-
 template <int LPP, int VPL, bool FULL, int LPH>
 __global__ __launch_bounds__(WB) void k_wupdate(tpnet_state S, WPlan P, int64_t w, int layer, uint32_t bid,
-                                                double lambda, int HB, int CP) {
-    __shared__ float lds_part[WPART_FLOATS];
-    __shared__ uint32_t lds_u[heavy_lds_words<LPH>()];
+                                                double lambda, int HB, int CP, int dbg_skip) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_u[HeavyCfg<LPH>::WORDS];
     const int64_t wc0 = 2 * w * P.Ew;
     const BatchDesc* __restrict__ wdesc0 = P.base.desc + w * P.K;
     const WinDesc wd = P.wdesc[w];
+    unsigned long long* dbg = P.base.dbg;      // in-kernel stamps of diagnostic builds (-DTPNET_STAMPS), else unused
+    (void)dbg;
     if ((int)blockIdx.x < HB) {
+        if (dbg_skip & 1) return;
         const Chain* __restrict__ heavy = reinterpret_cast<const Chain*>(P.base.heavy) + wc0;
         const uint32_t units = wd.n_heavy * (uint32_t)CP;
         for (uint32_t h = blockIdx.x; h < units; h += (uint32_t)HB)
             chain_heavy<LPH>(S, P, heavy[h / (uint32_t)CP], (int)(h % (uint32_t)CP), layer, bid, lambda, wc0, wdesc0,
-                             lds_part, lds_u);
+                             lds_u, dbg);
         return;
     }
+    if (dbg_skip & 2) return;
     constexpr int GPB = WB / LPP;
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
@@ -330,7 +465,7 @@ __global__ __launch_bounds__(WB) void k_wupdate(tpnet_state S, WPlan P, int64_t 
         const int64_t idx = base + g;
         const bool valid = idx < (int64_t)wd.n_small;
         const Chain c = small[valid ? idx : 0];
-        chain_light<LPP, VPL, FULL>(S, P, c, valid, layer, bid, lambda, gl, wc0, wdesc0);
+        chain_light<LPP, VPL, FULL>(S, P, c, valid, layer, bid, lambda, gl, wc0, wdesc0, dbg);
     }
 }
 
@@ -415,7 +550,8 @@ template <int LPP, int VPL, bool FULL>
 static int launch_wupdate_g(const tpnet_state& st, const WPlan& p, int64_t w, int layer, uint32_t bid, double lambda,
                             int64_t nc_w, hipStream_t s) {
     static const int hb_env = getenv("TPNET_DEV_WIN_HB") ? atoi(getenv("TPNET_DEV_WIN_HB")) : 0;
-    const int HB = hb_env > 0 ? hb_env : 512;
+    const int HB = hb_env > 0 ? hb_env : 768;
+    static const int skip = getenv("TPNET_DEV_WIN_SKIP") ? atoi(getenv("TPNET_DEV_WIN_SKIP")) : 0;   // timing experiments only
     const int lph = heavy_lph(st.d);
     const int CP = (st.d / 4 + lph - 1) / lph;
     constexpr int GPB = WB / LPP;
@@ -424,11 +560,11 @@ static int launch_wupdate_g(const tpnet_state& st, const WPlan& p, int64_t w, in
     if (lb < 1) lb = 1;
     const dim3 grid((unsigned)(HB + lb));
     if (lph == 4)
-        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 4>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP);
+        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 4>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP, skip);
     else if (lph == 8)
-        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 8>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP);
+        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 8>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP, skip);
     else
-        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 16>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP);
+        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 16>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP, skip);
     return TPNET_OK;
 }
 
@@ -439,14 +575,22 @@ int launch_window(const tpnet_state& st, const StreamArgs& a, const WPlan& p, in
     const int64_t e0 = w * p.Ew;
     const int64_t ne = (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew;
     if (ne < 1) return TPNET_ERR_BAD_ARG;
-    const Geom geo = pick_geom(st.d, true);        // (TPNET_DISPATCH_G declares its own `gm`)
+    // the update walks chains (latency: one lane per 16 bytes of a row, more contributions per round of lanes); the readout
+    // is a long list of independent pairs (throughput: the 16-lane x 2-vector geometry where it applies)
+    static const int ugeo_env = getenv("TPNET_DEV_WIN_UGEOM") ? atoi(getenv("TPNET_DEV_WIN_UGEOM")) : 0;
+    const Geom geo = pick_geom(st.d, ugeo_env == 1);          // (TPNET_DISPATCH_G declares its own `gm`)
+    static const int rgeo_env = getenv("TPNET_DEV_WIN_RGEOM") ? atoi(getenv("TPNET_DEV_WIN_RGEOM")) : 1;
+    const Geom rgeo = pick_geom(st.d, rgeo_env == 1);
     const bool full = st.d == geo.lpp * geo.vpl * 4;
     if (ev) (void)hipEventRecord(ev[0], s);
+    static const int stamp_layer = getenv("TPNET_DEV_STAMP_LAYER") ? atoi(getenv("TPNET_DEV_STAMP_LAYER")) : 0;
+    WPlan pu = p;
     for (int layer = 1; layer <= st.L; ++layer) {
         int rc = TPNET_ERR_BAD_ARG;
+        pu.base.dbg = (layer == stamp_layer) ? p.base.dbg : nullptr;
 #define TPNET_WUPD(LPP_, VPL_) \
-        rc = full ? launch_wupdate_g<LPP_, VPL_, true>(st, p, w, layer, launch_id, lambda, 2 * ne, s) \
-                  : launch_wupdate_g<LPP_, VPL_, false>(st, p, w, layer, launch_id, lambda, 2 * ne, s)
+        rc = full ? launch_wupdate_g<LPP_, VPL_, true>(st, pu, w, layer, launch_id, lambda, 2 * ne, s) \
+                  : launch_wupdate_g<LPP_, VPL_, false>(st, pu, w, layer, launch_id, lambda, 2 * ne, s)
         if (geo.lpp == 4) { TPNET_WUPD(4, 1); }
         else if (geo.lpp == 8) { TPNET_WUPD(8, 1); }
         else if (geo.lpp == 16 && geo.vpl == 1) { TPNET_WUPD(16, 1); }
@@ -461,7 +605,7 @@ int launch_window(const tpnet_state& st, const StreamArgs& a, const WPlan& p, in
     }
     if (a.out_pos || a.out_neg) {
         const int64_t npairs = (a.out_pos ? ne : 0) + (a.out_neg ? ne : 0);
-        TPNET_DISPATCH_G(geo, ({
+        TPNET_DISPATCH_G(rgeo, ({
             if constexpr (W == 4) {
                 const int grid = grid_for(npairs, WB / LPP, 256 * 16);
                 hipLaunchKernelGGL((k_wreadout<LPP, VPL, L, FULL>), dim3(grid), dim3(WB), 0, s, st, p, a, w, Ec, batch,
