@@ -199,7 +199,7 @@ def main():
         NG = rp.pair_wise_feature_dim
         out_pos = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
         out_neg = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
-        rp._workspace(K * Bg, Bg)
+        rp._workspace(K * Bg, Bg, stream=True)
 
         def run(a, b_):
             sl_ = slice(a * Bg, b_ * Bg)
@@ -279,7 +279,7 @@ def main():
     if rank == 0 and shard == "single":
         lib = _lib.load()
         st = rp._state()
-        ws = rp._workspace(K * B, B)
+        ws = rp._workspace(K * B, B, stream=True)
         total_ms, kern_ms = C.c_float(0), C.c_float(0)
         lid = rp._next_launch_ids(3 * K + 8)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

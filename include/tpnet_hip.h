@@ -76,6 +76,10 @@ typedef struct tpnet_state {
                                        format of the column-sharded table, whose partial inner products are summed
                                        across GPUs before tpnet_gram_unpack finishes them */
 
+#define TPNET_FLAG_SCHED_WINDOWED 16u /* tpnet_run_stream: take the windowed schedule whenever it applies (>= 4 batches), not
+                                       only for streams long enough for it to pay (>= 48 batches) */
+#define TPNET_FLAG_SCHED_BATCH 32u    /* tpnet_run_stream: one launch per batch, always */
+
 const char* tpnet_strerror(int status);
 int tpnet_abi_version(void);
 int tpnet_last_hip_error(void);
@@ -128,11 +132,13 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
 /* Workspace for tpnet_update / tpnet_run_stream with at most max_edges edges per call. */
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
 
-/* Workspace for tpnet_run_stream on a table of N rows x d columns x L layers: the larger of tpnet_workspace_bytes and
- * what the WINDOWED schedule needs (plan + the version log of one window of batches).  With at least this much
- * tpnet_run_stream runs a stream of small batches as L+1 launches per window of up to 64 batches (one launch per layer
- * of the update, one for all readouts) instead of one launch per batch; with less it falls back to per-batch launches.
- * Results do not depend on which schedule ran beyond f32 summation order (both within 1e-4 of the reference). */
+/* Workspace for tpnet_run_stream on a table of N rows x d columns x L layers and a stream of up to max_edges edges: the
+ * larger of the per-batch plan (capped at a chunk of ~2 M edges; longer streams are walked chunk by chunk) and what the
+ * WINDOWED schedule needs: its plan + a version log of 2*L*d*4 bytes per edge of a chunk (at most 4 GiB).  With at
+ * least this much, tpnet_run_stream runs a stream of small batches (<= 4096 edges, d % 4 == 0) as a software pipeline
+ * over windows of batches -- one launch per window carrying one layer of the update for each of L consecutive windows
+ * plus the readouts of the window behind them -- instead of one launch per batch; with less it falls back to per-batch
+ * launches.  The two schedules differ in f32 summation order only (both within 1e-4 of the reference). */
 size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch);
 
 /* update (models/TPNet.py:67-99) for one batch: src, dst device int64[B], t device double[B] (absolute times,

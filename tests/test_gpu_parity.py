@@ -581,7 +581,7 @@ def _raw_run_stream(rp, ds, dd, dn, dt, B, now, lam, ws, flags=0):
     st = rp._state()
     t_end = C.c_double(0.0)
     rc = _lib.load().tpnet_run_stream(C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr(), dt.data_ptr(), E, B, now, lam,
-                                      rp._next_launch_ids((E + B - 1) // B), flags, fp.data_ptr(), fn.data_ptr(), ws.data_ptr(),
+                                      rp._next_launch_ids((E + B - 1) // B), flags | _lib.FLAG_SCHED_WINDOWED, fp.data_ptr(), fn.data_ptr(), ws.data_ptr(),
                                       ws.numel(), C.byref(t_end), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     rp._now_host = t_end.value

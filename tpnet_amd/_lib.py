@@ -14,6 +14,8 @@ FLAG_NOT_SCALE = 1
 FLAG_EAGER_DECAY = 2
 FLAG_SEQUENTIAL = 4
 FLAG_PACKED = 8
+FLAG_SCHED_WINDOWED = 16
+FLAG_SCHED_BATCH = 32
 
 ERR_INDEX = -4
 

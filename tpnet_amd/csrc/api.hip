@@ -51,14 +51,19 @@ struct StepTimer {
 // for a window to pay, and the caller's workspace holds the plan of at least one window.  Returns the chunk (edges per
 // plan: whole windows of K batches, or all of E) and K; 0 = use the per-batch path.
 static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, int64_t batch, uint32_t flags, int* K_out) {
-    if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL)) return 0;
+    if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL | TPNET_FLAG_SCHED_BATCH)) return 0;
     const int K = wplan_window_batches(batch, st.d, st.L);
     const int64_t nb = (E + batch - 1) / batch;
-    if (K == 0 || nb < 4) return 0;
+    // short streams: the windowed schedule pays ~280 us up front (two sorts, pipeline fill) and ~4 us per batch at C2, the
+    // per-batch one ~160 us and ~7 us: the crossover is near 40 batches
+    static const int min_nb = env_int("TPNET_DEV_WIN_MIN_BATCHES", 48);
+    if (K == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
     *K_out = K;
     const int64_t Ew = (int64_t)K * batch;
-    const int64_t hard = (((int64_t)1 << 30) / Ew) * Ew;
-    const int64_t lim = (E < hard || hard < Ew) ? E : hard;
+    const int64_t cap = wplan_max_chunk_edges(batch, st.d, st.L);          // the version log of a chunk is bounded
+    const int64_t hard = cap / Ew * Ew;
+    const int64_t lim = (E <= cap) ? E : hard;
+    if ((lim + batch - 1) / batch < 4) return 0;
     if (wplan_bytes(lim, batch, st.N, st.d, st.L) <= ws_bytes) return lim;
     int64_t lo = 0, hi = (lim + Ew - 1) / Ew;       // in windows; lo fits (0), hi does not
     while (hi - lo > 1) {
@@ -75,7 +80,7 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
     const int NN = 2 * st.L + 2;
     const int NG = (flags & TPNET_FLAG_PACKED) ? NN * (NN + 1) / 2 : NN * NN;
     uint32_t lid = launch_id_base;
-    for (int64_t c0 = 0; c0 < E; c0 += chunk) {
+    for (int64_t c0 = 0; c0 < E; c0 += chunk, ++lid) {
         const int64_t Ec = (E - c0 < chunk) ? (E - c0) : chunk;
         // windows of equal length: a chunk of nb batches is cut into ceil(nb / Kmax) windows of ceil(nb / that) batches
         const int64_t nb = (Ec + batch - 1) / batch;
@@ -98,16 +103,20 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
         a.own_mod = 1;
         a.own_rem = 0;
         const int64_t nw = (Ec + p.Ew - 1) / p.Ew;
-        for (int64_t w = 0; w < nw; ++w, ++lid) {
-            hipEvent_t* ev = nullptr;
-            if (timer && timer->wev && timer->wn < timer->wcap) {
-                ev = timer->wev + timer->wn * (TPNET_MAX_LAYERS + 2);
-                ++timer->wn;
-                const int64_t e0 = w * p.Ew;
-                timer->wedges += (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew;
-            }
-            rc = launch_window(st, a, p, w, Ec, batch, lambda, lid, flags, s, ev);
+        const int64_t nsteps = nw + (have_readout ? st.L : st.L - 1);
+        const bool timed = timer && timer->n < timer->cap;
+        if (timed) (void)hipEventRecord(timer->ev[2 * timer->n], s);
+        for (int64_t j = 0; j < nsteps; ++j) {
+            rc = launch_wstep(st, a, p, j, Ec, batch, lambda, flags, s);
             if (rc) return rc;
+        }
+        rc = launch_wwriteback(st, p, Ec, lid, s);
+        if (rc) return rc;
+        if (timed) {
+            (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);
+            ++timer->n;
+            timer->launches += nsteps + 1;
+            timer->batches += nb;
         }
     }
     return TPNET_OK;
@@ -286,8 +295,17 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
 
 size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch) {
-    const size_t a = plan_bytes(max_edges, batch);
-    const size_t b = wplan_bytes(max_edges, batch, N, d, L);
+    if (max_edges < 1) max_edges = 1;
+    if (batch < 1) batch = 1;
+    // a plan never covers more than a chunk: ~2 M edges on the per-batch schedule, what the version log allows on the
+    // windowed one; longer streams are walked chunk by chunk
+    const int64_t cap_a = (2000000 / batch > 0 ? 2000000 / batch : 1) * batch;
+    const size_t a = plan_bytes(max_edges < cap_a ? max_edges : cap_a, batch);
+    size_t b = 0;
+    if (wplan_window_batches(batch, d, L) > 0) {
+        const int64_t cap_b = wplan_max_chunk_edges(batch, d, L);
+        b = wplan_bytes(max_edges < cap_b ? max_edges : cap_b, batch, N, d, L);
+    }
     return a > b ? a : b;
 }
 

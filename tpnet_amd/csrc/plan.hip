@@ -340,39 +340,50 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
 
 
 // =====================================================================================================================
-// Windowed stream path: plan of a chunk cut into windows of K batches (see tpnet_common.h, WPlan).
-// Sort key = (window, target node, batch inside the window): a node's contributions of a window are contiguous (its
-// CHAIN), ordered by batch (its RUNS), inside a run in the reference's summation order (stable sort on the payload
-// order: src-side edges, then dst-side edges, models/TPNet.py:93-96).  Everything a kernel needs to find a row version
-// without touching another unit's output of the same launch is resolved here, once per chunk:
-//   * the version of a partner / readout node "before batch b" = the run of that node with the largest batch < b in
-//     the window (binary search over the sorted keys) -> a slot of the version log, or else the table's pre-window row;
-//   * per run: the decay from the node's previous run; per contribution: block boundaries of the fixed-association sum.
+// Windowed stream path: plan of a chunk (see tpnet_common.h, WPlan).
+// Sort key = (target node, batch in the chunk): ALL contributions of a node in the chunk are contiguous, ordered by
+// batch (its RUNS), inside a run in the reference's summation order (stable sort on the payload order: src-side edges,
+// then dst-side edges, models/TPNet.py:93-96).  The part of a node's range that falls into one window is a CHAIN (the
+// unit of the update kernels).  Everything a kernel needs to find a row version without touching another unit's output
+// of the same launch is resolved here, once per chunk:
+//   * the version of a node "before batch b" = its run with the largest batch < b in the chunk (binary search over
+//     the sorted keys) -> a slot of the version log (the run's last sorted position), or else the frozen table row;
+//   * per run: the decay from the node's previous run; per contribution: block boundaries of the fixed-association sum;
+//   * per window: the lists of chains (walked by a lane group / by a workgroup per column part);
+//   * the list of every node's last run in the chunk (what the write-back copies to the table).
 // =====================================================================================================================
 int wplan_window_batches(int64_t batch, int d, int L) {
     static const char* env = getenv("TPNET_DEV_WINDOW");       // developer override: 0 = off, n = batches per window
+    (void)L;
     if (d % 4 != 0 || d < 4 || batch < 1) return 0;             // scalar-load rows (use_matrix, odd d) keep the per-batch path
     if (batch > 4096) return 0;                                 // such batches are bandwidth-bound one launch at a time already
-    int64_t K = 16384 / batch;
+    int64_t K = 16384 / batch;                                  // ~16 K edges per window (measured: C2 4.9 us per batch at 16 K, 5.4 at 8 K and at 32 K)
     if (env) K = atoi(env);
-    const int64_t log_cap = 96ll << 20;                         // bytes of version log per window
-    const int64_t per_batch = 2 * batch * (int64_t)L * d * 4;
-    if (K * per_batch > log_cap) K = log_cap / per_batch;
     if (K > WIN_MAX_BATCHES) K = WIN_MAX_BATCHES;
-    if (2 * K * batch > (int64_t)WREF_SLOT_MASK) K = (int64_t)WREF_SLOT_MASK / (2 * batch);
     return K >= 2 ? (int)K : 0;
+}
+
+int64_t wplan_max_chunk_edges(int64_t batch, int d, int L) {
+    static const char* env = getenv("TPNET_DEV_WIN_CHUNK_MB");
+    const int64_t log_cap = (env ? (int64_t)atoi(env) : 4096) << 20;         // bytes of version log per chunk (C2: 1 GiB 4.6 us per batch, 4 GiB 4.1: fewer pipeline drains)
+    int64_t e = log_cap / (2 * (int64_t)L * d * 4);
+    const int64_t hard = (int64_t)(WREF_SLOT_MASK >> 1);                     // slots are 26-bit sorted positions
+    if (e > hard) e = hard;
+    if (e > 65535 * batch) e = 65535 * batch;                               // 16-bit batch numbers
+    e = e / batch * batch;
+    return e < batch ? batch : e;
 }
 
 static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int d, int L, int K) {
     const size_t nc = 2 * (size_t)Ec;
     const int64_t Ew = (int64_t)K * batch;
     const size_t nw = (size_t)((Ec + Ew - 1) / Ew);
-    const size_t ew = (size_t)(Ec < Ew ? Ec : Ew);
     size_t tot = 0;
     tot += align_up(nc * 4, 256) * 3;                           // s_ref, s_g, s_dec
-    tot += align_up(nw * sizeof(WinDesc), 256);
+    tot += align_up(nc * 2, 256);                               // s_bc
+    tot += align_up(nw * sizeof(WinDesc), 256) + 256;           // wdesc, wb_count
     tot += align_up(3 * (size_t)Ec * 4, 256) * 2;               // e_ref, e_g
-    tot += align_up(2 * ew * (size_t)L * (size_t)d * 4, 256);   // version log
+    tot += align_up(nc * (size_t)L * (size_t)d * 4, 256);       // version log
     return tot + 256;
 }
 
@@ -387,6 +398,7 @@ size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L) {
 
 int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int L, int K, WPlan* out) {
     if (K < 1 || K > WIN_MAX_BATCHES || K > wplan_window_batches(batch, d, L)) return TPNET_ERR_BAD_ARG;
+    if (Ec > wplan_max_chunk_edges(batch, d, L)) return TPNET_ERR_BAD_ARG;
     int rc = plan_carve(ws, ws_bytes, Ec, batch, &out->base);
     if (rc) return rc;
     const size_t base_bytes = plan_bytes(Ec, batch);
@@ -401,14 +413,23 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int
     const size_t nc = 2 * (size_t)Ec;
     const int64_t Ew = (int64_t)K * batch;
     const size_t nw = (size_t)((Ec + Ew - 1) / Ew);
-    const size_t ew = (size_t)(Ec < Ew ? Ec : Ew);
     out->s_ref = (uint32_t*)take(nc * 4);
     out->s_g = (float*)take(nc * 4);
     out->s_dec = (float*)take(nc * 4);
+    out->s_bc = (uint16_t*)take(nc * 2);
     out->wdesc = (WinDesc*)take(nw * sizeof(WinDesc));
+    (void)take(256);
     out->e_ref = (uint32_t*)take(3 * (size_t)Ec * 4);
     out->e_g = (float*)take(3 * (size_t)Ec * 4);
-    out->log = (float*)take(2 * ew * (size_t)L * (size_t)d * 4);
+    out->log = (float*)take(nc * (size_t)L * (size_t)d * 4);
+    out->chains = reinterpret_cast<Chain*>(out->base.light);
+    out->chains_sparse = reinterpret_cast<Chain*>(out->base.heavy);
+    // the second sort's keys live where the first sort's unsorted keys were (8 bytes per contribution, dead by then), its
+    // payload where the first sort's payload was (dead once k_finish_w has read it)
+    out->lk_in = reinterpret_cast<uint32_t*>(out->base.keys_in);
+    out->lk_out = out->lk_in + nc;
+    out->lv_in = out->base.vals_in;
+    out->lv_out = out->base.vals_out;
     out->K = K;
     out->Ew = Ew;
     if (p > reinterpret_cast<char*>(ws) + ws_bytes) return TPNET_ERR_WORKSPACE;
@@ -417,7 +438,7 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int
 
 template <typename K>
 __global__ void k_make_keys_w(K* __restrict__ keys, uint32_t* __restrict__ vals, const int64_t* __restrict__ src,
-                              const int64_t* __restrict__ dst, int64_t Ec, int64_t B, int64_t N, int node_bits, int KW) {
+                              const int64_t* __restrict__ dst, int64_t Ec, int64_t B, int64_t N, int batch_bits) {
     const int64_t nc = 2 * Ec;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
         int64_t b, e;
@@ -425,8 +446,7 @@ __global__ void k_make_keys_w(K* __restrict__ keys, uint32_t* __restrict__ vals,
         decode(j, B, Ec, b, side, e);
         int64_t tgt = side ? dst[e] : src[e];
         if ((uint64_t)tgt >= (uint64_t)N) tgt = 0;  // counted (once per edge) in k_finish_w
-        const uint64_t win = (uint64_t)(b / KW), bw = (uint64_t)(b % KW);
-        keys[j] = (K)((((win << node_bits) | (uint64_t)tgt) << 6) | bw);
+        keys[j] = (K)(((uint64_t)tgt << batch_bits) | (uint64_t)b);
         vals[j] = (uint32_t)j;
     }
 }
@@ -447,83 +467,79 @@ __device__ __forceinline__ float decay_f32(double lambda, double dt) {
     return (x == 0.0f) ? 1.0f : expf(x);
 }
 
-// version of `node` before batch `bw` of window `win`: the last run of the node with a smaller batch, if any
+// version of `node` before batch b of the chunk: its last run with a smaller batch, if any, else the table row -- which is
+// frozen while the chunk runs, so which copy is current and as of when is read from the node's meta record HERE, once:
+// ref = log slot, or WREF_TABLE | copy; g = the version's decay to t_to
 template <typename K>
-__device__ __forceinline__ void resolve_version(const K* __restrict__ keys, int64_t wc0, int64_t wc1, uint64_t win,
-                                                int node_bits, int64_t node, int bw, const BatchDesc* __restrict__ wdesc0,
-                                                double lambda, double t_to, uint32_t& ref, float& g) {
-    const K skey = (K)((((win << node_bits) | (uint64_t)node) << 6) | (uint64_t)bw);
-    const int64_t pos = lower_bound_keys(keys, wc0, wc1, skey);
-    ref = WREF_TABLE;
-    g = 1.0f;
-    if (pos > wc0) {
+__device__ __forceinline__ void resolve_version(const K* __restrict__ keys, int64_t nc, int batch_bits, int64_t node,
+                                                int64_t b, const BatchDesc* __restrict__ desc,
+                                                const NodeMeta* __restrict__ meta, double lambda, double t_to,
+                                                uint32_t& ref, float& g) {
+    const K skey = (K)(((uint64_t)node << batch_bits) | (uint64_t)b);
+    const int64_t pos = lower_bound_keys(keys, (int64_t)0, nc, skey);
+    if (pos > 0) {
         const K pk = keys[pos - 1];
-        if ((pk >> 6) == (skey >> 6)) {
-            ref = (uint32_t)(pos - 1 - wc0);                       // the run's tail position = its log slot
-            g = decay_f32(lambda, t_to - wdesc0[(int)(pk & 63)].t_last);
+        if ((pk >> batch_bits) == (skey >> batch_bits)) {
+            ref = (uint32_t)(pos - 1);                              // the run's tail position = its log slot
+            const int64_t bp = (int64_t)(pk & (((K)1 << batch_bits) - 1));
+            g = decay_f32(lambda, t_to - desc[bp].t_last);
+            return;
         }
     }
-}
-
-__device__ __forceinline__ uint32_t agg_append_w(WinDesc* __restrict__ wd, int64_t w, bool pred, bool heavy) {
-    const int lane = (int)(threadIdx.x & 63);
-    uint32_t idx = 0;
-    unsigned long long todo = __ballot(pred);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int64_t wsel = __shfl(w, leader, 64);
-        const unsigned long long grp = __ballot(pred && w == wsel);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(heavy ? &wd[wsel].n_heavy : &wd[wsel].n_small, (uint32_t)__popcll(grp));
-        base = __shfl(base, leader, 64);
-        if (pred && w == wsel) idx = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1ull));
-        todo &= ~grp;
-    }
-    return idx;
+    const NodeMeta m = meta[node];
+    const uint32_t c = m.ver & 1u;
+    ref = WREF_TABLE | c;
+    g = decay_f32(lambda, t_to - m.tref[c]);
 }
 
 template <typename K>
-__global__ void k_finish_w(WPlan p, const K* __restrict__ keys, const int64_t* __restrict__ src,
+__device__ __forceinline__ void finish_w(uint32_t bx, uint32_t nbx, WPlan p, const K* __restrict__ keys, const int64_t* __restrict__ src,
                            const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N,
-                           int node_bits, double lambda, uint32_t heavy_threshold, uint32_t* err) {
+                           int batch_bits, double lambda, uint32_t* __restrict__ lk, uint32_t* __restrict__ lv,
+                           uint32_t lk_none /* key of a position that heads no chain: above every (window, length) */,
+                           const NodeMeta* __restrict__ meta, uint32_t* err) {
     const int64_t nc = 2 * Ec;
     const int KW = p.K;
-    const int64_t wlen = 2 * p.Ew;
-    const uint64_t node_mask = (1ull << node_bits) - 1;
-    for (int64_t jb = (int64_t)blockIdx.x * blockDim.x; jb < nc; jb += (int64_t)gridDim.x * blockDim.x) {
+    const K bmask = ((K)1 << batch_bits) - 1;
+    const BatchDesc* __restrict__ desc = p.base.desc;
+    for (int64_t jb = (int64_t)bx * blockDim.x; jb < nc; jb += (int64_t)nbx * blockDim.x) {
         const int64_t j = jb + threadIdx.x;
         const bool active = j < nc;
-        bool chain_head = false;
-        int64_t w = 0, wc0 = 0;
+        bool chain_head = false, last_run = false;
+        int64_t w = 0;
+        if (active) lv[j] = (uint32_t)j;
         Chain ch;
-        ch.j0 = 0; ch.cnt = 0; ch.target = 0; ch.pad = 0; ch.t_first = 0.0; ch.t_final = 0.0;
+        ch.j0 = 0; ch.cnt = 0; ch.target = 0; ch.prev_ref = WREF_TABLE; ch.g_first = 1.0f; ch.pad0 = 0; ch.pad1 = 0; ch.pad2 = 0;
         if (active) {
-            w = j / wlen;
-            wc0 = w * wlen;
-            const int64_t wc1 = (wc0 + wlen < nc) ? wc0 + wlen : nc;
-            const BatchDesc* __restrict__ wdesc0 = p.base.desc + w * KW;
             const K key = keys[j];
             const uint32_t val = p.base.vals_out[j];
-            const int bw = (int)(key & 63);
-            const int64_t node = (int64_t)((key >> 6) & node_mask);
-            const double Tb = wdesc0[bw].t_last;
+            const int64_t b = (int64_t)(key & bmask);
+            const int64_t node = (int64_t)(key >> batch_bits);
+            w = b / KW;
+            const double Tb = desc[b].t_last;
             int32_t partner;
             float wgt;
             contribution(p.base, src, dst, t, Ec, B, N, lambda, val, partner, wgt, err);
             p.base.s_partner[j] = partner;
             p.base.s_coef[j] = wgt;
+            p.s_bc[j] = (uint16_t)b;
+            p.base.s_target[j] = (int32_t)node;
 
-            const bool run_head = (j == wc0) || keys[j - 1] != key;
-            const bool run_tail = (j == wc1 - 1) || keys[j + 1] != key;
-            chain_head = (j == wc0) || (keys[j - 1] >> 6) != (key >> 6);
-            const bool chain_end = (j == wc1 - 1) || (keys[j + 1] >> 6) != (key >> 6);
+            const bool has_prev = j > 0, has_next = j < nc - 1;
+            const K kp = has_prev ? keys[j - 1] : key, kn = has_next ? keys[j + 1] : key;
+            const bool run_head = !has_prev || kp != key;
+            const bool run_tail = !has_next || kn != key;
+            const bool same_node_prev = has_prev && (kp >> batch_bits) == (key >> batch_bits);
+            const bool same_node_next = has_next && (kn >> batch_bits) == (key >> batch_bits);
+            chain_head = !same_node_prev || (int64_t)(kp & bmask) / KW != w;
+            last_run = run_tail && !same_node_next;
             // position inside the run (backward gallop + binary search to the run's head)
             int64_t h = j;
             if (!run_head) {
-                int64_t hi = j, step = 1, lo;            // keys[hi] == key; find lo with keys[lo] != key (or wc0 - 1)
+                int64_t hi = j, step = 1, lo;            // keys[hi] == key; find lo with keys[lo] != key (or -1)
                 for (;;) {
                     lo = hi - step;
-                    if (lo < wc0) { lo = wc0 - 1; break; }
+                    if (lo < 0) { lo = -1; break; }
                     if (keys[lo] != key) break;
                     hi = lo;
                     step <<= 1;
@@ -537,78 +553,128 @@ __global__ void k_finish_w(WPlan p, const K* __restrict__ keys, const int64_t* _
             const int64_t ri = j - h;
             uint32_t ref;
             float g;
-            resolve_version(keys, wc0, wc1, (uint64_t)w, node_bits, (int64_t)partner, bw, wdesc0, lambda, Tb, ref, g);
-            uint32_t fl = ((uint32_t)bw << WREF_BW_SHIFT);
+            resolve_version(keys, nc, batch_bits, (int64_t)partner, b, desc, meta, lambda, Tb, ref, g);
+            uint32_t fl = 0;
             if (run_head) fl |= WREF_RUN_HEAD;
             if (run_tail) fl |= WREF_RUN_TAIL;
             if (ri % WIN_BLOCK == 0) fl |= WREF_BLK_HEAD;
             if (ri % WIN_BLOCK == WIN_BLOCK - 1 || run_tail) fl |= WREF_BLK_TAIL;
-            if (run_tail && chain_end) fl |= WREF_LAST_RUN;
+            if (last_run) fl |= WREF_LAST_RUN;
             p.s_ref[j] = ref | fl;
             p.s_g[j] = g;
             float dec = 1.0f;
-            if (run_head && !chain_head) dec = decay_f32(lambda, Tb - wdesc0[(int)(keys[j - 1] & 63)].t_last);
+            if (run_head && same_node_prev) dec = decay_f32(lambda, Tb - desc[(int64_t)(kp & bmask)].t_last);
             p.s_dec[j] = dec;
 
             if (chain_head) {
-                // chain length by galloping + binary search on the node bits
-                const K nk = key >> 6;
+                // the chain ends where the node or the window does: first key >= (node, first batch of the next window)
+                const K bound = (K)(((uint64_t)node << batch_bits) | (uint64_t)((w + 1) * KW));
+                // (w+1)*KW may exceed the batch field only when it is past the chunk's last batch: then every key of
+                // the node is smaller and the node's own range bounds the chain
+                const K node_end = (K)(((uint64_t)(node + 1)) << batch_bits);
+                const K stop = ((uint64_t)((w + 1) * KW) > (uint64_t)bmask) ? node_end : bound;
                 int64_t lo = j, hi, step = 1;
                 for (;;) {
                     const int64_t nx = lo + step;
-                    if (nx >= wc1) { hi = wc1; break; }
-                    if ((keys[nx] >> 6) != nk) { hi = nx; break; }
+                    if (nx >= nc) { hi = nc; break; }
+                    if (keys[nx] >= stop) { hi = nx; break; }
                     lo = nx;
                     step <<= 1;
                 }
                 while (hi - lo > 1) {
                     const int64_t mid = (lo + hi) >> 1;
-                    if ((keys[mid] >> 6) == nk) lo = mid; else hi = mid;
+                    if (keys[mid] < stop) lo = mid; else hi = mid;
                 }
                 ch.j0 = (uint32_t)j;
                 ch.cnt = (uint32_t)(hi - j);
                 ch.target = (int32_t)node;
-                ch.t_first = Tb;
-                ch.t_final = wdesc0[(int)(keys[hi - 1] & 63)].t_last;
+                if (same_node_prev) {
+                    ch.prev_ref = (uint32_t)(j - 1);
+                    ch.g_first = 1.0f;                       // (a log row's decay comes with the run: s_dec)
+                } else {
+                    const NodeMeta m = meta[node];
+                    const uint32_t c = m.ver & 1u;
+                    ch.prev_ref = WREF_TABLE | c;
+                    ch.g_first = decay_f32(lambda, Tb - m.tref[c]);
+                }
             }
         }
-        const bool is_heavy = chain_head && ch.cnt > heavy_threshold;
-        const bool is_small = chain_head && !is_heavy;
-        const uint32_t is_ = agg_append_w(p.wdesc, w, is_small, false);
-        const uint32_t ih = agg_append_w(p.wdesc, w, is_heavy, true);
-        if (is_small) reinterpret_cast<Chain*>(p.base.light)[wc0 + is_] = ch;
-        if (is_heavy) reinterpret_cast<Chain*>(p.base.heavy)[wc0 + ih] = ch;
+        if (active) {
+            // key of the second sort: chain heads by (window, decreasing length); everything else goes to the end
+            const uint32_t c8 = ch.cnt > 255u ? 255u : ch.cnt;
+            lk[j] = chain_head ? (((uint32_t)w << 8) | (255u - c8)) : lk_none;
+            if (chain_head) p.chains_sparse[j] = ch;
+        }
+    }
+}
+
+// chain records in list order; the extra last block tables, per window, where its chains start in the (window, length)-sorted
+// list, how many there are, how many are hubs
+__global__ void k_gather_chains(WPlan p, const uint32_t* __restrict__ lk, const uint32_t* __restrict__ lv, int64_t nc,
+                                int64_t nw, uint32_t heavy_threshold, uint32_t lk_none) {
+    if (blockIdx.x == gridDim.x - 1) {
+        auto lb = [&](uint32_t key) {
+            int64_t lo = 0, hi = nc;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (lk[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            return lo;
+        };
+        const uint32_t thr8 = heavy_threshold > 254u ? 254u : heavy_threshold;
+        for (int64_t w = threadIdx.x; w < nw; w += blockDim.x) {
+            const int64_t a = lb((uint32_t)w << 8);
+            const int64_t h = lb(((uint32_t)w << 8) | (255u - thr8));     // lengths > thr8 sort before this key
+            const int64_t z = lb((uint32_t)(w + 1) << 8);
+            WinDesc D;
+            D.start = (uint32_t)a;
+            D.n_heavy = (uint32_t)(h - a);
+            D.n_chains = (uint32_t)(z - a);
+            D.pad = 0;
+            p.wdesc[w] = D;
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += (int64_t)(gridDim.x - 1) * blockDim.x) {
+        if (lk[i] >= lk_none) continue;
+        p.chains[i] = p.chains_sparse[lv[i]];
     }
 }
 
 // readout references: the version of src / dst / neg of every edge before the edge's batch, decayed to the batch's
 // readout clock (BatchDesc::now)
 template <typename K>
-__global__ void k_edge_refs(WPlan p, const K* __restrict__ keys, const int64_t* __restrict__ src,
+__device__ __forceinline__ void edge_refs(uint32_t bx, uint32_t nbx, WPlan p, const K* __restrict__ keys, const int64_t* __restrict__ src,
                             const int64_t* __restrict__ dst, const int64_t* __restrict__ neg, int64_t Ec, int64_t B,
-                            int64_t N, int node_bits, double lambda) {
+                            int64_t N, int batch_bits, double lambda, const NodeMeta* __restrict__ meta) {
     const int nwhich = neg ? 3 : 2;
     const int64_t tot = (int64_t)nwhich * Ec;
-    const int KW = p.K;
-    const int64_t wlen = 2 * p.Ew;
     const int64_t nc = 2 * Ec;
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t x = (int64_t)bx * blockDim.x + threadIdx.x; x < tot; x += (int64_t)nbx * blockDim.x) {
         const int which = (int)(x / Ec);
         const int64_t e = x - (int64_t)which * Ec;
         int64_t node = which == 0 ? src[e] : (which == 1 ? dst[e] : neg[e]);
         if ((uint64_t)node >= (uint64_t)N) node = 0;               // the readout reports the bad id itself
         const int64_t b = e / B;
-        const int64_t w = b / KW;
-        const int bw = (int)(b % KW);
-        const int64_t wc0 = w * wlen;
-        const int64_t wc1 = (wc0 + wlen < nc) ? wc0 + wlen : nc;
-        const BatchDesc* __restrict__ wdesc0 = p.base.desc + w * KW;
         uint32_t ref;
         float g;
-        resolve_version(keys, wc0, wc1, (uint64_t)w, node_bits, node, bw, wdesc0, lambda, wdesc0[bw].now, ref, g);
+        resolve_version(keys, nc, batch_bits, node, b, p.base.desc, meta, lambda, p.base.desc[b].now, ref, g);
         p.e_ref[x] = ref;
         p.e_g[x] = g;
     }
+}
+
+// one launch: blocks [0, fgrid) resolve the sorted contributions (finish_w), the rest the readout references (edge_refs)
+template <typename K>
+__global__ void k_plan_w(WPlan p, const K* __restrict__ keys, const int64_t* __restrict__ src,
+                         const int64_t* __restrict__ dst, const int64_t* __restrict__ neg, const double* __restrict__ t,
+                         int64_t Ec, int64_t B, int64_t N, int batch_bits, double lambda, uint32_t* __restrict__ lk,
+                         uint32_t* __restrict__ lv, uint32_t lk_none, const NodeMeta* __restrict__ meta, uint32_t* err,
+                         uint32_t fgrid) {
+    if (blockIdx.x < fgrid)
+        finish_w<K>(blockIdx.x, fgrid, p, keys, src, dst, t, Ec, B, N, batch_bits, lambda, lk, lv, lk_none, meta, err);
+    else
+        edge_refs<K>(blockIdx.x - fgrid, gridDim.x - fgrid, p, keys, src, dst, neg, Ec, B, N, batch_bits, lambda, meta);
 }
 
 int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
@@ -618,26 +684,26 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     const int64_t nc = 2 * Ec;
     const int64_t nw = (Ec + p.Ew - 1) / p.Ew;
     const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
-    const int win_bits = ceil_log2_u64((uint64_t)nw) < 1 ? 1 : ceil_log2_u64((uint64_t)nw);
-    const int key_bits = 6 + node_bits + win_bits;
-    if (key_bits > 64) return TPNET_ERR_BAD_ARG;
+    // one spare value above the last batch: the chain-end bound (node, first batch of the next window) stays in the field
+    const int batch_bits = ceil_log2_u64((uint64_t)nb + 1) < 1 ? 1 : ceil_log2_u64((uint64_t)nb + 1);
+    const int key_bits = node_bits + batch_bits;
+    if (key_bits > 63 || nb > 65535) return TPNET_ERR_BAD_ARG;
     hipLaunchKernelGGL(k_batch_desc, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, p.base.desc, t, Ec, batch, nb,
                        now_time, t_prev_dev, lambda, (int)st.L);
-    TPNET_HIP_TRY(hipMemsetAsync(p.wdesc, 0, (size_t)nw * sizeof(WinDesc), s));
     int grid = (int)((nc + 255) / 256);
     if (grid > 4096) grid = 4096;
-    const bool narrow = key_bits <= 32;
+    const bool narrow = key_bits <= 31;       // (the chain-end bound (node + 1) << batch_bits must not wrap)
     uint32_t* k32_in = reinterpret_cast<uint32_t*>(p.base.keys_in);
     uint32_t* k32_out = reinterpret_cast<uint32_t*>(p.base.keys_out);
     size_t tmp = p.base.sort_tmp_bytes;
     if (narrow) {
         hipLaunchKernelGGL(k_make_keys_w<uint32_t>, dim3(grid), dim3(256), 0, s, k32_in, p.base.vals_in, src, dst, Ec,
-                           batch, st.N, node_bits, (int)p.K);
+                           batch, st.N, batch_bits);
         TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.base.sort_tmp, tmp, k32_in, k32_out, p.base.vals_in, p.base.vals_out,
                                                 (size_t)nc, 0u, (unsigned)key_bits, s, false));
     } else {
         hipLaunchKernelGGL(k_make_keys_w<uint64_t>, dim3(grid), dim3(256), 0, s, p.base.keys_in, p.base.vals_in, src,
-                           dst, Ec, batch, st.N, node_bits, (int)p.K);
+                           dst, Ec, batch, st.N, batch_bits);
         TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.base.sort_tmp, tmp, p.base.keys_in, p.base.keys_out, p.base.vals_in,
                                                 p.base.vals_out, (size_t)nc, 0u, (unsigned)key_bits, s, false));
     }
@@ -645,18 +711,26 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     static const char* thr_env = getenv("TPNET_DEV_WIN_HEAVY");
     const uint32_t thr = thr_env ? (uint32_t)atoi(thr_env) : 64u;   // contributions per (node, window) above which a workgroup per column part walks the chain
     const int egrid = (int)(((want_readout ? 3 : 0) * Ec + 255) / 256) > 4096 ? 4096 : (int)(((want_readout ? 3 : 0) * Ec + 255) / 256);
-    if (narrow) {
-        hipLaunchKernelGGL(k_finish_w<uint32_t>, dim3(grid), dim3(256), 0, s, p, k32_out, src, dst, t, Ec, batch, st.N,
-                           node_bits, lambda, thr, st.err);
-        if (want_readout)
-            hipLaunchKernelGGL(k_edge_refs<uint32_t>, dim3(egrid), dim3(256), 0, s, p, k32_out, src, dst, neg, Ec, batch,
-                               st.N, node_bits, lambda);
-    } else {
-        hipLaunchKernelGGL(k_finish_w<uint64_t>, dim3(grid), dim3(256), 0, s, p, p.base.keys_out, src, dst, t, Ec, batch,
-                           st.N, node_bits, lambda, thr, st.err);
-        if (want_readout)
-            hipLaunchKernelGGL(k_edge_refs<uint64_t>, dim3(egrid), dim3(256), 0, s, p, p.base.keys_out, src, dst, neg, Ec,
-                               batch, st.N, node_bits, lambda);
+    const int win_bits = ceil_log2_u64((uint64_t)nw + 1) < 1 ? 1 : ceil_log2_u64((uint64_t)nw + 1);
+    if (win_bits + 9 > 31) return TPNET_ERR_BAD_ARG;
+    const uint32_t lk_none = 1u << (win_bits + 8);
+    // (the second sort's payload array is the first sort's payload INPUT: dead since the first sort ran; its OUTPUT is read
+    // by k_finish_w, which writes position j to lv_in[j] -- a different array)
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(st.meta);
+    if (narrow)
+        hipLaunchKernelGGL(k_plan_w<uint32_t>, dim3(grid + (want_readout ? egrid : 0)), dim3(256), 0, s, p, k32_out, src, dst,
+                           neg, t, Ec, batch, st.N, batch_bits, lambda, p.lk_in, p.lv_in, lk_none, meta, st.err, (uint32_t)grid);
+    else
+        hipLaunchKernelGGL(k_plan_w<uint64_t>, dim3(grid + (want_readout ? egrid : 0)), dim3(256), 0, s, p, p.base.keys_out,
+                           src, dst, neg, t, Ec, batch, st.N, batch_bits, lambda, p.lk_in, p.lv_in, lk_none, meta, st.err,
+                           (uint32_t)grid);
+    TPNET_HIP_TRY(hipGetLastError());
+    // second sort: chain heads by (window, decreasing length) -> every window's chain list, long chains first
+    {
+        size_t tmp2 = p.base.sort_tmp_bytes;
+        TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.base.sort_tmp, tmp2, p.lk_in, p.lk_out, p.lv_in, p.lv_out, (size_t)nc, 0u,
+                                                (unsigned)(win_bits + 9), s, false));
+        hipLaunchKernelGGL(k_gather_chains, dim3(grid + 1), dim3(256), 0, s, p, p.lk_out, p.lv_out, nc, nw, thr, lk_none);
     }
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;

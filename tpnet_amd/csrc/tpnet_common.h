@@ -68,7 +68,7 @@ struct Plan {
     size_t sort_tmp_bytes;
     unsigned long long* dbg;  // first TPNET_DBG_BYTES of the workspace: in-kernel stamps of diagnostic builds (-DTPNET_STAMPS)
 };
-static constexpr size_t TPNET_DBG_BYTES = 1u << 20;
+static constexpr size_t TPNET_DBG_BYTES = 1u << 20;   // (diagnostic builds: 512 KB of per-wave stamps + 512 KB of per-block stamps)
 
 struct StreamArgs {
     const int64_t* src;
@@ -153,63 +153,79 @@ static constexpr uint32_t STEP_HAS_NEG = 1u << 22;   // preloaded kernel argumen
 static constexpr uint32_t PLAN_FUSE = 1u << 19;     // plan_build: divert single-contribution targets to the edge-fused path
 
 // ---------------------------------------------------------------------------------------------------------------
-// Windowed stream path (wplan.hip, wstep.hip; DESIGN.md "windows"): K consecutive batches are executed as L+1 launches
-// -- one per layer of the update, then one for all readouts -- instead of K.  What makes it legal: layer i of a node
-// after batch b depends only on layer i-1 of its partners BEFORE batch b and on its own layer i after its previous
-// batch, and layer 0 never changes; so with every intermediate version of a row kept in a log (one slot per (node,
-// batch) run of the window), a whole layer of a whole window is one dependency-free launch.  The arithmetic per run
-// is the reference's (models/TPNet.py:83-96) and does not depend on how the stream is cut into windows.
+// Windowed stream path (plan.hip: wplan_*, wstep.hip; DESIGN.md "windows").  A chunk of the stream is cut into windows
+// of K batches, and the work of a window into L+1 ROLES: update of layer 1, ..., update of layer L, readout.  What
+// makes a role a dependency-free launch: layer i of a node after batch b depends only on layer i-1 of its partners
+// BEFORE batch b and on its own layer i after its previous batch, and layer 0 never changes.  Every (node, batch) run
+// writes its result to its own slot of a version LOG that lives as long as the chunk, the table stays frozen at its
+// pre-chunk state until a write-back pass at the end of the chunk, and the plan resolves every read "row of node n
+// before batch b" to a log slot or to the frozen table.  So role i of window w only needs role i-1 of windows <= w and
+// role i of windows < w -- and ONE launch carries {layer 1 of window j, layer 2 of window j-1, ..., readout of window
+// j-L}: a software pipeline over the windows in which the long dependent chain of a hub node hides behind the
+// bandwidth-bound readout of an older window.  The arithmetic per run is the reference's (models/TPNet.py:83-96) in a
+// fixed association that does not depend on how the stream is cut into windows or chunks.
 // ---------------------------------------------------------------------------------------------------------------
-static constexpr int WIN_MAX_BATCHES = 64;          // batches per window (6 bits of the sort key and of a reference)
-static constexpr uint32_t WREF_TABLE = 1u << 31;    // the version to read is the table's pre-window row (resolved through meta)
+static constexpr int WIN_MAX_BATCHES = 64;          // batches per window (the workgroup-walked chains table their runs by batch)
+static constexpr uint32_t WREF_TABLE = 1u << 31;    // the version to read is the table's (frozen) pre-chunk row; bit 0 = which copy
 static constexpr uint32_t WREF_RUN_HEAD = 1u << 30; // first / last contribution of a (node, batch) run
 static constexpr uint32_t WREF_RUN_TAIL = 1u << 29;
 static constexpr uint32_t WREF_BLK_HEAD = 1u << 28; // first / last contribution of a block of WIN_BLOCK inside a run
 static constexpr uint32_t WREF_BLK_TAIL = 1u << 27;
-static constexpr uint32_t WREF_LAST_RUN = 1u << 26; // the run is its node's last one in the window: its result is the new table row
-static constexpr int WREF_BW_SHIFT = 20;            // bits 25..20: batch inside the window
-static constexpr uint32_t WREF_SLOT_MASK = (1u << 20) - 1;   // bits 19..0: log slot (= window-relative sorted position of a run's tail)
+static constexpr uint32_t WREF_LAST_RUN = 1u << 26; // the run is its node's last one in the chunk: the write-back copies it to the table
+static constexpr uint32_t WREF_SLOT_MASK = (1u << 26) - 1;   // bits 25..0: log slot (= chunk-relative sorted position of a run's tail)
 static constexpr int WIN_BLOCK = 8;                 // contributions summed on their own before they join the row (fixed
                                                     // association: the result of a run does not depend on who sums it)
 
-struct WinDesc {          // per window: lengths of its chain lists (filled by the plan)
-    uint32_t n_small;     // chains one lane group walks
-    uint32_t n_heavy;     // chains a workgroup per column part walks
-    uint32_t pad[2];
+struct WinDesc {          // per window: its slice of the chain list (sorted by decreasing length: the plan's second sort)
+    uint32_t start;       // first chain of the window in WPlan::chains
+    uint32_t n_heavy;     // the first n_heavy are walked by a workgroup per column part ...
+    uint32_t n_chains;    // ... the rest by one lane group each
+    uint32_t pad;
 };
 
 struct Chain {            // all contributions of ONE node inside ONE window: sorted positions [j0, j0 + cnt)
     uint32_t j0;          // chunk-relative
     uint32_t cnt;
     int32_t target;
-    uint32_t pad;
-    double t_first;       // clock after the batch of the chain's first run (the first decay's end point)
-    double t_final;       // clock after the batch of its last run: the node's new reference time
+    uint32_t prev_ref;    // the node's row before the window: log slot of its previous run in the chunk, or WREF_TABLE | copy
+    float g_first;        // prev_ref a table row: its pending decay to the first run's clock (layer 1; layer i: ^i)
+    uint32_t pad0, pad1, pad2;
 };
 static_assert(sizeof(Chain) == 32, "Chain must be 32 bytes");
 
 struct WPlan {
     Plan base;            // desc, sorted keys / payload, s_partner, s_coef, sort temp; light / heavy hold the Chain lists
-    uint32_t* s_ref;      // [2*Ec] per sorted contribution: flags | batch in window | log slot of the partner's version
+    uint32_t* s_ref;      // [2*Ec] per sorted contribution: flags | log slot of the partner's version
     float* s_g;           // [2*Ec] decay of the partner's (log) version to the run's clock: exp(-lambda (T_b - T_version))
-    float* s_dec;         // [2*Ec] at run heads: decay of the node's own previous run to this run's clock
+    float* s_dec;         // [2*Ec] at run heads: decay of the node's own previous run (in the chunk) to this run's clock
+    uint16_t* s_bc;       // [2*Ec] batch (in the chunk) of the contribution
     WinDesc* wdesc;       // [nw]
+    Chain* chains;        // [<= 2*Ec] every window's chains, window by window, longest first
+    Chain* chains_sparse; // [2*Ec] plan scratch: the chain record at its head's sorted position
+    uint32_t* lk_in;      // [2*Ec] x 4: keys / payload of the plan's second sort (chain heads by (window, length))
+    uint32_t* lk_out;
+    uint32_t* lv_in;
+    uint32_t* lv_out;
     uint32_t* e_ref;      // [3][Ec] readout: version of src / dst / neg of every edge before its batch
     float* e_g;           // [3][Ec]
-    float* log;           // [2*Ew][L][d] version log of ONE window (reused by the next)
+    float* log;           // [2*Ec][L][d] version log of the chunk (only the slots of run tails are ever touched)
     int32_t K;            // batches per window
     int64_t Ew;           // edges per full window = K * batch
 };
 
 size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L);
 int wplan_window_batches(int64_t batch, int d, int L);                 // 0 = the windowed path does not apply
+int64_t wplan_max_chunk_edges(int64_t batch, int d, int L);            // edges one plan (and its log) may cover
 int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int L, int K, WPlan* out);   // K <= wplan_window_batches
 int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                 const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
                 bool want_readout, hipStream_t s);
-// one window: L update launches (+ one readout launch if out_pos / out_neg)
-int launch_window(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t w, int64_t Ec, int64_t batch,
-                  double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s, hipEvent_t* ev /* optional [L+2] */);
+// pipeline step j of a chunk of nw windows: layer i of window j-i+1 (i = 1..L) and the readout of window j-L, whichever
+// exist, in ONE launch; j = 0 .. nw+L-1.
+int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t j, int64_t Ec, int64_t batch,
+                 double lambda, uint32_t flags, hipStream_t s);
+// end of the chunk: every touched node's last version -> the table's other copy, meta published under launch_id
+int launch_wwriteback(const tpnet_state& st, const WPlan& p, int64_t Ec, uint32_t launch_id, hipStream_t s);
 
 extern thread_local int g_last_hip_error;
 #define TPNET_HIP_TRY(expr)                                   \

@@ -1,13 +1,16 @@
-// gfx950 kernels of the WINDOWED stream path (tpnet_common.h, WPlan; plan: plan.hip): a window of K batches runs as
-// L launches of k_wupdate (one per layer of models/TPNet.py:90-96, ascending) + one launch of k_wreadout (all the
-// window's pairwise readouts, models/TPNet.py:112-128) instead of K fused per-batch launches.
+// gfx950 kernels of the WINDOWED stream path (tpnet_common.h, WPlan; plan: plan.hip).  A chunk of the stream is cut into
+// windows of K batches; pipeline step j is ONE launch of k_wpipe that carries
+//     update of layer 1 for window j, layer 2 for window j-1, ..., layer L for window j-L+1    (models/TPNet.py:90-96)
+//     and all pairwise readouts of window j-L                                                   (models/TPNet.py:112-128)
+// instead of one fused launch per batch.
 //
-// Why ascending layers are legal here: layer i of node u after batch b needs (1) its own layer i after u's previous
-// batch and (2) layer i-1 of its partners BEFORE batch b.  (1) is a chain inside ONE unit (all runs of u in the window
-// are walked in order by the same lanes); (2) was written by the previous launch -- every run's result goes to a slot of
-// the window's version log, and the plan has resolved, for every read, which slot (or the table's pre-window row)
-// holds "the row before batch b".  Layer 0 never changes.  So no unit of a launch reads what another unit of the same
-// launch writes, and a whole layer of K batches is one dependency-free, bandwidth-bound launch.
+// Why this is legal: layer i of node u after batch b needs (1) its own layer i after u's previous batch and (2) layer i-1
+// of its partners BEFORE batch b.  Every (node, batch) run writes its result to its own slot of the chunk's version log,
+// the table is frozen at its pre-chunk state until the write-back at the end of the chunk, and the plan has resolved
+// every read "row of node n before batch b" to a log slot or the frozen table row.  (1) comes from a log slot written by
+// the same role in an earlier step (or is carried in registers inside a chain), (2) from the role one layer down, which
+// is one window ahead: written at step j-1 at the latest.  So no unit of a launch reads what another unit of the same
+// launch writes, and the long dependent chain of a hub node's update hides behind the bandwidth-bound readout.
 //
 // Arithmetic per run (node u, batch b), identical for the lane-group and the workgroup variant and independent of how
 // the stream is cut into windows:   new = old * g_u^i + S,   S = ((b_0 + b_1) + b_2) + ...,   b_k = the sum, in index order
@@ -17,6 +20,9 @@
 namespace tpnet {
 
 static constexpr int WB = 256;            // threads per workgroup of both kernels
+#ifndef TPNET_WPIPE_MINW
+#define TPNET_WPIPE_MINW 4
+#endif
 
 // g^n by repeated multiplication, as the per-batch kernels form the layers' decay (update.hpp: gu[i] = gu[i-1] * g)
 __device__ __forceinline__ float pow_rep(float g, int n) {
@@ -25,23 +31,29 @@ __device__ __forceinline__ float pow_rep(float g, int n) {
     return r;
 }
 
-// where a contribution's partner row of layer (layer-1) lives, and its pending decay g^(layer-1)
+// where a contribution's partner row of layer (layer-1) lives, and its pending decay g^(layer-1).  The plan has resolved the
+// version: a log slot, or a copy of the (frozen) table bundle; g = its decay to the run's clock.
 __device__ __forceinline__ const float* partner_row(const tpnet_state& S, const WPlan& P, int layer, int32_t pv,
-                                                    uint32_t ref, float g_log, uint32_t bid, double lambda,
-                                                    const BatchDesc* __restrict__ wdesc0, float& gp) {
+                                                    uint32_t ref, float g, float& gp) {
     const int d = S.d, L = S.L;
     if (layer == 1) {
         gp = 1.0f;
         return S.p0 + (int64_t)pv * d;
     }
-    if (ref & WREF_TABLE) {
-        const double Tb = wdesc0[(ref >> WREF_BW_SHIFT) & 63u].t_last;
-        const MetaView m = read_meta(reinterpret_cast<const NodeMeta*>(S.meta), pv, bid, Tb, lambda);
-        gp = pow_rep(m.g, layer - 1);
-        return S.q + (((int64_t)m.copy * S.N + pv) * L + (layer - 2)) * (int64_t)d;
-    }
-    gp = pow_rep(g_log, layer - 1);
+    gp = pow_rep(g, layer - 1);
+    if (ref & WREF_TABLE) return S.q + (((int64_t)(ref & 1u) * S.N + pv) * L + (layer - 2)) * (int64_t)d;
     return P.log + ((int64_t)(ref & WREF_SLOT_MASK) * L + (layer - 2)) * (int64_t)d;
+}
+
+// the row a chain starts from (layer `layer` of its node before the window) and, for a table row, its decay^layer to the
+// first run's clock (a log row's decay comes with the run: WPlan::s_dec)
+__device__ __forceinline__ const float* chain_start(const tpnet_state& S, const WPlan& P, const Chain& c, int layer,
+                                                    float& g0) {
+    const int d = S.d, L = S.L;
+    g0 = pow_rep(c.g_first, layer);
+    if (c.prev_ref & WREF_TABLE)
+        return S.q + (((int64_t)(c.prev_ref & 1u) * S.N + c.target) * L + (layer - 1)) * (int64_t)d;
+    return P.log + ((int64_t)(c.prev_ref & WREF_SLOT_MASK) * L + (layer - 1)) * (int64_t)d;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -49,20 +61,16 @@ __device__ __forceinline__ const float* partner_row(const tpnet_state& S, const 
 // ---------------------------------------------------------------------------------------------------------------
 template <int LPP, int VPL, bool FULL>
 __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P, Chain c, bool valid, int layer,
-                                            uint32_t bid, double lambda, int gl, int64_t wc0,
-                                            const BatchDesc* __restrict__ wdesc0, unsigned long long* dbg) {
+                                            double lambda, int gl, unsigned long long* dbg) {
     (void)dbg;
     STAMP(5);
     constexpr int W = 4, F = VPL * W, U = (F == 4) ? 8 : 4;   // rows in flight per group: 32 VGPRs
     const int d = S.d, L = S.L;
     const int nvec = d / W;
-    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
-    if (!valid) { c.cnt = 0; c.target = 0; c.j0 = 0; }
-    const int32_t u = c.target;
-    const MetaView mu = read_meta(meta, u, bid, c.t_first, lambda);
-    const float g0 = pow_rep(mu.g, layer);
-    const float* qold = S.q + (((int64_t)mu.copy * S.N + u) * L + (layer - 1)) * (int64_t)d;
-    float* qnew = S.q + (((int64_t)(mu.copy ^ 1) * S.N + u) * L + (layer - 1)) * (int64_t)d;
+    if (!valid) { c.cnt = 0; c.target = 0; c.j0 = 0; c.prev_ref = WREF_TABLE; c.g_first = 1.0f; }
+    float g0;
+    const float* qold = chain_start(S, P, c, layer, g0);
+    const bool from_table = (c.prev_ref & WREF_TABLE) != 0;
     const int32_t* __restrict__ s_partner = P.base.s_partner;
     const float* __restrict__ s_coef = P.base.s_coef;
 
@@ -86,7 +94,7 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
             const float my_glog = mine ? P.s_g[jm] : 1.0f;
             const float my_dec = mine ? pow_rep(P.s_dec[jm], layer) : 1.0f;
             float my_gp;
-            const float* my_row = partner_row(S, P, layer, my_pv, my_ref, my_glog, bid, lambda, wdesc0, my_gp);
+            const float* my_row = partner_row(S, P, layer, my_pv, my_ref, my_glog, my_gp);
             const uint32_t n_here = (r0 < c.cnt) ? ((c.cnt - r0 < (uint32_t)LPP) ? c.cnt - r0 : (uint32_t)LPP) : 0u;
             for (uint32_t k0 = 0; __any(k0 < n_here); k0 += U) {
                 const float* rp[U];
@@ -125,7 +133,7 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
                         }
                         if (fl[k] & WREF_RUN_HEAD) {
                             firstblk = true;
-                            cur_dec = (pos == c.j0) ? g0 : dc[k];
+                            cur_dec = (pos == c.j0 && from_table) ? g0 : dc[k];
                         }
                         if (fl[k] & WREF_BLK_TAIL) {
 #pragma unroll
@@ -138,14 +146,11 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
                                 acc[x] *= cur_dec;                       // decay to the run's clock (TPNet.py:83-85)
                                 acc[x] = acc[x] + srun[x];
                             }
-                            float* lrow = P.log + ((int64_t)(pos - (uint32_t)wc0) * L + (layer - 1)) * (int64_t)d;
+                            float* lrow = P.log + ((int64_t)pos * L + (layer - 1)) * (int64_t)d;   // the run's slot of the log
 #pragma unroll
                             for (int j = 0; j < VPL; ++j) {
                                 const int vi = c0 + j * LPP + gl;
-                                if (FULL || vi < nvec) {
-                                    stv<W>(lrow, vi, &acc[j * W]);
-                                    if (fl[k] & WREF_LAST_RUN) stv<W>(qnew, vi, &acc[j * W]);
-                                }
+                                if (FULL || vi < nvec) stv<W>(lrow, vi, &acc[j * W]);
                             }
                         }
                     }
@@ -153,7 +158,6 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
             }
         }
     }
-    if (valid && gl == 0 && layer == 1) publish_meta(meta + u, mu.copy ^ 1, c.t_final, bid);
     STAMP(6);
 }
 
@@ -189,9 +193,8 @@ struct HeavyCfg {
 
 template <int LPH>
 __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P, const Chain c, int part, int layer,
-                                            uint32_t bid, double lambda, int64_t wc0,
-                                            const BatchDesc* __restrict__ wdesc0, uint32_t* __restrict__ lds_u,
-                                            unsigned long long* dbg) {
+                                            double lambda, uint32_t b0 /* first batch of the window */,
+                                            uint32_t* __restrict__ lds_u, unsigned long long* dbg) {
     (void)dbg;
     STAMP(0);
     using H = HeavyCfg<LPH>;
@@ -201,7 +204,6 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
     const int nvec = d / 4;
     const int vi = part * LPH + gl;
     const bool vok = vi < nvec;
-    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
     uint32_t* run_start = lds_u + H::O_START;   // [64] by bw: chain-relative position of the run of batch bw (0xFFFFFFFF: none)
     uint32_t* run_end = lds_u + H::O_END;       // [64] by bw
     float* r_decp = reinterpret_cast<float*>(lds_u + H::O_DECP);   // [64] by rank: (decay from the node's previous run)^layer
@@ -222,7 +224,7 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
     // (the flags and decays of 8 positions per thread are fetched together: one memory round trip per 2048 contributions)
     float* dec_bw = r_sum;                  // scratch until the runs are ranked: decay by bw
     for (uint32_t p0 = 0; p0 < c.cnt; p0 += 8 * WB) {
-        uint32_t ref[8];
+        uint32_t ref[8], bcq[8];
         float dec[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -230,11 +232,12 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
             const bool in = p < c.cnt;
             ref[q] = in ? P.s_ref[c.j0 + p] : 0u;
             dec[q] = in ? P.s_dec[c.j0 + p] : 1.0f;
+            bcq[q] = in ? (uint32_t)P.s_bc[c.j0 + p] : b0;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const uint32_t p = p0 + (uint32_t)(q * WB + tid);
-            const uint32_t bw = (ref[q] >> WREF_BW_SHIFT) & 63u;
+            const uint32_t bw = (bcq[q] - b0) & 63u;
             if (ref[q] & WREF_RUN_HEAD) { run_start[bw] = p; dec_bw[bw] = dec[q]; }
             if (ref[q] & WREF_RUN_TAIL) run_end[bw] = p;
         }
@@ -259,7 +262,7 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
         if (has) {
             rlist[rank] = (uint32_t)tid;
             r_toff[rank] = inc - nt;
-            r_slot[rank] = c.j0 + run_end[tid] - (uint32_t)wc0;
+            r_slot[rank] = c.j0 + run_end[tid];               // chunk-relative sorted position of the run's tail
             r_decp[rank] = dcp;
         }
         if (tid == 0) { *nrun_p = (uint32_t)nrun; }
@@ -270,11 +273,9 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
     const uint32_t R = *nrun_p;
     STAMP(1);
 
-    const int32_t u = c.target;
-    const MetaView mu = read_meta(meta, u, bid, c.t_first, lambda);
-    const float g0 = pow_rep(mu.g, layer);
-    const float* qold = S.q + (((int64_t)mu.copy * S.N + u) * L + (layer - 1)) * (int64_t)d;
-    float* qnew = S.q + (((int64_t)(mu.copy ^ 1) * S.N + u) * L + (layer - 1)) * (int64_t)d;
+    float g0;
+    const float* qold = chain_start(S, P, c, layer, g0);
+    const bool from_table = (c.prev_ref & WREF_TABLE) != 0;
     float acc[4];
     ldv_pred<4>(qold, vi, g == 0 && vok, acc);
     uint32_t next_run = 0;                  // rank of the first run the chain walk has not applied yet
@@ -315,7 +316,7 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
             for (int q = 0; q < 4; ++q) {
                 const uint32_t x = x0 + (uint32_t)(q * WB + tid);
                 HRec r;
-                r.row = partner_row(S, P, layer, pv[q], ref[q], glog[q], bid, lambda, wdesc0, r.gp);
+                r.row = partner_row(S, P, layer, pv[q], ref[q], glog[q], r.gp);
                 r.w = w[q];
                 if (!in[q]) { r.row = nullptr; r.w = 0.0f; r.gp = 0.0f; }
                 if (x < (Tend - T0) * WIN_BLOCK) rec[x] = r;
@@ -400,7 +401,7 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t rr = (r0 + q < last) ? r0 + q : last - 1;
-                    dec[q] = (rr == 0) ? g0 : r_decp[rr];
+                    dec[q] = (rr == 0 && from_table) ? g0 : r_decp[rr];
                     slot[q] = r_slot[rr];
                     const float* rs_ = r_sum + (size_t)rr * PW + gl * 4;
 #pragma unroll
@@ -418,7 +419,6 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
                         if (vok) {
                             float* lrow = P.log + ((int64_t)slot[q] * L + (layer - 1)) * (int64_t)d;
                             stv<4>(lrow, vi, acc);
-                            if (rr == R - 1) stv<4>(qnew, vi, acc);
                         }
                     }
                 }
@@ -434,186 +434,303 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
         if (wv < 4000) dbg[(wv * 8 + 7) * 2 + 0] = c.cnt;
     }
 #endif
-    if (tid == 0 && part == 0 && layer == 1) publish_meta(meta + u, mu.copy ^ 1, c.t_final, bid);
 }
 
-template <int LPP, int VPL, bool FULL, int LPH>
-__global__ __launch_bounds__(WB) void k_wupdate(tpnet_state S, WPlan P, int64_t w, int layer, uint32_t bid,
-                                                double lambda, int HB, int CP, int dbg_skip) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds_u[HeavyCfg<LPH>::WORDS];
-    const int64_t wc0 = 2 * w * P.Ew;
-    const BatchDesc* __restrict__ wdesc0 = P.base.desc + w * P.K;
-    const WinDesc wd = P.wdesc[w];
-    unsigned long long* dbg = P.base.dbg;      // in-kernel stamps of diagnostic builds (-DTPNET_STAMPS), else unused
-    (void)dbg;
-    if ((int)blockIdx.x < HB) {
-        if (dbg_skip & 1) return;
-        const Chain* __restrict__ heavy = reinterpret_cast<const Chain*>(P.base.heavy) + wc0;
-        const uint32_t units = wd.n_heavy * (uint32_t)CP;
-        for (uint32_t h = blockIdx.x; h < units; h += (uint32_t)HB)
-            chain_heavy<LPH>(S, P, heavy[h / (uint32_t)CP], (int)(h % (uint32_t)CP), layer, bid, lambda, wc0, wdesc0,
-                             lds_u, dbg);
-        return;
-    }
-    if (dbg_skip & 2) return;
-    constexpr int GPB = WB / LPP;
-    const int gl = threadIdx.x % LPP;
-    const int g = threadIdx.x / LPP;
-    const Chain* __restrict__ small = reinterpret_cast<const Chain*>(P.base.light) + wc0;
-    const int64_t nblk = (int64_t)gridDim.x - HB;
-    for (int64_t base = ((int64_t)blockIdx.x - HB) * GPB; base < (int64_t)wd.n_small; base += nblk * GPB) {
-        const int64_t idx = base + g;
-        const bool valid = idx < (int64_t)wd.n_small;
-        const Chain c = small[valid ? idx : 0];
-        chain_light<LPP, VPL, FULL>(S, P, c, valid, layer, bid, lambda, gl, wc0, wdesc0, dbg);
-    }
-}
+// lanes per column part of a workgroup-walked chain, by the geometry's row chunk (LPP * VPL vectors)
+constexpr int heavy_lph(int lpp, int vpl) { return lpp * vpl <= 32 ? 4 : (lpp * vpl <= 64 ? 8 : 16); }
+
+// what one pipeline step carries (host -> kernel, by value)
+struct WStep {
+    int64_t w_upd[TPNET_MAX_LAYERS];   // window of the update of layer i+1 at this step (-1: none)
+    int64_t w_read;                    // window whose readouts run at this step (-1: none)
+    uint32_t seg[TPNET_MAX_LAYERS + 3];       // first block of: hub chains[layer 1..L], chains (all layers), readout; then the grid size
+    int32_t CP;                        // column parts of a workgroup-walked chain
+    int32_t dbg_layer;                 // diagnostic builds: the layer whose units are stamped (0: none)
+    int32_t dbg_skip;                  // timing experiments: 1 = no hub chains, 2 = no chains, 4 = no readout
+    uint32_t n_active;                 // layers that have a window at this step
+};
 
 // ---------------------------------------------------------------------------------------------------------------
-// all pairwise readouts of a window: (src,dst) and (src,neg) of every edge on the state BEFORE the edge's batch
+// one pipeline step: block ranges = [hub chains of layer 1 | ... | of layer L | chains of layer 1 | ... | L | readout pairs]
+// (the long units first, the short uniform ones last: they fill the tail)
 // ---------------------------------------------------------------------------------------------------------------
-template <int LPP, int VPL, int L, bool FULL>
-__global__ __launch_bounds__(WB) void k_wreadout(tpnet_state S, WPlan P, StreamArgs a, int64_t w, int64_t Ec, int64_t B,
-                                                 uint32_t bid, double lambda, uint32_t flags) {
+// RS: the readout takes the 16-lane x 2-vector geometry while the chains keep 32 lanes x 1 vector (rows of 17..32 vectors:
+// a long list of independent pairs wants four pairs per wave, a chain wants a contribution per lane and round)
+template <int LPP, int VPL, int L, bool FULL, bool RS>
+__global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, WPlan P, StreamArgs a, WStep st, int64_t Ec, int64_t B,
+                                              double lambda, uint32_t flags) {
     constexpr int W = 4;
-    using C = GramCfg<LPP, L>;
-    constexpr int NR = C::NR, NN = C::NN;
-    constexpr int GPB = WB / LPP;
-    constexpr bool LR = C::template lds_reduce<WB>();
-    __shared__ float stage[C::template stage_floats<WB>()];
+    constexpr int LPH = heavy_lph(LPP, VPL);
+    constexpr int RLPP = RS ? 16 : LPP, RVPL = RS ? 2 : VPL;
+    static_assert(!RS || (LPP == 32 && VPL == 1), "readout split: chains on 32 x 1");
+    using C = GramCfg<RLPP, L>;
+    // (the readout adds its lanes' partial sums through DPP / permlane swaps here, not through LDS: the workgroup-walked
+    // chains' tables are what the block's LDS is for, and 30 KB instead of 44-50 KB is one more resident workgroup per CU)
+    constexpr bool LR = false;
+    constexpr int RWORDS = (RLPP < 16) ? C::NG * (WB / RLPP) : 1;
+    constexpr int LWORDS = HeavyCfg<LPH>::WORDS > RWORDS ? HeavyCfg<LPH>::WORDS : RWORDS;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_u[LWORDS];
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
-    const int d = S.d;
-    const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
-    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
-    const int ostride = packed ? C::NT : C::NG;
-    const int64_t e0 = w * P.Ew;
-    const int64_t ne = (Ec - e0 < P.Ew) ? Ec - e0 : P.Ew;
-    const int64_t npos = a.out_pos ? ne : 0;
-    const int64_t nneg = a.out_neg ? ne : 0;
-    const int64_t npairs = npos + nneg;
-    const bool both = npos != 0 && nneg != 0;
-    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
-    for (int64_t base = (int64_t)blockIdx.x * GPB; base < npairs; base += (int64_t)gridDim.x * GPB) {
-        const int64_t pw = base + g;
-        const bool valid = pw < npairs;
-        // (src,dst) and (src,neg) of one edge sit in adjacent lane groups: the src rows are fetched by the same instructions
-        const int64_t idx = valid ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
-        const bool isneg = both ? (pw & 1) != 0 : (pw >= npos);
-        const int64_t e = e0 + idx;
-        int64_t ids[2] = {a.src[e], isneg ? a.neg[e] : a.dst[e]};
-        const int which[2] = {0, isneg ? 2 : 1};
-        float* out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
-        const bool idok = valid && (uint64_t)ids[0] < (uint64_t)S.N && (uint64_t)ids[1] < (uint64_t)S.N;
-        if (valid && !idok && gl == 0) atomicAdd(S.err, 1u);
-        if (!idok) { ids[0] = 0; ids[1] = 0; }
-        const double now = P.base.desc[e / B].now;
-        const float* rowp[NN];
-        float rs[NN];
+    constexpr int GPB = WB / LPP;
+    const uint32_t bx = blockIdx.x;
+    // which range is this block in (compares against every bound: no dynamic indexing of the kernel arguments).
+    // Ranges: 0..L-1 hub chains of layer 1..L; L: the chains of all active layers, interleaved block by block (chain lists are
+    // sorted longest first: every layer's long chains start early); L+1: readout
+    int sidx = 0;
+    uint32_t seg_lo = 0, seg_hi = st.seg[1];
+    int64_t w = st.w_upd[0];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const uint32_t ref = idok ? P.e_ref[(int64_t)which[s] * Ec + e] : WREF_TABLE;
-            const float* qb;
-            float gs;
-            if (ref & WREF_TABLE) {
-                const MetaView m = read_meta(meta, ids[s], bid, now, lambda);
-                qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
-                gs = m.g;
-            } else {
-                qb = P.log + (int64_t)(ref & WREF_SLOT_MASK) * ((int64_t)L * d);
-                gs = P.e_g[(int64_t)which[s] * Ec + e];
-            }
-            rowp[s * NR] = S.p0 + ids[s] * (int64_t)d;
-            rs[s * NR] = 1.0f;
-            float gg = 1.0f;
+    for (int i = 1; i <= L + 1; ++i) {
+        if (bx >= st.seg[i]) {
+            sidx = i;
+            seg_lo = st.seg[i];
+            seg_hi = st.seg[i + 1];
+            w = (i < L) ? st.w_upd[i] : st.w_read;
+        }
+    }
+    uint32_t rb_ = bx - seg_lo, nblk_ = seg_hi - seg_lo;
+    int layer = sidx + 1;
+    if (sidx == L) {                                           // interleaved chains: block k -> the (k % nact)-th active layer
+        const uint32_t nact = st.n_active;
+        const uint32_t r = rb_ % nact;
+        rb_ = rb_ / nact;
+        nblk_ = nblk_ / nact;
+        uint32_t seen = 0;
 #pragma unroll
-            for (int i = 1; i <= L; ++i) {
-                gg *= gs;
-                rowp[s * NR + i] = qb + (int64_t)(i - 1) * d;
-                rs[s * NR + i] = gg;
+        for (int i = 0; i < L; ++i) {
+            if (st.w_upd[i] >= 0) {
+                if (seen == r) { layer = i + 1; w = st.w_upd[i]; }
+                ++seen;
             }
         }
-        if (packed)
-            gram_rows<LPP, VPL, W, L, FULL, true, LR>(rowp, rs, d, valid, idok, do_scale, out, gl, stage);
-        else
-            gram_rows<LPP, VPL, W, L, FULL, false, LR>(rowp, rs, d, valid, idok, do_scale, out, gl, stage);
+    }
+    const uint32_t rb = rb_;                                   // block inside its range (of its layer, for chains)
+    const uint32_t nblk = nblk_;
+#ifdef TPNET_STAMPS
+    // diagnostic build: wall-clock start / end of every block of the stamped step (second half of the stamp buffer)
+    unsigned long long* bst = (st.dbg_layer == -1 && P.base.dbg && bx < 16000) ? P.base.dbg + 65536 + (size_t)bx * 4 : nullptr;
+    if (bst && threadIdx.x == 0) { bst[0] = __builtin_amdgcn_s_memrealtime(); bst[2] = (unsigned long long)(sidx == L ? L + layer - 1 : (sidx > L ? 2 * L : sidx)); }
+#define BEND() do { if (bst) { __syncthreads(); if (threadIdx.x == 0) bst[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define BEND() do { } while (0)
+#endif
+
+    if (sidx == L + 1) {
+        if (st.dbg_skip & 4) return;
+        // ---- readouts of window w_read: (src,dst) and (src,neg) of every edge on the state BEFORE the edge's batch
+        constexpr int NR = C::NR, NN = C::NN;
+        constexpr int RGPB = WB / RLPP;
+        const int rgl = threadIdx.x % RLPP;
+        const int rg = threadIdx.x / RLPP;
+        float* stage = reinterpret_cast<float*>(lds_u);
+        const int d = S.d;
+        const bool packed = (flags & TPNET_FLAG_PACKED) != 0;
+        const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
+        const int ostride = packed ? C::NT : C::NG;
+        const int64_t e0 = w * P.Ew;
+        const int64_t ne = (Ec - e0 < P.Ew) ? Ec - e0 : P.Ew;
+        const int64_t npos = a.out_pos ? ne : 0;
+        const int64_t nneg = a.out_neg ? ne : 0;
+        const int64_t npairs = npos + nneg;
+        const bool both = npos != 0 && nneg != 0;
+        for (int64_t base = (int64_t)rb * RGPB; base < npairs; base += (int64_t)nblk * RGPB) {
+            const int64_t pw = base + rg;
+            const bool valid = pw < npairs;
+            // (src,dst) and (src,neg) of one edge sit in adjacent lane groups: the src rows are fetched by the same instructions
+            const int64_t idx = valid ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
+            const bool isneg = both ? (pw & 1) != 0 : (pw >= npos);
+            const int64_t e = e0 + idx;
+            int64_t ids[2] = {a.src[e], isneg ? a.neg[e] : a.dst[e]};
+            const int which[2] = {0, isneg ? 2 : 1};
+            float* out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
+            const bool idok = valid && (uint64_t)ids[0] < (uint64_t)S.N && (uint64_t)ids[1] < (uint64_t)S.N;
+            if (valid && !idok && rgl == 0) atomicAdd(S.err, 1u);
+            if (!idok) { ids[0] = 0; ids[1] = 0; }
+            const float* rowp[NN];
+            float rs[NN];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint32_t ref = idok ? P.e_ref[(int64_t)which[s] * Ec + e] : WREF_TABLE;
+                const float gs = idok ? P.e_g[(int64_t)which[s] * Ec + e] : 1.0f;
+                const float* qb = (ref & WREF_TABLE) ? S.q + ((int64_t)(ref & 1u) * S.N + ids[s]) * ((int64_t)L * d)
+                                                     : P.log + (int64_t)(ref & WREF_SLOT_MASK) * ((int64_t)L * d);
+                rowp[s * NR] = S.p0 + ids[s] * (int64_t)d;
+                rs[s * NR] = 1.0f;
+                float gg = 1.0f;
+#pragma unroll
+                for (int i = 1; i <= L; ++i) {
+                    gg *= gs;
+                    rowp[s * NR + i] = qb + (int64_t)(i - 1) * d;
+                    rs[s * NR + i] = gg;
+                }
+            }
+            if (packed)
+                gram_rows<RLPP, RVPL, W, L, FULL, true, LR>(rowp, rs, d, valid, idok, do_scale, out, rgl, stage);
+            else
+                gram_rows<RLPP, RVPL, W, L, FULL, false, LR>(rowp, rs, d, valid, idok, do_scale, out, rgl, stage);
+        }
+        BEND();
+        return;
+    }
+    const WinDesc wd = P.wdesc[w];
+    unsigned long long* dbg = (st.dbg_layer == layer) ? P.base.dbg : nullptr;   // stamps of diagnostic builds (-DTPNET_STAMPS)
+    (void)dbg;
+    if (sidx < L) {
+        if (st.dbg_skip & 1) return;
+        const Chain* __restrict__ heavy = P.chains + wd.start;         // the window's longest chains
+        const uint32_t units = wd.n_heavy * (uint32_t)st.CP;
+        for (uint32_t h = rb; h < units; h += nblk)
+            chain_heavy<LPH>(S, P, heavy[h / (uint32_t)st.CP], (int)(h % (uint32_t)st.CP), layer, lambda,
+                             (uint32_t)(w * P.K), lds_u, dbg);
+        BEND();
+        return;
+    }
+    if (st.dbg_skip & 2) return;
+    const Chain* __restrict__ small = P.chains + wd.start + wd.n_heavy;   // the others, longest first: a block's chains are alike
+    const int64_t n_small = (int64_t)wd.n_chains - (int64_t)wd.n_heavy;
+    for (int64_t base = (int64_t)rb * GPB; base < n_small; base += (int64_t)nblk * GPB) {
+        const int64_t idx = base + g;
+        const bool valid = idx < n_small;
+        const Chain c = small[valid ? idx : 0];
+        chain_light<LPP, VPL, FULL>(S, P, c, valid, layer, lambda, gl, dbg);
+    }
+    BEND();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// end of a chunk: the last version of every touched node -> the other copy of its table bundle, meta published
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WB) void k_wwriteback(tpnet_state S, WPlan P, int64_t nc, uint32_t bid) {
+    const int per = S.L * S.d;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    __shared__ uint32_t n_list;
+    __shared__ uint32_t l_pos[WB];
+    __shared__ int32_t l_node[WB];
+    __shared__ int32_t l_copy[WB];
+    // a block scans WB sorted positions for runs that are their node's last in the chunk, lists them in LDS, then all its
+    // threads copy the listed bundles (every load of the copy is independent: two memory round trips per block)
+    for (int64_t j0 = (int64_t)blockIdx.x * WB; j0 < nc; j0 += (int64_t)gridDim.x * WB) {
+        __syncthreads();
+        if (threadIdx.x == 0) n_list = 0;
+        __syncthreads();
+        const int64_t j = j0 + threadIdx.x;
+        if (j < nc && (P.s_ref[j] & WREF_LAST_RUN)) {
+            const int32_t u = P.base.s_target[j];
+            const int c = (int)(meta[u].ver & 1u);
+            const uint32_t k = atomicAdd(&n_list, 1u);
+            l_pos[k] = (uint32_t)j;
+            l_node[k] = u;
+            l_copy[k] = c;
+        }
+        __syncthreads();
+        const uint32_t n = n_list;
+        if ((per & 3) == 0) {
+            const uint32_t pv = (uint32_t)per / 4;
+            for (uint32_t x = threadIdx.x; x < n * pv; x += WB) {
+                const uint32_t k = x / pv, o = x - k * pv;
+                const float4* src = reinterpret_cast<const float4*>(P.log + (int64_t)l_pos[k] * per);
+                float4* dst = reinterpret_cast<float4*>(S.q + ((int64_t)(l_copy[k] ^ 1) * S.N + l_node[k]) * (int64_t)per);
+                dst[o] = src[o];
+            }
+        } else {
+            for (uint32_t x = threadIdx.x; x < n * (uint32_t)per; x += WB) {
+                const uint32_t k = x / (uint32_t)per, o = x - k * (uint32_t)per;
+                S.q[((int64_t)(l_copy[k] ^ 1) * S.N + l_node[k]) * (int64_t)per + o] = P.log[(int64_t)l_pos[k] * per + o];
+            }
+        }
+        if (threadIdx.x < n) {
+            const uint32_t k = threadIdx.x;
+            publish_meta(meta + l_node[k], l_copy[k] ^ 1, P.base.desc[P.s_bc[l_pos[k]]].t_last, bid);
+        }
     }
 }
 
-// heavy-path geometry: lanes per column part
-static inline int heavy_lph(int d) {
-    const int nvec = d / 4;
-    return nvec <= 32 ? 4 : (nvec <= 64 ? 8 : 16);
-}
-
-template <int LPP, int VPL, bool FULL>
-static int launch_wupdate_g(const tpnet_state& st, const WPlan& p, int64_t w, int layer, uint32_t bid, double lambda,
-                            int64_t nc_w, hipStream_t s) {
-    static const int hb_env = getenv("TPNET_DEV_WIN_HB") ? atoi(getenv("TPNET_DEV_WIN_HB")) : 0;
-    const int HB = hb_env > 0 ? hb_env : 768;
-    static const int skip = getenv("TPNET_DEV_WIN_SKIP") ? atoi(getenv("TPNET_DEV_WIN_SKIP")) : 0;   // timing experiments only
-    const int lph = heavy_lph(st.d);
-    const int CP = (st.d / 4 + lph - 1) / lph;
-    constexpr int GPB = WB / LPP;
-    int lb = (int)((nc_w + GPB - 1) / GPB);          // chains <= contributions
-    if (lb > 2048) lb = 2048;
-    if (lb < 1) lb = 1;
-    const dim3 grid((unsigned)(HB + lb));
-    if (lph == 4)
-        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 4>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP, skip);
-    else if (lph == 8)
-        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 8>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP, skip);
-    else
-        hipLaunchKernelGGL((k_wupdate<LPP, VPL, FULL, 16>), grid, dim3(WB), 0, s, st, p, w, layer, bid, lambda, HB, CP, skip);
+int launch_wwriteback(const tpnet_state& st, const WPlan& p, int64_t Ec, uint32_t launch_id, hipStream_t s) {
+    const int64_t nc = 2 * Ec;
+    int grid = (int)((nc + WB - 1) / WB);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_wwriteback, dim3(grid), dim3(WB), 0, s, st, p, nc, launch_id);
+    TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }
 
-int launch_window(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t w, int64_t Ec, int64_t batch,
-                  double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s, hipEvent_t* ev) {
+int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t j, int64_t Ec, int64_t batch,
+                 double lambda, uint32_t flags, hipStream_t s) {
     if ((reinterpret_cast<uintptr_t>(a.out_pos) | reinterpret_cast<uintptr_t>(a.out_neg)) & 15) return TPNET_ERR_BAD_ARG;
     if (st.d % 4 != 0) return TPNET_ERR_BAD_ARG;
-    const int64_t e0 = w * p.Ew;
-    const int64_t ne = (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew;
-    if (ne < 1) return TPNET_ERR_BAD_ARG;
-    // the update walks chains (latency: one lane per 16 bytes of a row, more contributions per round of lanes); the readout
-    // is a long list of independent pairs (throughput: the 16-lane x 2-vector geometry where it applies)
-    static const int ugeo_env = getenv("TPNET_DEV_WIN_UGEOM") ? atoi(getenv("TPNET_DEV_WIN_UGEOM")) : 0;
-    const Geom geo = pick_geom(st.d, ugeo_env == 1);          // (TPNET_DISPATCH_G declares its own `gm`)
-    static const int rgeo_env = getenv("TPNET_DEV_WIN_RGEOM") ? atoi(getenv("TPNET_DEV_WIN_RGEOM")) : 1;
-    const Geom rgeo = pick_geom(st.d, rgeo_env == 1);
-    const bool full = st.d == geo.lpp * geo.vpl * 4;
-    if (ev) (void)hipEventRecord(ev[0], s);
+    const int L = st.L;
+    const int64_t nw = (Ec + p.Ew - 1) / p.Ew;
+    static const int hb_env = getenv("TPNET_DEV_WIN_HB") ? atoi(getenv("TPNET_DEV_WIN_HB")) : 0;
     static const int stamp_layer = getenv("TPNET_DEV_STAMP_LAYER") ? atoi(getenv("TPNET_DEV_STAMP_LAYER")) : 0;
-    WPlan pu = p;
-    for (int layer = 1; layer <= st.L; ++layer) {
-        int rc = TPNET_ERR_BAD_ARG;
-        pu.base.dbg = (layer == stamp_layer) ? p.base.dbg : nullptr;
-#define TPNET_WUPD(LPP_, VPL_) \
-        rc = full ? launch_wupdate_g<LPP_, VPL_, true>(st, pu, w, layer, launch_id, lambda, 2 * ne, s) \
-                  : launch_wupdate_g<LPP_, VPL_, false>(st, pu, w, layer, launch_id, lambda, 2 * ne, s)
-        if (geo.lpp == 4) { TPNET_WUPD(4, 1); }
-        else if (geo.lpp == 8) { TPNET_WUPD(8, 1); }
-        else if (geo.lpp == 16 && geo.vpl == 1) { TPNET_WUPD(16, 1); }
-        else if (geo.lpp == 16) { TPNET_WUPD(16, 2); }
-        else if (geo.lpp == 32 && geo.vpl == 1) { TPNET_WUPD(32, 1); }
-        else if (geo.lpp == 32) { TPNET_WUPD(32, 2); }
-        else if (geo.vpl == 1) { TPNET_WUPD(64, 1); }
-        else { TPNET_WUPD(64, 2); }
-#undef TPNET_WUPD
-        if (rc) return rc;
-        if (ev) (void)hipEventRecord(ev[layer], s);
+    static const int geo_env = getenv("TPNET_DEV_WIN_GEOM") ? atoi(getenv("TPNET_DEV_WIN_GEOM")) : 0;
+    const Geom geo = pick_geom(st.d, geo_env == 1);           // (TPNET_DISPATCH_G declares its own `gm`)
+    const int lph = heavy_lph(geo.lpp, geo.vpl);
+    const int GPB = WB / geo.lpp;
+    static const int rs_env = getenv("TPNET_DEV_WIN_RSPLIT") ? atoi(getenv("TPNET_DEV_WIN_RSPLIT")) : 0;   // (measured: no gain at C2)
+    const bool rsplit = rs_env == 1 && geo.lpp == 32 && geo.vpl == 1 && st.d / 4 > 16;   // rows of 17..32 vectors
+    WStep ws;
+    ws.CP = (st.d / 4 + lph - 1) / lph;
+    static const int stamp_step = getenv("TPNET_DEV_STAMP_STEP") ? atoi(getenv("TPNET_DEV_STAMP_STEP")) : -1;
+    ws.dbg_layer = (stamp_layer == -1 && stamp_step >= 0 && j != stamp_step) ? 0 : stamp_layer;
+    static const int skip_env = getenv("TPNET_DEV_WIN_SKIP") ? atoi(getenv("TPNET_DEV_WIN_SKIP")) : 0;   // timing experiments only
+    ws.dbg_skip = skip_env;
+    const bool have_readout = a.out_pos || a.out_neg;
+    auto win_edges = [&](int64_t w) { const int64_t e0 = w * p.Ew; return (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew; };
+    uint32_t nb = 0;
+    for (int i = 0; i < TPNET_MAX_LAYERS; ++i) ws.w_upd[i] = -1;
+    // hub chains first
+    for (int i = 0; i < L; ++i) {
+        const int64_t w = j - i;
+        ws.seg[i] = nb;
+        if (w >= 0 && w < nw) {
+            ws.w_upd[i] = w;
+            nb += (uint32_t)(hb_env > 0 ? hb_env : 128);
+        }
     }
-    if (a.out_pos || a.out_neg) {
-        const int64_t npairs = (a.out_pos ? ne : 0) + (a.out_neg ? ne : 0);
-        TPNET_DISPATCH_G(rgeo, ({
-            if constexpr (W == 4) {
-                const int grid = grid_for(npairs, WB / LPP, 256 * 16);
-                hipLaunchKernelGGL((k_wreadout<LPP, VPL, L, FULL>), dim3(grid), dim3(WB), 0, s, st, p, a, w, Ec, batch,
-                                   launch_id, lambda, flags);
+    ws.seg[L] = nb;
+    {
+        uint32_t nact = 0, per = 0;
+        for (int i = 0; i < L; ++i) {
+            if (ws.w_upd[i] >= 0) {
+                ++nact;
+                // (chains <= contributions, typically a third of them; the lists are sorted longest first, so a block that
+                // walks a second round of chains gets short ones)
+                static const int lb_env = getenv("TPNET_DEV_WIN_LB") ? atoi(getenv("TPNET_DEV_WIN_LB")) : 0;
+                const uint32_t g_ = (uint32_t)grid_for(2 * win_edges(ws.w_upd[i]) / 3 + 1, GPB, lb_env > 0 ? lb_env : 768);
+                per = g_ > per ? g_ : per;
             }
-        }));
+        }
+        ws.n_active = nact ? nact : 1;
+        nb += nact * per;
     }
-    if (ev) (void)hipEventRecord(ev[st.L + 1], s);
+    ws.seg[L + 1] = nb;
+    ws.w_read = -1;
+    {
+        const int64_t w = j - L;
+        if (have_readout && w >= 0 && w < nw) {
+            ws.w_read = w;
+            const int64_t npairs = (a.out_pos ? win_edges(w) : 0) + (a.out_neg ? win_edges(w) : 0);
+            nb += (uint32_t)grid_for(npairs, rsplit ? WB / 16 : GPB, 256 * 8);
+        }
+    }
+    ws.seg[L + 2] = nb;
+    if (nb == 0) return TPNET_OK;
+    TPNET_DISPATCH_G(geo, ({
+        if constexpr (W == 4) {
+            if constexpr (LPP == 32 && VPL == 1) {
+                if (rsplit)
+                    hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, true>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+                else
+                    hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+            } else {
+                hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+            }
+        } else {
+            return TPNET_ERR_BAD_ARG;
+        }
+    }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }

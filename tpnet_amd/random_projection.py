@@ -139,16 +139,12 @@ class RandomProjectionModule(nn.Module):
         return _lib.State(p0=p0.data_ptr(), q=eng["q"].data_ptr(), meta=eng["meta"].data_ptr(), N=self.node_num,
                           d=self.dim, L=self.num_layer, err=eng["err"].data_ptr())
 
-    _STREAM_CHUNK_EDGES = 2_000_000        # a plan covers at most about this many edges; the C side chunks longer streams
-
     def _workspace(self, max_edges: int, batch: int, stream: bool = False):
-        """Plan workspace.  `stream`: sized for tpnet_run_stream's windowed schedule (plan + the version log of one window)
-        and capped at a fixed chunk of the stream -- the C side walks longer streams chunk by chunk."""
+        """Plan workspace.  `stream`: sized for tpnet_run_stream (the windowed schedule's plan + version log where it applies),
+        capped at one chunk of the stream -- the C side walks longer streams chunk by chunk."""
         eng = self._engine()
         if stream:
-            cap = max(batch, (self._STREAM_CHUNK_EDGES // batch) * batch)
-            need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer,
-                                                            min(max_edges, cap), batch)
+            need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer, max_edges, batch)
         else:
             need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
         if eng["ws"] is None or eng["ws"].numel() < need:
@@ -450,9 +446,11 @@ class RandomProjectionModule(nn.Module):
     # ------------------------------------------------------------------------------------------------------
     # extension: device-resident edge stream (the reference's batch loop, train_link_prediction.py:253-373)
     # ------------------------------------------------------------------------------------------------------
+    default_schedule = "auto"      # run_stream: "auto" | "windowed" | "batch" (see include/tpnet_hip.h, TPNET_FLAG_SCHED_*)
+
     def run_stream(self, src: torch.Tensor, dst: torch.Tensor, neg, t: torch.Tensor, batch_size: int,
                    want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None,
-                   raw: bool = False, packed: bool = False):
+                   raw: bool = False, packed: bool = False, schedule: str = None):
         """For each chronological batch: pre-mlp pairwise features of (src,dst) and (src,neg) on the pre-batch
         state, then update().  src/dst/neg: int64 [E] on the GPU, t: float64 [E] on the GPU.  Returns
         (feat_pos, feat_neg) of shape [E, (2L+2)^2] (None where not requested).  `t_end` = t[-1] if the caller
@@ -483,6 +481,10 @@ class RandomProjectionModule(nn.Module):
             flags |= _lib.FLAG_PACKED
         if self.exact:
             flags |= _lib.FLAG_EAGER_DECAY | _lib.FLAG_SEQUENTIAL
+        schedule = schedule or self.default_schedule
+        if schedule not in ("auto", "windowed", "batch"):
+            raise ValueError("schedule must be 'auto', 'windowed' or 'batch'")
+        flags |= {"auto": 0, "windowed": _lib.FLAG_SCHED_WINDOWED, "batch": _lib.FLAG_SCHED_BATCH}[schedule]
         t_out = C.c_double(0.0)
         _lib.check(_lib.load().tpnet_run_stream(
             C.byref(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
