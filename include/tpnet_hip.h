@@ -237,16 +237,18 @@ int tpnet_gram_unpack(const float* packed, int64_t n, int32_t L, uint32_t flags,
  * the last call (and clears the words), TPNET_OK otherwise. */
 int tpnet_check_errors(const tpnet_state* st, void* stream);
 
-/* Timing aid for bench.py: elapsed milliseconds of `reps` back-to-back tpnet_run_stream calls measured with
- * hipEvents recorded on `stream` (the stream the kernels run on).  The state is advanced `reps` times; the
- * caller resets it.  kernel_ms_out (may be NULL) receives the average PERIOD of the per-batch step launches of
- * the last rep: hipEvent pairs around each chunk's loop of step launches (planning kernels excluded) divided by
- * the number of launches, i.e. kernel duration + the inter-kernel boundary (~1.7 us on MI355X). */
+/* Timing aid for bench.py (not part of the drop-in surface): elapsed milliseconds of `reps` back-to-back tpnet_run_stream
+ * calls measured with hipEvents recorded on `stream` (the stream the kernels run on).  The state is advanced `reps` times;
+ * the caller resets it.  For the LAST rep, hipEvent pairs around each chunk's loop of launches of the dominant kernel (planning
+ * kernels and the write-back excluded) give: kernel_ms_out = their summed time / the number of launches, i.e. the average
+ * launch PERIOD (kernel duration + inter-kernel boundary) of k_step (per-batch schedule: one launch per batch) or k_wpipe
+ * (windowed schedule: one launch per pipeline step); launches_out = those launches; edges_out = the edges they covered
+ * (up to 256 chunks).  Any of the out pointers may be NULL. */
 int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                       const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                       uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
                       void* workspace, size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out,
-                      void* stream);
+                      int64_t* launches_out, int64_t* edges_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,7 @@ SIGNATURES = {
     "tpnet_check_errors": (C.c_int, [_SP, _P]),
     "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                     C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),
-                                    C.POINTER(C.c_float), _P]),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
 }
 
 _lib = None

@@ -40,6 +40,7 @@ struct StepTimer {
     int64_t n = 0, cap = 0;    // pairs recorded / available
     int64_t launches = 0;      // step launches between the recorded pairs
     int64_t batches = 0;       // batches those launches covered
+    int64_t edges = 0;         // edges those launches covered
     // windowed path: L+2 events per timed window (before the first update launch, after each launch)
     hipEvent_t* wev = nullptr;
     int64_t wn = 0, wcap = 0;  // windows recorded / available
@@ -110,14 +111,15 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
             rc = launch_wstep(st, a, p, j, Ec, batch, lambda, flags, s);
             if (rc) return rc;
         }
-        rc = launch_wwriteback(st, p, Ec, lid, s);
-        if (rc) return rc;
         if (timed) {
             (void)hipEventRecord(timer->ev[2 * timer->n + 1], s);
             ++timer->n;
-            timer->launches += nsteps + 1;
+            timer->launches += nsteps;
             timer->batches += nb;
+            timer->edges += Ec;
         }
+        rc = launch_wwriteback(st, p, Ec, lid, s);
+        if (rc) return rc;
     }
     return TPNET_OK;
 }
@@ -193,6 +195,7 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
             ++timer->n;
             timer->launches += nb;
             timer->batches += nb;
+            timer->edges += Ec;
         }
     }
     return TPNET_OK;
@@ -430,7 +433,8 @@ int tpnet_check_errors(const tpnet_state* st, void* stream) {
 int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                       const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                       uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* workspace,
-                      size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out, void* stream) {
+                      size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out, int64_t* launches_out,
+                      int64_t* edges_out, void* stream) {
     int rc = check_state(st);
     if (rc) return rc;
     if (reps < 1 || E < 1 || batch < 1) return TPNET_ERR_BAD_ARG;
@@ -442,7 +446,7 @@ int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
     TPNET_HIP_TRY(hipEventCreate(&e1));
     // event pairs around the step-launch loop of every chunk of the LAST rep (at most 64 chunks)
     StepTimer tm;
-    tm.cap = 64;
+    tm.cap = 256;
     std::vector<hipEvent_t> evs((size_t)(2 * tm.cap));
     for (auto& e : evs) TPNET_HIP_TRY(hipEventCreate(&e));
     tm.ev = evs.data();
@@ -468,6 +472,8 @@ int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
         }
         *kernel_ms_out = tm.launches ? (float)(sum / (double)tm.launches) : 0.f;
     }
+    if (launches_out) *launches_out = tm.launches;
+    if (edges_out) *edges_out = tm.edges;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     for (auto& e : evs) (void)hipEventDestroy(e);
