@@ -19,27 +19,37 @@ def main(cfg, tag):
     lines += ["## kernel-trace --stats (top kernels)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
     for r in list(csv.DictReader(open(ks)))[:8]:
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
-    tr = [r for r in csv.DictReader(open(one(f"{base}/trace/*/*_kernel_trace.csv"))) if "k_step" in r["Kernel_Name"]]
+    alltr = list(csv.DictReader(open(one(f"{base}/trace/*/*_kernel_trace.csv"))))
+    # the dominant kernel: k_wpipe (windowed schedule: one launch per pipeline step) if it ran, else k_step (one per batch)
+    kname = "k_wpipe" if any("k_wpipe" in r["Kernel_Name"] for r in alltr) else "k_step"
+    tr = [r for r in alltr if kname in r["Kernel_Name"]]
     dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr]
     avg = st.mean(dur)
-    bpl = bytes_per_edge(c["d"], 3) * c["B"]
-    lines += ["", f"k_step: {len(dur)} launches, avg {avg:.0f} ns, median {st.median(dur):.0f} ns; grid {tr[0]['Grid_Size_X']} x {tr[0]['Workgroup_Size_X']}, "
+    if kname == "k_step":
+        epl = c["B"]
+    else:
+        # edges per launch: the runs of profile_stream.py cover NB batches per rep; every rep's launches cover all of them
+        nb = int(os.environ.get("PROF_BATCHES", "0")) or None
+        reps = int(os.environ.get("PROF_REPS", "2"))
+        epl = (nb * c["B"] * reps / len(dur)) if nb else c["B"] * 16
+    bpl = bytes_per_edge(c["d"], 3) * epl
+    lines += ["", f"{kname}: {len(dur)} launches, avg {avg:.0f} ns, median {st.median(dur):.0f} ns; grid {tr[0]['Grid_Size_X']} x {tr[0]['Workgroup_Size_X']}, "
               f"VGPR {tr[0]['VGPR_Count']}+{tr[0]['Accum_VGPR_Count']}, LDS {tr[0]['LDS_Block_Size']} B",
-              f"algorithmic bytes per launch = {bytes_per_edge(c['d'], 3)} B/edge x {c['B']} = {bpl / 1e6:.2f} MB -> "
+              f"algorithmic bytes per launch = {bytes_per_edge(c['d'], 3)} B/edge x {epl:.0f} edges = {bpl / 1e6:.2f} MB -> "
               f"achieved {bpl / avg:.1f} GB/s = {bpl / avg / 8000 * 100:.1f} % of 8 TB/s", ""]
     res = {}
     for name in ("fetch", "write"):
         f = one(f"{base}/{name}/*/*_counter_collection.csv")
         if not f:
             continue
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_step" in r["Kernel_Name"]]
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
         if vals:
             res[name] = st.mean(vals)
     if res:
         fetch_b = res.get("fetch", 0) * 1024 * 2        # gfx950: FETCH_SIZE reads 1/2 of wide coalesced reads
         write_b = res.get("write", 0) * 1024
         lines += ["## PMC (separate passes)", "",
-                  f"FETCH_SIZE avg per k_step launch = {res.get('fetch', 0):.1f} KiB (x2 gfx950 correction -> {fetch_b / 1e6:.2f} MB); "
+                  f"FETCH_SIZE avg per {kname} launch = {res.get('fetch', 0):.1f} KiB (x2 gfx950 correction -> {fetch_b / 1e6:.2f} MB); "
                   f"WRITE_SIZE avg = {res.get('write', 0):.1f} KiB ({write_b / 1e6:.2f} MB)",
                   f"memory-side traffic per launch ~ {(fetch_b + write_b) / 1e6:.2f} MB vs algorithmic {bpl / 1e6:.2f} MB "
                   f"(ratio {(fetch_b + write_b) / bpl:.2f}) = {(fetch_b + write_b) / avg:.0f} GB/s on the memory side; " +
@@ -47,7 +57,7 @@ def main(cfg, tag):
                    if (c["U"] + c["I"] + 1) * 7 * c["d"] * 4 < 256e6 else
                    f"state {(c['U'] + c['I'] + 1) * 7 * c['d'] * 4 / 1e9:.0f} GB >> Infinity Cache: this is HBM traffic"), ""]
     import json
-    js = {"config": cfg, "kernel": "k_step", "launches": len(dur), "avg_ns": avg, "median_ns": st.median(dur),
+    js = {"config": cfg, "kernel": kname, "schedule": "windowed" if kname == "k_wpipe" else "batch", "edges_per_launch": epl, "launches": len(dur), "avg_ns": avg, "median_ns": st.median(dur),
           "algorithmic_bytes_per_launch": bpl,
           "fetch_size_kib_avg": res.get("fetch"), "write_size_kib_avg": res.get("write"),
           "traffic_bytes_per_launch": (res.get("fetch", 0) * 1024 * 2 + res.get("write", 0) * 1024) if res else None,
@@ -59,6 +69,6 @@ def main(cfg, tag):
     return res, avg
 
 if __name__ == "__main__":
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     for cfg in sys.argv[2:] or ["C2"]:
         main(cfg, tag)

@@ -13,9 +13,9 @@ print('k_batch_desc launches:', len(idx))
 for start in idx[:3]:
     t0=int(rows[start]['Start_Timestamp'])
     print('--- call starting at row', start)
-    for r in rows[start:start+40]:
+    for r in rows[start:start+34]:
         s=int(r['Start_Timestamp'])-t0; e=int(r['End_Timestamp'])-t0
         n=r['Kernel_Name'].replace('void ','').replace('tpnet::','')[:46]
         print(f"{s/1000:9.1f} {e/1000:9.1f} {(e-s)/1000:7.1f}  {n}  grid {r['Grid_Size_X']}")
-        if 'wwriteback' in r['Kernel_Name']: break
+        if "wwriteback" in r["Kernel_Name"]: break
 PY
