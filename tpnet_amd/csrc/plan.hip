@@ -43,6 +43,12 @@ static bool use_segmented_sort(int64_t batch, size_t nc) {
 }
 
 static size_t sort_tmp_bytes(size_t n, int64_t batch) {
+    // (the size queries below cost microseconds each and the same sizes are asked for several times per call)
+    static thread_local size_t memo_n[4] = {0, 0, 0, 0}, memo_v[4] = {0, 0, 0, 0};
+    static thread_local int64_t memo_b[4] = {0, 0, 0, 0};
+    static thread_local int memo_next = 0;
+    for (int i = 0; i < 4; ++i)
+        if (memo_v[i] && memo_n[i] == n && memo_b[i] == batch) return memo_v[i];
     size_t bytes = 0, bytes32 = 0, bytes_seg = 0;
     uint64_t* kn64 = nullptr;
     uint32_t* kn = nullptr;
@@ -59,7 +65,10 @@ static size_t sort_tmp_bytes(size_t n, int64_t batch) {
         (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes_seg, kn, kn, vn, vn, (unsigned)n, nseg, b, e, 0u, 32u,
                                                   (hipStream_t)0, false);
     }
-    return bytes > bytes_seg ? bytes : bytes_seg;
+    const size_t res = bytes > bytes_seg ? bytes : bytes_seg;
+    memo_n[memo_next] = n; memo_b[memo_next] = batch; memo_v[memo_next] = res;
+    memo_next = (memo_next + 1) & 3;
+    return res;
 }
 
 size_t plan_bytes(int64_t max_edges, int64_t batch) {
@@ -118,9 +127,9 @@ int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out) 
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------
-__global__ void k_batch_desc(BatchDesc* __restrict__ desc, const double* __restrict__ t, int64_t Ec, int64_t B,
-                             int64_t nb, double now_time, const double* __restrict__ t_prev, double lambda, int L) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void batch_desc(int64_t b, BatchDesc* __restrict__ desc, const double* __restrict__ t, int64_t Ec,
+                                           int64_t B, int64_t nb, double now_time, const double* __restrict__ t_prev,
+                                           double lambda, int L) {
     if (b >= nb) return;
     BatchDesc D;
     D.e0 = b * B;
@@ -140,6 +149,17 @@ __global__ void k_batch_desc(BatchDesc* __restrict__ desc, const double* __restr
     desc[b] = D;
 }
 
+struct DescArgs {          // the batch descriptors ride in the last blocks of the key kernels (one launch less per plan)
+    BatchDesc* desc;
+    const double* t;
+    int64_t nb;
+    double now_time;
+    const double* t_prev;
+    double lambda;
+    int L;
+    uint32_t kblocks;      // blocks [0, kblocks) make keys, the rest descriptors
+};
+
 // contribution j of the chunk: batch b = j / (2B); inside the batch the first ne are the src-side scatter-adds
 // (target src[e] <- partner dst[e]), the next ne the dst-side ones.
 __device__ __forceinline__ void decode(int64_t j, int64_t B, int64_t Ec, int64_t& b, int& side, int64_t& e) {
@@ -156,9 +176,15 @@ __device__ __forceinline__ void decode(int64_t j, int64_t B, int64_t Ec, int64_t
 template <typename K>
 __global__ void k_make_keys(K* __restrict__ keys, uint32_t* __restrict__ vals,
                             const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t Ec, int64_t B,
-                            int64_t N, int node_bits, int with_batch, uint32_t* err) {
+                            int64_t N, int node_bits, int with_batch, uint32_t* err, DescArgs da) {
+    if (blockIdx.x >= da.kblocks) {
+        for (int64_t b = (int64_t)(blockIdx.x - da.kblocks) * blockDim.x + threadIdx.x; b < da.nb;
+             b += (int64_t)(gridDim.x - da.kblocks) * blockDim.x)
+            batch_desc(b, da.desc, da.t, Ec, B, da.nb, da.now_time, da.t_prev, da.lambda, da.L);
+        return;
+    }
     const int64_t nc = 2 * Ec;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)da.kblocks * blockDim.x) {
         int64_t b, e;
         int side;
         decode(j, B, Ec, b, side, e);
@@ -287,20 +313,20 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     const int batch_bits = ceil_log2_u64((uint64_t)nb) < 1 ? 1 : ceil_log2_u64((uint64_t)nb);
     if (node_bits + batch_bits > 64) return TPNET_ERR_BAD_ARG;
 
-    hipLaunchKernelGGL(k_batch_desc, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, p.desc, t, Ec, batch, nb,
-                       now_time, t_prev_dev, lambda, (int)st.L);
     int grid = (int)((nc + 255) / 256);
     if (grid > 4096) grid = 4096;
+    const int dgrid = (int)((nb + 255) / 256) > 64 ? 64 : (int)((nb + 255) / 256);
+    const DescArgs da{p.desc, t, nb, now_time, t_prev_dev, lambda, (int)st.L, (uint32_t)grid};
     const bool seg = use_segmented_sort(batch, (size_t)nc);
     const bool narrow = seg || node_bits + batch_bits <= 32;
     uint32_t* k32_in = reinterpret_cast<uint32_t*>(p.keys_in);
     uint32_t* k32_out = reinterpret_cast<uint32_t*>(p.keys_out);
     if (narrow)
-        hipLaunchKernelGGL(k_make_keys<uint32_t>, dim3(grid), dim3(256), 0, s, k32_in, p.vals_in, src, dst, Ec, batch,
-                           st.N, node_bits, seg ? 0 : 1, st.err);
+        hipLaunchKernelGGL(k_make_keys<uint32_t>, dim3(grid + dgrid), dim3(256), 0, s, k32_in, p.vals_in, src, dst, Ec, batch,
+                           st.N, node_bits, seg ? 0 : 1, st.err, da);
     else
-        hipLaunchKernelGGL(k_make_keys<uint64_t>, dim3(grid), dim3(256), 0, s, p.keys_in, p.vals_in, src, dst, Ec, batch,
-                           st.N, node_bits, 1, st.err);
+        hipLaunchKernelGGL(k_make_keys<uint64_t>, dim3(grid + dgrid), dim3(256), 0, s, p.keys_in, p.vals_in, src, dst, Ec, batch,
+                           st.N, node_bits, 1, st.err, da);
     TPNET_HIP_TRY(hipGetLastError());
     size_t tmp = p.sort_tmp_bytes;
     if (seg) {
@@ -438,9 +464,15 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int
 
 template <typename K>
 __global__ void k_make_keys_w(K* __restrict__ keys, uint32_t* __restrict__ vals, const int64_t* __restrict__ src,
-                              const int64_t* __restrict__ dst, int64_t Ec, int64_t B, int64_t N, int batch_bits) {
+                              const int64_t* __restrict__ dst, int64_t Ec, int64_t B, int64_t N, int batch_bits, DescArgs da) {
+    if (blockIdx.x >= da.kblocks) {
+        for (int64_t b = (int64_t)(blockIdx.x - da.kblocks) * blockDim.x + threadIdx.x; b < da.nb;
+             b += (int64_t)(gridDim.x - da.kblocks) * blockDim.x)
+            batch_desc(b, da.desc, da.t, Ec, B, da.nb, da.now_time, da.t_prev, da.lambda, da.L);
+        return;
+    }
     const int64_t nc = 2 * Ec;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)da.kblocks * blockDim.x) {
         int64_t b, e;
         int side;
         decode(j, B, Ec, b, side, e);
@@ -688,22 +720,22 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     const int batch_bits = ceil_log2_u64((uint64_t)nb + 1) < 1 ? 1 : ceil_log2_u64((uint64_t)nb + 1);
     const int key_bits = node_bits + batch_bits;
     if (key_bits > 63 || nb > 65535) return TPNET_ERR_BAD_ARG;
-    hipLaunchKernelGGL(k_batch_desc, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, p.base.desc, t, Ec, batch, nb,
-                       now_time, t_prev_dev, lambda, (int)st.L);
     int grid = (int)((nc + 255) / 256);
     if (grid > 4096) grid = 4096;
+    const int dgrid = (int)((nb + 255) / 256) > 64 ? 64 : (int)((nb + 255) / 256);
+    const DescArgs da{p.base.desc, t, nb, now_time, t_prev_dev, lambda, (int)st.L, (uint32_t)grid};
     const bool narrow = key_bits <= 31;       // (the chain-end bound (node + 1) << batch_bits must not wrap)
     uint32_t* k32_in = reinterpret_cast<uint32_t*>(p.base.keys_in);
     uint32_t* k32_out = reinterpret_cast<uint32_t*>(p.base.keys_out);
     size_t tmp = p.base.sort_tmp_bytes;
     if (narrow) {
-        hipLaunchKernelGGL(k_make_keys_w<uint32_t>, dim3(grid), dim3(256), 0, s, k32_in, p.base.vals_in, src, dst, Ec,
-                           batch, st.N, batch_bits);
+        hipLaunchKernelGGL(k_make_keys_w<uint32_t>, dim3(grid + dgrid), dim3(256), 0, s, k32_in, p.base.vals_in, src, dst, Ec,
+                           batch, st.N, batch_bits, da);
         TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.base.sort_tmp, tmp, k32_in, k32_out, p.base.vals_in, p.base.vals_out,
                                                 (size_t)nc, 0u, (unsigned)key_bits, s, false));
     } else {
-        hipLaunchKernelGGL(k_make_keys_w<uint64_t>, dim3(grid), dim3(256), 0, s, p.base.keys_in, p.base.vals_in, src,
-                           dst, Ec, batch, st.N, batch_bits);
+        hipLaunchKernelGGL(k_make_keys_w<uint64_t>, dim3(grid + dgrid), dim3(256), 0, s, p.base.keys_in, p.base.vals_in, src,
+                           dst, Ec, batch, st.N, batch_bits, da);
         TPNET_HIP_TRY(rocprim::radix_sort_pairs(p.base.sort_tmp, tmp, p.base.keys_in, p.base.keys_out, p.base.vals_in,
                                                 p.base.vals_out, (size_t)nc, 0u, (unsigned)key_bits, s, false));
     }

@@ -84,6 +84,7 @@ class RandomProjectionModule(nn.Module):
         self._param_sig = None                # (data_ptr, _version) of the layer Parameters at the last sync
         self._now_host = float(beginning_time)
         self._launch_id = 1
+        self._now_dirty = False
 
     # ------------------------------------------------------------------------------------------------------
     # plumbing
@@ -101,7 +102,17 @@ class RandomProjectionModule(nn.Module):
         # external readers of `random_projections` / `now_time` see the reference's eager values
         if name == "random_projections" and "_modules" in self.__dict__ and not self.__dict__.get("_params_valid", True):
             self._materialize()
+        elif name == "now_time" and self.__dict__.get("_now_dirty", False):
+            self._sync_now_time()
         return super().__getattr__(name)
+
+    def _sync_now_time(self):
+        """The clock Parameter is written lazily: the hot methods keep the clock on the host (`_now_host`) and mark the
+        Parameter stale instead of launching a fill kernel per call; whoever reads it (attribute access, state_dict, backup,
+        copy, .to()) gets it filled first."""
+        if self.__dict__.get("_now_dirty", False):
+            self.__dict__["_now_dirty"] = False
+            self._parameters["now_time"].data.fill_(self._now_host)
 
     def _sig(self):
         return tuple((p.data_ptr(), p._version, p.device) for p in self._plist())
@@ -143,10 +154,16 @@ class RandomProjectionModule(nn.Module):
         """Plan workspace.  `stream`: sized for tpnet_run_stream (the windowed schedule's plan + version log where it applies),
         capped at one chunk of the stream -- the C side walks longer streams chunk by chunk."""
         eng = self._engine()
-        if stream:
-            need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer, max_edges, batch)
-        else:
-            need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
+        cache = self.__dict__.setdefault("_ws_need", {})
+        need = cache.get((max_edges, batch, stream))
+        if need is None:
+            if stream:
+                need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer, max_edges, batch)
+            else:
+                need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
+            if len(cache) > 64:
+                cache.clear()
+            cache[(max_edges, batch, stream)] = need
         if eng["ws"] is None or eng["ws"].numel() < need:
             eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
         return eng["ws"]
@@ -181,6 +198,7 @@ class RandomProjectionModule(nn.Module):
 
     def _materialize(self):
         """Write the eager matrices P[1..L] (decay applied) into the Parameters (in place)."""
+        self._sync_now_time()
         if self._params_valid:
             return
         st = self._state()
@@ -321,7 +339,7 @@ class RandomProjectionModule(nn.Module):
                    "update")
         self._now_host = next_time
         self._params_valid = False
-        self._parameters["now_time"].data.fill_(next_time)
+        self._now_dirty = True
 
     def get_random_projections(self, node_ids: np.ndarray):
         """models/TPNet.py:101-110: [P[i][node_ids] for i in 0..L]."""
@@ -416,6 +434,7 @@ class RandomProjectionModule(nn.Module):
         for i in range(1, self.num_layer + 1):
             nn.init.zeros_(self._plist()[i])
         self._parameters["now_time"].data = self._parameters["begging_time"].clone()
+        self._now_dirty = False
         if not self.use_matrix:
             nn.init.normal_(self._plist()[0], mean=0, std=1 / math.sqrt(self.dim))
         self._now_host = float(self._parameters["begging_time"].item())
@@ -438,6 +457,7 @@ class RandomProjectionModule(nn.Module):
         """models/TPNet.py:149-157."""
         now_time, layers = random_projections
         self._parameters["now_time"].data = now_time.clone()
+        self._now_dirty = False
         for i in range(1, self.num_layer + 1):
             self._plist()[i].data = layers[i - 1].clone()
         self._params_valid = True
@@ -493,7 +513,7 @@ class RandomProjectionModule(nn.Module):
             ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream()), "run_stream")
         self._now_host = float(t_end) if t_end is not None else float(t_out.value)
         self._params_valid = False
-        self._parameters["now_time"].data.fill_(self._now_host)
+        self._now_dirty = True
         return (out_pos if want_pos else None), (out_neg if want_neg else None)
 
     def check_device_errors(self):
