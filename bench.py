@@ -169,17 +169,18 @@ def main():
 
     # N = 1: configs[1] as is.  N > 1: the SAME graph and table cut over the ranks, weak scaling: the global batch is N*B
     # edges per step (B per GPU), every rank holds the whole edge stream (32 bytes per edge).
-    #   cols (default): column sharding -- every rank keeps d/N columns of every row; the update needs no exchange, the
-    #                   raw Gram entries are reduce-scattered per chunk of steps behind the next chunk's kernels
-    #                   (tpnet_amd/sharded.py: ColumnShardedRunner).
-    #   rows:           row sharding, owner(n) = n % N, one RCCL all-gather of the touched rows per step
-    #                   (ShardedStreamRunner) -- north_star's layout; timed as a second, shorter leg and reported
-    #                   under "row_sharded" (TPNET_BENCH_SHARD=rows makes it the main leg).
+    #   rows (default, `value`): row sharding, BASELINE.json north_star's layout -- owner(n) = n % N, every rank holds ONLY
+    #                   its rows (all layers) + a halo; one RCCL all-gather of the touched rows' bundles per step
+    #                   (tpnet_amd/sharded.py: ShardedStreamRunner).
+    #   cols (ablation, reported under "col_sharded"; TPNET_BENCH_SHARD=cols makes it the main leg): column sharding --
+    #                   every rank keeps d/N columns of every row; the update needs no exchange, the raw Gram entries are
+    #                   reduce-scattered per chunk of steps behind the next chunk's kernels (ColumnShardedRunner).
     Bg = B * world
     cfg_run = dict(cfg, B=Bg)
     src, dst, neg, t, N = make_workload(cfg_run, W + K, 0)
-    shard = os.environ.get("TPNET_BENCH_SHARD", "cols") if (world > 1 or force_dist) else "single"
-    if shard == "cols" and (d % world or (d // world) % 4):
+    shard = os.environ.get("TPNET_BENCH_SHARD", "rows") if (world > 1 or force_dist) else "single"
+    cols_ok = not (d % world or (d // world) % 4)
+    if shard == "cols" and not cols_ok:
         shard = "rows"
     to_dev = lambda x: torch.from_numpy(x).to(dev)
     d_src, d_dst, d_neg, d_t = to_dev(src), to_dev(dst), to_dev(neg), to_dev(t)
@@ -224,9 +225,9 @@ def main():
 
     def rows_leg(k_steps):
         from tpnet_amd.sharded import ShardedStreamRunner
-        m = make_full_module()
-        runner = ShardedStreamRunner(m)
-        m._workspace(max(k_steps, W) * Bg, Bg)
+        runner = ShardedStreamRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L, time_decay_weight=cfg["lam"],
+                                            device=dev, beginning_time=np.float64(0.0), halo_rows=3 * Bg)
+        runner.rp._workspace(max(k_steps, W) * Bg, Bg)
 
         def run(a, b_):
             sl_ = slice(a * Bg, b_ * Bg)
@@ -234,7 +235,20 @@ def main():
             # features stay sharded by the owner of the pair's src node (a sharded decoder consumes them in place)
             runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last, merge_outputs=False)
         el = time_leg(run, k_steps)
-        m.check_device_errors()
+        runner.rp.check_device_errors()
+        return el, runner.table_bytes()
+
+    def cols_leg(k_steps):
+        from tpnet_amd.sharded import ColumnShardedRunner
+        crun = ColumnShardedRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L,
+                                          time_decay_weight=cfg["lam"], device=dev, beginning_time=np.float64(0.0))
+
+        def run(a, b_):
+            sl_ = slice(a * Bg, b_ * Bg)
+            ends = [a * Bg + hi - 1 for _, hi in crun.chunk_bounds((b_ - a) * Bg, Bg)]
+            crun.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, merge="scatter", t_chunk_last=t[ends])
+        el = time_leg(run, k_steps)
+        crun.rp.check_device_errors()
         return el
 
     rp = None
@@ -253,26 +267,17 @@ def main():
         elapsed = time_leg(run, K)
         rp.check_device_errors()
     elif shard == "cols":
-        from tpnet_amd.sharded import ColumnShardedRunner
-        crun = ColumnShardedRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L,
-                                          time_decay_weight=cfg["lam"], device=dev, beginning_time=np.float64(0.0))
-        crun.rp._workspace(min(K * Bg, 2_000_000 + Bg), Bg)
-
-        def run(a, b_):
-            sl_ = slice(a * Bg, b_ * Bg)
-            ends = [a * Bg + hi - 1 for _, hi in crun.chunk_bounds((b_ - a) * Bg, Bg)]
-            crun.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, merge="scatter", t_chunk_last=t[ends])
-        elapsed = time_leg(run, K)
-        crun.rp.check_device_errors()
+        elapsed = cols_leg(K)
     else:
-        elapsed = rows_leg(K)
+        elapsed, row_bytes = rows_leg(K)
 
     par = {"single": "single GPU",
            "cols": f"columns sharded over {world} GPUs ({d // world} of {d} per GPU), global batch {Bg} = {B} per GPU, no "
                    f"per-step collective; the 36 distinct raw Gram entries per pair are reduce-scattered (RCCL) per "
                    f"chunk of ~2M edges behind the next chunk's kernels",
-           "rows": f"rows sharded over {world} GPUs (owner = id % {world}), global batch {Bg} = {B} per GPU, one RCCL "
-                   f"all-gather of touched rows per step"}[shard]
+           "rows": f"rows sharded over {world} GPUs (owner = id % {world}; every GPU holds only its {(N + world - 1) // world} "
+                   f"rows of all {L + 1} layers + {3 * Bg} halo rows), global batch {Bg} = {B} per GPU, one RCCL "
+                   f"all-gather of the touched rows' bundles per step"}[shard]
 
     def emit(row_info=None, roof=None, cpu=None, dropin=None):
         line = {
@@ -286,32 +291,33 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         if row_info is not None:
-            line["row_sharded"] = row_info
+            line["col_sharded"] = row_info
+        if shard == "rows":
+            line["config"]["table_bytes_per_gpu"] = row_bytes
         if dropin is not None:
             line["dropin"] = dropin
         print(json.dumps(line), flush=True)
 
-    # second leg at N > 1: the row-sharded layout on the same workload, fewer steps, behind a watchdog (a collective
-    # that never returns must not cost the main line)
+    # second leg at N > 1: the column-sharded layout (ablation) on the same workload, behind a watchdog (a collective that
+    # never returns must not cost the main line)
     row_info = None
-    if shard == "cols" and os.environ.get("TPNET_BENCH_ROWS_LEG", "1") != "0":
+    if shard == "rows" and cols_ok and world > 1 and os.environ.get("TPNET_BENCH_COLS_LEG", "1") != "0":
         import threading
         state = {"done": False}
 
         def give_up():
             if not state["done"]:
                 if rank == 0:
-                    emit({"error": "row-sharded leg did not finish within 150 s"})
+                    emit({"error": "column-sharded leg did not finish within 150 s"})
                 os._exit(0)
         wd = threading.Timer(150.0, give_up)
         wd.daemon = True
-        kr = min(K, 500)
         try:
             wd.start()
-            el_r = rows_leg(kr)
-            row_info = {"value": kr * Bg / el_r, "unit": "edges/s", "steps": kr, "ms_per_step": el_r * 1e3 / kr,
-                        "parallelism": f"rows sharded over {world} GPUs (owner = id % {world}), one RCCL all-gather of "
-                                       f"touched rows per step"}
+            el_c = cols_leg(K)
+            row_info = {"value": K * Bg / el_c, "unit": "edges/s", "steps": K, "ms_per_step": el_c * 1e3 / K,
+                        "parallelism": f"ablation: columns sharded over {world} GPUs ({d // world} of {d} per GPU), no per-step "
+                                       f"collective; raw Gram entries reduce-scattered per chunk behind the next chunk's kernels"}
         except Exception as ex:                   # noqa: BLE001 -- report, keep the main line
             row_info = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         state["done"] = True

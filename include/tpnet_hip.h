@@ -173,7 +173,8 @@ int tpnet_plan_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
                       void* stream);
 
 /* One fused launch for batch b of a planned stream: readout of the pairs whose src node this rank owns (other
- * output rows are left untouched) + update of the targets it owns (id % own_mod == own_rem; own_mod = 1: all). */
+ * output rows are left untouched) + update of the targets it owns (id % own_mod == own_rem; own_mod = 1: all;
+ * own_mod = 0: ids < own_rem, the owned rows of a compact local table). */
 int tpnet_step_batch(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                      const double* t, int64_t E, int64_t batch, int64_t b, double lambda, uint32_t launch_id,
                      uint32_t flags, int32_t own_mod, int32_t own_rem, float* out_pos, float* out_neg,
@@ -191,6 +192,19 @@ int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, doub
  * run inside ids.  Rows owned by `me` are skipped. */
 int tpnet_unpack_gathered(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* recv,
                           int64_t maxc, const int64_t* offs, int32_t G, int32_t me, void* stream);
+
+/* Compact row shards: a rank's table holds ONLY the rows it owns (local row = global id / G) followed by halo rows, which
+ * per batch receive copies of the other ranks' rows that the batch reads.  Layer 0 is sharded like the others, so whole
+ * bundles travel:
+ *   tpnet_pack_bundles:   out[k][i][:] = P[i][ids[k]] at now_time, i = 0..L          (ids: LOCAL rows of this rank's table)
+ *   tpnet_unpack_bundles: list entry k of the batch's touched nodes (ordered by (owner, node); offs[r] = start of owner r's run)
+ *                         sits at recv[r][k - offs[r]] ([G][maxc][L+1][d] as all-gathered) and is written to local row
+ *                         local_ids[k] (< 0: skip): layer 0 into p0, layers 1..L into the row's current copy, as of now_time.
+ * tpnet_step_batch with own_mod = 0 then restricts the step to the targets / pair sources with local id < own_rem. */
+int tpnet_pack_bundles(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out,
+                       void* stream);
+int tpnet_unpack_bundles(const tpnet_state* st, const int64_t* local_ids, int64_t n, double now_time, const float* recv,
+                         int64_t maxc, const int64_t* offs, int32_t G, void* stream);
 
 /* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
  * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,

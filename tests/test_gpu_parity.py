@@ -859,3 +859,33 @@ def test_c4_wide_keys_chunked_equals_unchunked():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]) and torch.equal(outs[0][2], outs[2][2])
     assert float(outs[0][2][2].abs().max()) > 0
+
+
+def test_in_place_writes_through_data_are_seen():
+    """p.data.copy_() / p.data[idx] = ... on a handed-out Parameter change neither data_ptr nor _version; the
+    engine must still pick them up (the hand-out itself forces the re-import)."""
+    _need_gpu()
+    rng = np.random.RandomState(5)
+    N, d, L, B = 120, 64, 3, 32
+    src, dst, neg, t = _random_stream(rng, N, 4 * B, 1.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    rp = _module(N, d, L, 1e-6, t[0], P0=P0)
+    st = O.OracleState(P0, L, 1e-6, t[0])
+    for b in range(2):
+        s = slice(b * B, (b + 1) * B)
+        rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
+    new1 = (rng.randn(N, d)).astype(np.float32)
+    rp.random_projections[1].data.copy_(torch.from_numpy(new1))          # in place, through .data
+    rp.random_projections[2].data[5] = 7.0
+    st.P[1] = new1.copy(); st.P[2][5] = 7.0
+    s = slice(2 * B, 3 * B)
+    _assert_features(rp.pair_gram(src[s], dst[s]).cpu().numpy(), st, src[s], dst[s], "after in-place writes")
+    rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "after in-place writes + update")
+    # a state_dict() hands out aliases too
+    sd = rp.state_dict()
+    sd["random_projections.3"].zero_()
+    st.P[3][...] = 0
+    s = slice(3 * B, 4 * B)
+    rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "after a write through state_dict()")

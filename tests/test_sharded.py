@@ -92,6 +92,59 @@ def test_plan_touched_single_rank_and_no_neg():
 
 
 # ---------------------------------------------------------------------------------------------------------
+def _relabel_worker(rank, world, port, N, E, B, q):
+    """CPU tier: the host logic of the compact row shard -- local ids of owned and halo rows, per batch."""
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from tpnet_amd.sharded import ShardedStreamRunner
+
+        class _Stub:                                   # stands in for the local module (no GPU in this tier)
+            node_num = (N + world - 1) // world + 3 * B
+        src, dst, neg, t = _stream(2, N, E)
+        run = ShardedStreamRunner(_Stub(), N, 3 * B)
+        ts = lambda x: torch.from_numpy(x)
+        R = run.relabel(ts(src), ts(dst), ts(neg), B)
+        n_cap, H = run.n_cap, run.H
+        ok = True
+        nb = (E + B - 1) // B
+        for b in range(nb):
+            s = slice(b * B, min((b + 1) * B, E))
+            g = np.concatenate([src[s], dst[s], neg[s]])
+            l = np.concatenate([R["src"][s].numpy(), R["dst"][s].numpy(), R["neg"][s].numpy()])
+            own = g % world == rank
+            ok &= bool(np.all(l[own] == g[own] // world))                          # owned rows: n // G
+            ok &= bool(np.all((l[~own] >= n_cap) & (l[~own] < n_cap + H)))         # the rest: this batch's halo
+            # one halo row per distinct remote node of the batch, and the unpack list agrees with the edge relabelling
+            pairs = set(zip(g[~own].tolist(), l[~own].tolist()))
+            ok &= len(pairs) == len({a for a, _ in pairs}) == len({c for _, c in pairs})
+            k0, k1 = int(R["offsets"][b, 0]), int(R["offsets"][b, 0] + R["tot"][b])
+            ent = R["nodes"][k0:k1].numpy(); lid = R["unpack_ids"][k0:k1].numpy()
+            ok &= bool(np.all(lid[ent % world == rank] == -1))
+            ok &= {(int(a), int(c)) for a, c in zip(ent, lid) if c >= 0} == pairs
+            mine = ent[ent % world == rank]
+            o, c = int(R["offsets"][b, rank]), int(R["counts"][b, rank])
+            ok &= bool(np.array_equal(R["pack_ids"][o:o + c].numpy(), mine // world))
+        q.put((rank, ok, n_cap + H))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_shard_relabelling_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    N, E, B = 101, 470, 60
+    procs = [ctx.Process(target=_relabel_worker, args=(r, world, port, N, E, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert all(rows == (N + world - 1) // world + 3 * B for _, _, rows in res)     # rows per rank: N/G + halo, not N
+
+
 def _gpu_worker(rank, world, port, cfg, q):
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -101,34 +154,41 @@ def _gpu_worker(rank, world, port, cfg, q):
         N, d, L, E, B, lam = cfg
         dev = torch.device("cuda:0")
         src, dst, neg, t = _stream(5, N, E)
-        torch.manual_seed(123 + rank)                       # different P[0] draws: the runner must broadcast rank 0's
-        mk = lambda: tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L,
-                                                      time_decay_weight=lam, device="cuda:0", use_matrix=False,
-                                                      beginning_time=np.float64(t[0]), not_scale=False,
-                                                      enforce_dim=d).to(dev)
-        rp = mk()
-        runner = ShardedStreamRunner(rp)
+        P0 = torch.from_numpy((np.random.RandomState(77).randn(N, d) / np.sqrt(d)).astype(np.float32))
+        runner = ShardedStreamRunner.create(node_num=N, edge_num=E, dim=d, num_layer=L, time_decay_weight=lam, device=dev,
+                                            beginning_time=np.float64(t[0]), halo_rows=3 * B, seed=rank)
+        runner.set_full_p0(P0)
+        # the shard holds N/G + halo rows, not N
+        n_cap = (N + world - 1) // world
+        assert runner.rp.node_num == n_cap + 3 * B
+        assert runner.rp.random_projections[0].shape[0] == n_cap + 3 * B
+        full_bytes = N * d * 4 * (1 + 2 * L) + 32 * N
         D = lambda x: torch.from_numpy(x).to(dev)
         fp, fn = runner.run_stream(D(src), D(dst), D(neg), D(t), B)
-        runner.sync_full_state()
-        layers = torch.stack([rp.random_projections[i].detach() for i in range(1, L + 1)]).cpu()
-        rp.check_device_errors()
+        layers = runner.gather_full_layers().cpu()                       # [L+1, N, d], global row order
+        runner.rp.check_device_errors()
         if rank == 0:
-            ref = mk()
-            ref.random_projections[0].data = rp.random_projections[0].detach().clone()
-            rfp, rfn = ref.run_stream(D(src), D(dst), D(neg), D(t), B)
-            rl = torch.stack([ref.random_projections[i].detach() for i in range(1, L + 1)]).cpu()
-            scale = float(rl.abs().max())
+            ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L, time_decay_weight=lam,
+                                                   device="cuda:0", use_matrix=False, beginning_time=np.float64(t[0]),
+                                                   not_scale=False, enforce_dim=d)
+            ref.random_projections[0].data = P0.clone()
+            ref = ref.to(dev)
+            rfp, rfn = ref.run_stream(D(src), D(dst), D(neg), D(t), B, schedule="batch")
+            rl = torch.stack([ref.random_projections[i].detach() for i in range(0, L + 1)]).cpu()
+            scale = float(rl[1:].abs().max())
             q.put(("cmp", float((fp - rfp).abs().max()), float((fn - rfn).abs().max()),
-                   float((layers - rl).abs().max()) / scale, float(rp.now_time.item()) == float(t[-1])))
+                   float((layers[1:] - rl[1:]).abs().max()) / scale, bool(torch.equal(layers[0], rl[0])),
+                   float(runner.rp.now_time.item()) == float(t[-1]), runner.table_bytes(), full_bytes))
         q.put(("layers", rank, layers.numpy()))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(211, 128, 3, 700, 100, 2e-6), (150, 64, 2, 333, 50, 1e-6)])
+@pytest.mark.parametrize("cfg", [(211, 128, 3, 700, 100, 2e-6), (150, 64, 2, 333, 50, 1e-6), (3000, 128, 3, 900, 60, 2e-6)])
 def test_sharded_stream_equals_single_gpu(cfg):
+    """Two ranks (gloo) sharing cuda:0, each holding ONLY its rows (+ halo): features and the re-assembled table equal the
+    single-GPU run; the per-rank table is N/G + halo rows."""
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
     ctx = mp.get_context("spawn")
@@ -144,8 +204,11 @@ def test_sharded_stream_equals_single_gpu(cfg):
     lay = {m[1]: m[2] for m in msgs if m[0] == "layers"}
     # features: same tolerance as the single-GPU parity tests; state: one extra f32 rounding of the pending decay
     assert cmp[1] < 2e-4 and cmp[2] < 2e-4, cmp
-    assert cmp[3] < 1e-5 and cmp[4], cmp
-    np.testing.assert_array_equal(lay[0], lay[1])            # after sync_full_state every rank holds the same table
+    assert cmp[3] < 1e-5 and cmp[4] and cmp[5], cmp
+    np.testing.assert_array_equal(lay[0], lay[1])            # every rank re-assembles the same table
+    N, d, L, E, B, lam = cfg
+    if N >= 3000:                                            # memory: about half of the table per rank (+ 3B halo rows)
+        assert cmp[6] < 0.6 * cmp[7], cmp
 
 
 # =========================================================================================================

@@ -58,6 +58,8 @@ SIGNATURES = {
                                    C.c_uint32, C.c_int32, C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     "tpnet_pack_rows": (C.c_int, [_SP, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "tpnet_unpack_rows": (C.c_int, [_SP, _P, C.c_int64, C.c_double, _P, _P]),
+    "tpnet_pack_bundles": (C.c_int, [_SP, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
+    "tpnet_unpack_bundles": (C.c_int, [_SP, _P, C.c_int64, C.c_double, _P, C.c_int64, _P, C.c_int32, _P]),
     "tpnet_unpack_gathered": (C.c_int, [_SP, _P, C.c_int64, C.c_double, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
     "tpnet_sampler_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_sampler_build": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),

@@ -366,7 +366,7 @@ int tpnet_step_batch(const tpnet_state* st, const int64_t* src, const int64_t* d
     if (rc) return rc;
     const int64_t nb = (E + batch - 1) / batch;
     if (E < 1 || batch < 1 || b < 0 || b >= nb || !src || !dst || !t) return TPNET_ERR_BAD_ARG;
-    if (own_mod < 1 || own_rem < 0 || own_rem >= own_mod) return TPNET_ERR_BAD_ARG;
+    if (own_mod < 0 || own_rem < 0 || (own_mod > 0 && own_rem >= own_mod)) return TPNET_ERR_BAD_ARG;
     if (out_neg && !neg) return TPNET_ERR_BAD_ARG;
     if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
     if (flags & TPNET_FLAG_EAGER_DECAY) return TPNET_ERR_BAD_ARG;   // the sharded path carries the decay lazily
@@ -397,6 +397,22 @@ int tpnet_unpack_rows(const tpnet_state* st, const int64_t* ids, int64_t n, doub
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!ids || !in))) return TPNET_ERR_BAD_ARG;
     return launch_unpack_rows(*st, ids, n, now_time, in, (hipStream_t)stream);
+}
+
+int tpnet_pack_bundles(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out,
+                       void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!ids || !out))) return TPNET_ERR_BAD_ARG;
+    return launch_pack_bundles(*st, ids, n, now_time, lambda, out, (hipStream_t)stream);
+}
+
+int tpnet_unpack_bundles(const tpnet_state* st, const int64_t* local_ids, int64_t n, double now_time, const float* recv,
+                         int64_t maxc, const int64_t* offs, int32_t G, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n < 0 || G < 1 || maxc < 0 || (n > 0 && (!local_ids || !recv || !offs))) return TPNET_ERR_BAD_ARG;
+    return launch_unpack_bundles(*st, local_ids, n, now_time, recv, maxc, offs, G, (hipStream_t)stream);
 }
 
 int tpnet_unpack_gathered(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, const float* recv,

@@ -141,11 +141,8 @@ __device__ __forceinline__ void batch_desc(int64_t b, BatchDesc* __restrict__ de
     D.n_light = 0;
     D.n_heavy = 0;
     const double g = exp(-lambda * (D.t_last - D.now));  // TPNet.py:84-85, f64 then rounded to f32 once
-    double gi = 1.0;
-    for (int i = 0; i < TPNET_MAX_LAYERS; ++i) {
-        gi *= g;
-        D.decay[i] = (i < L) ? (float)gi : 1.0f;
-    }
+    for (int i = 0; i < TPNET_MAX_LAYERS; ++i)
+        D.decay[i] = (i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;     // np.power(g, i) like the reference (TPNet.py:84-85)
     desc[b] = D;
 }
 

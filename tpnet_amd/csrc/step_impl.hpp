@@ -9,6 +9,15 @@
 
 namespace tpnet {
 
+// row sharding: does this rank compute node `id`'s update / the pairs whose src it is?  own_mod > 1: cyclic ownership over the
+// global ids (id % own_mod == own_rem); own_mod == 0: compact local tables, owned rows first (id < own_rem; the rows behind
+// them are the batch's halo: copies of other ranks' rows); own_mod == 1: everything
+__device__ __forceinline__ bool owns(const StreamArgs& a, int64_t id) {
+    if (a.own_mod > 1) return (int32_t)((uint64_t)id % (uint32_t)a.own_mod) == a.own_rem;
+    if (a.own_mod == 0) return id < (int64_t)a.own_rem;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fused per-batch step: readout (src,dst) and (src,neg) on the pre-batch state + update, ONE launch.
 // Blocks [0, HEAVY_BLOCKS) take the heavy update items (one workgroup per target and layer); the others walk a work index
@@ -52,7 +61,7 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
                 const uint32_t n_heavy = Dp->n_heavy;
                 const double t_last = Dp->t_last;
                 if (h / (L * CP) >= n_heavy) break;
-                if (a.own_mod > 1 && (I.target % a.own_mod) != a.own_rem) continue;
+                if (!owns(a, I.target)) continue;
                 update_item_block<LPH, VPL, W, L, FULL, NT, BS>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt,
                                                                 (int)((h / CP) % L), bid, t_last, lambda, part,
                                                                 (int)(h % CP) * LPH * VPL);
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
             const double now = Dp->now;
             const double t_last_p = Dp->t_last;
             // row sharding: a pair is read out by the owner of its src node (the other ranks leave the output row alone)
-            const bool mine = valid && (a.own_mod <= 1 || (int32_t)((uint64_t)u % (uint32_t)a.own_mod) == a.own_rem);
+            const bool mine = valid && owns(a, u);
             if (!__any(mine)) continue;
             if (packed)
                 gram_pair<LPP, VPL, W, L, FULL, true, CAN_FUSE, LR>(S, u, v, mine, bid, now, lambda, do_scale, out, gl, p.dbg, part, fbits,
@@ -154,8 +163,7 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
             const int64_t n_light = (int64_t)Dp->n_light;
             const double t_last = Dp->t_last;
             if ((wave0 - RP) / ISL >= n_light) break;   // wave-uniform: no item of this wave exists (and none later)
-            const bool valid = it < n_light &&
-                               (a.own_mod <= 1 || (I.target % a.own_mod) == a.own_rem);   // targets belong to their owner
+            const bool valid = it < n_light && owns(a, I.target);   // targets belong to their owner
             if constexpr (ISL > 1)
                 update_item_narrow<LPP, L>(S, p.s_partner, p.s_coef, I, valid, bid, t_last, lambda, (int)(threadIdx.x % 16));
             else

@@ -233,6 +233,78 @@ __global__ void k_unpack_gathered(tpnet_state S, const int64_t* __restrict__ ids
     }
 }
 
+// compact row shards (tpnet_amd/sharded.py): whole bundles, layer 0 included -- a rank holds ONLY its own rows plus a halo of
+// the rows the current batch reads from other ranks, so the static layer travels with the others.
+//   pack:   out[k][i][:] = P[i][ids[k]] at `now` (decay applied), i = 0..L
+__global__ void k_pack_bundles(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now, double lambda,
+                               float* __restrict__ out) {
+    const int64_t d = S.d, L = S.L;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        int64_t id = ids[k];
+        if ((uint64_t)id >= (uint64_t)S.N) {
+            if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+            id = 0;
+        }
+        const MetaView m = read_meta(meta, id, READER_BID, now, lambda);
+        const float* qb = S.q + ((int64_t)m.copy * S.N + id) * (L * d);
+        float* o = out + k * (L + 1) * d;
+        for (int64_t r = threadIdx.x; r < (L + 1) * d; r += blockDim.x) {
+            const int64_t i = r / d;
+            if (i == 0) {
+                o[r] = S.p0[id * d + r];
+            } else {
+                float g = m.g;
+                for (int64_t z = 1; z < i; ++z) g *= m.g;
+                o[r] = qb[r - d] * g;
+            }
+        }
+    }
+}
+
+//   unpack: the gathered bundles of one batch -> the halo rows of the local table.  List entry k (the batch's touched nodes
+//   ordered by (owner, node)) of owner r sits at recv[r][k - offs[r]]; it goes to local row local_ids[k] (< 0: skip --
+//   the rank's own nodes).  Layer 0 into p0, layers 1..L into the row's current copy, expressed at `now`.
+__global__ void k_unpack_bundles(tpnet_state S, const int64_t* __restrict__ local_ids, int64_t n, double now,
+                                 const float* __restrict__ recv, int64_t maxc, const int64_t* __restrict__ offs, int G) {
+    const int64_t d = S.d, L = S.L;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    for (int64_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const int64_t id = local_ids[k];
+        if (id < 0) continue;
+        if (id >= S.N) {
+            if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+            continue;
+        }
+        int r = 0;
+        for (int z = 1; z < G; ++z) r = (offs[z] <= k) ? z : r;
+        const float* in = recv + ((int64_t)r * maxc + (k - offs[r])) * ((L + 1) * d);
+        const int c = (int)(meta[id].ver & 1u);
+        float* qb = S.q + ((int64_t)c * S.N + id) * (L * d);
+        for (int64_t x = threadIdx.x; x < (L + 1) * d; x += blockDim.x) {
+            if (x < d) S.p0[id * d + x] = in[x]; else qb[x - d] = in[x];
+        }
+        if (threadIdx.x == 0) meta[id].tref[c] = now;
+    }
+}
+
+int launch_pack_bundles(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
+                        hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_pack_bundles, dim3(grid_for(n, 1, 8192)), dim3(256), 0, s, st, ids, n, now, lambda, out);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+int launch_unpack_bundles(const tpnet_state& st, const int64_t* local_ids, int64_t n, double now, const float* recv,
+                          int64_t maxc, const int64_t* offs, int G, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    hipLaunchKernelGGL(k_unpack_bundles, dim3(grid_for(n, 1, 8192)), dim3(256), 0, s, st, local_ids, n, now, recv, maxc,
+                       offs, G);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------------------------

@@ -78,7 +78,7 @@ struct StreamArgs {
     float* out_pos;
     float* out_neg;
     int32_t own_mod;   // row sharding: this rank computes targets / pairs (by their src node) with id % own_mod == own_rem
-    int32_t own_rem;   // (own_mod = 1: everything)
+    int32_t own_rem;   // (own_mod = 1: everything; own_mod = 0: compact local table, the rank owns ids < own_rem)
 };
 
 // Launch geometry of the fast paths: LPP lanes cooperate on one row (one pair / one target), each lane owning VPL
@@ -136,6 +136,10 @@ int launch_pack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, doubl
 int launch_unpack_gathered(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* recv,
                            int64_t maxc, const int64_t* offs, int G, int me, hipStream_t s);
 int launch_unpack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* in, hipStream_t s);
+int launch_pack_bundles(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
+                        hipStream_t s);
+int launch_unpack_bundles(const tpnet_state& st, const int64_t* local_ids, int64_t n, double now, const float* recv,
+                          int64_t maxc, const int64_t* offs, int G, hipStream_t s);
 
 size_t plan_bytes(int64_t max_edges, int64_t batch);
 int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out);

@@ -46,8 +46,12 @@ class MatrixMemory(nn.Module):
         return self._parameters["matrix"]
 
     def __getattr__(self, name):
-        if name == "matrix" and "_parameters" in self.__dict__ and not self.__dict__.get("_matrix_valid", True):
-            self._materialize()
+        if name == "matrix" and "_parameters" in self.__dict__:
+            # a handed-out Parameter may be written in place through `.data` (the reference's own idiom,
+            # MemoryModel.py:381-384), which neither data_ptr nor _version shows: re-import before the next engine call
+            self.__dict__["_exposed"] = True
+            if not self.__dict__.get("_matrix_valid", True):
+                self._materialize()
         return super().__getattr__(name)
 
     def _signature(self):
@@ -59,7 +63,7 @@ class MatrixMemory(nn.Module):
         if p.device.type != "cuda":
             raise _lib.TPNetHipError("MatrixMemory (tpnet_amd) computes only on a GPU: move the module to a cuda device "
                                      "first; there is no CPU fallback")
-        if self._engine_valid and (not self._matrix_valid or self._sig == self._signature()):
+        if self._engine_valid and (not self._matrix_valid or (self._sig == self._signature() and not self.__dict__.get("_exposed", False))):
             return
         N, H = self.num_node, self.num_hop
         rp = self.__dict__["_rp"]
@@ -74,6 +78,7 @@ class MatrixMemory(nn.Module):
         rp._params_valid = True
         self.__dict__["_engine_valid"] = True
         self.__dict__["_matrix_valid"] = True
+        self.__dict__["_exposed"] = False
         self.__dict__["_sig"] = self._signature()
 
     def _materialize(self):
@@ -90,6 +95,7 @@ class MatrixMemory(nn.Module):
 
     def state_dict(self, *args, **kwargs):
         self._materialize()
+        self.__dict__["_exposed"] = True       # the returned tensors alias the Parameter's storage
         return super().state_dict(*args, **kwargs)
 
     def _load_from_state_dict(self, *args, **kwargs):

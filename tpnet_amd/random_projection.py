@@ -85,6 +85,7 @@ class RandomProjectionModule(nn.Module):
         self._now_host = float(beginning_time)
         self._launch_id = 1
         self._now_dirty = False
+        self._params_exposed = False          # the ParameterList was handed out since the last import (see __getattr__)
 
     # ------------------------------------------------------------------------------------------------------
     # plumbing
@@ -100,8 +101,13 @@ class RandomProjectionModule(nn.Module):
 
     def __getattr__(self, name):
         # external readers of `random_projections` / `now_time` see the reference's eager values
-        if name == "random_projections" and "_modules" in self.__dict__ and not self.__dict__.get("_params_valid", True):
-            self._materialize()
+        if name == "random_projections" and "_modules" in self.__dict__:
+            # whoever gets the ParameterList may write its tensors in place through `.data` (p.data.copy_(), p.data[i] = ...:
+            # the idiom of the reference's MatrixMemory), which changes neither data_ptr nor _version: the next engine call
+            # re-imports the layers (see _ensure_engine)
+            self.__dict__["_params_exposed"] = True
+            if not self.__dict__.get("_params_valid", True):
+                self._materialize()
         elif name == "now_time" and self.__dict__.get("_now_dirty", False):
             self._sync_now_time()
         return super().__getattr__(name)
@@ -183,8 +189,10 @@ class RandomProjectionModule(nn.Module):
                 and self._eng["dev"] == self._plist()[0].device:
             return                              # steady state of the batch loop: the engine is the only truth
         self._engine()
-        if self._engine_valid and self._params_valid and self._param_sig != self._sig():
-            self._engine_valid = False          # Parameters were written behind our back (.data = ..., copy_, ...)
+        if self._engine_valid and self._params_valid and (self._param_sig != self._sig() or self._params_exposed):
+            # Parameters were (or may have been) written behind our back: `.data = ...` / `p.copy_()` show in the signature,
+            # in-place writes through `.data` of a list that was handed out do not -- so a hand-out alone forces the re-import
+            self._engine_valid = False
         if not self._engine_valid:
             if not self._params_valid:
                 raise _lib.TPNetHipError("internal error: neither the engine nor the Parameters hold the state")
@@ -194,6 +202,7 @@ class RandomProjectionModule(nn.Module):
                        "import_layers")
             self._engine_valid = True
             self._param_sig = self._sig()
+            self._params_exposed = False
             self._launch_id = 1
 
     def _materialize(self):
@@ -291,6 +300,7 @@ class RandomProjectionModule(nn.Module):
     # nn.Module hooks that read or write the Parameters wholesale ---------------------------------------------
     def state_dict(self, *args, **kwargs):
         self._materialize()
+        self._params_exposed = True            # the returned tensors alias the Parameters' storage
         return super().state_dict(*args, **kwargs)
 
     def _load_from_state_dict(self, *args, **kwargs):
@@ -482,10 +492,14 @@ class RandomProjectionModule(nn.Module):
         for name, x, dt in (("src", src, torch.int64), ("dst", dst, torch.int64), ("t", t, torch.float64)):
             if x.device != dev or x.dtype != dt or not x.is_contiguous() or x.numel() != E:
                 raise ValueError(f"run_stream: {name} must be a contiguous {dt} tensor of {E} elements on {dev}")
-        if neg is not None and (neg.device != dev or neg.dtype != torch.int64 or neg.numel() != E):
-            raise ValueError("run_stream: neg must be an int64 tensor of the same length on the same device")
+        if neg is not None and (neg.device != dev or neg.dtype != torch.int64 or neg.numel() != E or not neg.is_contiguous()):
+            raise ValueError("run_stream: neg must be a contiguous int64 tensor of the same length on the same device")
         want_neg = want_neg and neg is not None
         NG = self.packed_feature_dim if packed else self.pair_wise_feature_dim
+        for name, o, want in (("out_pos", out_pos, want_pos), ("out_neg", out_neg, want_neg)):
+            if want and o is not None and (o.dtype != torch.float32 or o.device != dev or not o.is_contiguous()
+                                           or tuple(o.shape) != (E, NG)):
+                raise ValueError(f"run_stream: {name} must be a contiguous float32 tensor of shape ({E}, {NG}) on {dev}")
         if want_pos and out_pos is None:
             out_pos = torch.empty((E, NG), dtype=torch.float32, device=dev)
         if want_neg and out_neg is None:

@@ -13,16 +13,17 @@ Row sharding
 
 One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI in production; "gloo" in the tests).
 Rows are owned cyclically, owner(n) = n % G (spreads the power-law head over the ranks).  Every rank holds the
-whole edge stream (32 bytes per edge) and the static layer P[0]; layers 1..L of a row are authoritative on its
-owner only.  Per batch:
+whole edge stream (32 bytes per edge) but ONLY ITS OWN ROWS of the table -- all L+1 layers, in a compact local table
+of ceil(N/G) rows -- plus a halo of H rows that per batch receive the other ranks' rows the batch reads.  Per batch:
 
-  1. pack     the rows this rank owns that the batch touches (src, dst or neg endpoint), decayed to the batch's
-              clock                                                                    (tpnet_pack_rows)
-  2. exchange ONE all-gather of those row bundles (L*d floats per row; the lists are derived from the stream by
+  1. pack     the rows this rank owns that the batch touches (src, dst or neg endpoint): whole bundles, layer 0
+              included, decayed to the batch's clock                                   (tpnet_pack_bundles)
+  2. exchange ONE all-gather of those bundles ((L+1)*d floats per row; the lists are derived from the stream by
               every rank, so no request round is needed)                               (RCCL all_gather)
-  3. unpack   the other ranks' rows into the local table, one launch                    (tpnet_unpack_gathered)
-  4. step     the fused kernel restricted to the targets this rank owns and the pairs whose src it owns: all its
-              reads are pre-batch rows that are either owned or just refreshed         (tpnet_step_batch)
+  3. unpack   the other ranks' bundles into the batch's halo rows, one launch           (tpnet_unpack_bundles)
+  4. step     the fused kernel on the local table and relabelled node ids, restricted to the targets this rank owns
+              and the pairs whose src it owns: all its reads are pre-batch rows that are either owned or just
+              received                                                                 (tpnet_step_batch, own_mod = 0)
 
 Additions are owner-local, so no reduction collective is needed; the readout outputs of the ranks are disjoint
 rows and are merged by one all-reduce at the end of the stream.  Results equal the single-GPU results up to one
@@ -73,124 +74,193 @@ def exchange_rows(send: torch.Tensor, maxc: int, group=None):
 
 
 class ShardedStreamRunner:
-    """Drives a `RandomProjectionModule` (one per rank, identical construction and P[0]) as one row shard."""
+    """ROW shard of the table (BASELINE.json north_star: "shards row-wise ... all-gather only for cross-shard neighbour
+    rows").  Rank `me` of G holds ONLY the rows n with n % G == me -- all L+1 layers, local row n // G -- in a compact
+    `RandomProjectionModule` of n_cap + H rows: n_cap = ceil(N / G) owned rows followed by H HALO rows, which per batch
+    receive copies of the other ranks' rows that the batch reads (src, dst and neg endpoints).  The kernels run on the local
+    table with relabelled node ids (owned: n // G, remote: n_cap + its slot in the batch's halo), restricted to the
+    targets / pair sources the rank owns (tpnet_step_batch, own_mod = 0).  Memory per rank: (n_cap + H) rows instead of N.
+    """
 
-    def __init__(self, rp, group=None):
-        self.rp = rp
+    def __init__(self, rp_local, node_num: int, halo_rows: int, group=None):
+        self.rp = rp_local
         self.group = group
         self.G = dist.get_world_size(group)
         self.me = dist.get_rank(group)
-        # identical layer 0 everywhere (the reference draws it from the device RNG: TPNet.py:58,139)
-        dist.broadcast(rp._plist()[0].data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.N = int(node_num)
+        self.n_cap = (self.N + self.G - 1) // self.G
+        self.H = int(halo_rows)
+        if rp_local.node_num != self.n_cap + self.H:
+            raise ValueError(f"local table has {rp_local.node_num} rows, expected n_cap + halo = {self.n_cap} + {self.H}")
+
+    # ---- construction -------------------------------------------------------------------------------------------
+    @classmethod
+    def create(cls, node_num: int, edge_num: int, dim: int, num_layer: int, time_decay_weight: float, device,
+               beginning_time, halo_rows: int, not_scale: bool = False, group=None, seed: int = 0):
+        """Build the local shard.  `halo_rows` >= the distinct remote nodes one batch can touch (3 * batch is always enough).
+        P[0] ~ N(0, 1/sqrt(dim)) (models/TPNet.py:58): each rank draws its own rows from a generator seeded with (seed,
+        rank); tests inject a full matrix with set_full_p0."""
+        from .random_projection import RandomProjectionModule
+        G = dist.get_world_size(group)
+        n_cap = (node_num + G - 1) // G
+        rp = RandomProjectionModule(node_num=n_cap + int(halo_rows), edge_num=edge_num, dim_factor=1, num_layer=num_layer,
+                                    time_decay_weight=time_decay_weight, device=str(device), use_matrix=False,
+                                    beginning_time=beginning_time, not_scale=not_scale, enforce_dim=dim,
+                                    alloc_device=device)
+        self = cls(rp.to(device), node_num, halo_rows, group)
+        gen = torch.Generator().manual_seed(seed * 1021 + self.me)
+        p0 = self.rp._plist()[0]
+        p0.data[:self.n_cap].copy_(torch.normal(0.0, 1.0 / np.sqrt(dim), (self.n_cap, dim), generator=gen).to(p0.device))
+        p0.data[self.n_cap:].zero_()
+        return self
 
     def owned_nodes(self):
-        return torch.arange(self.me, self.rp.node_num, self.G, dtype=torch.int64, device=self.rp._dev())
+        return torch.arange(self.me, self.N, self.G, dtype=torch.int64, device=self.rp._dev())
+
+    def set_full_p0(self, P0_full: torch.Tensor):
+        """Take this rank's rows of a full [N, d] layer-0 matrix (tests, checkpoints of a single-GPU run)."""
+        own = P0_full[self.me::self.G]
+        p0 = self.rp._plist()[0]
+        p0.data[:own.shape[0]].copy_(own.to(p0.device))
+        self.rp._params_exposed = False
+
+    def table_bytes(self) -> int:
+        """Bytes of table state this rank holds (layer 0 + the two copies of layers 1..L + per-row records)."""
+        rp = self.rp
+        lib = _lib.load()
+        return rp.node_num * rp.dim * 4 + lib.tpnet_q_bytes(rp.node_num, rp.dim, rp.num_layer) + lib.tpnet_meta_bytes(rp.node_num)
+
+    # ---- the stream -----------------------------------------------------------------------------------------------
+    def relabel(self, src, dst, neg, batch_size: int):
+        """Everything the per-batch loop needs, derived from the stream by every rank on its own (no request round):
+        the touched-node lists, the local id of every list entry and of every edge endpoint, the rows to pack."""
+        G, me, N, n_cap = self.G, self.me, self.N, self.n_cap
+        E, B = int(src.numel()), int(batch_size)
+        nb = (E + B - 1) // B
+        dev = src.device
+        nodes, counts, offsets = plan_touched(src, dst, neg, B, N, G)
+        tot = counts.sum(axis=1)
+        start = offsets[:, 0] if nb else np.zeros(0, dtype=np.int64)
+        remote = tot - counts[:, me]
+        if nb and int(remote.max()) > self.H:
+            raise ValueError(f"a batch touches {int(remote.max())} rows of other ranks but the shard has {self.H} halo rows "
+                             f"(3 * batch_size is always enough)")
+        t_tot = torch.from_numpy(tot).to(dev)
+        b_of = torch.repeat_interleave(torch.arange(nb, device=dev), t_tot)                  # batch of every list entry
+        pos = torch.arange(nodes.numel(), device=dev) - torch.from_numpy(start).to(dev)[b_of]   # position inside its batch's list
+        owner = nodes % G
+        cnt_me = torch.from_numpy(counts[:, me]).to(dev)[b_of]
+        slot = pos - torch.where(owner > me, cnt_me, torch.zeros_like(cnt_me))             # among the batch's REMOTE nodes
+        entry_lid = torch.where(owner == me, nodes // G, n_cap + slot)                      # local row of every list entry
+        unpack_ids = torch.where(owner == me, torch.full_like(entry_lid, -1), entry_lid).contiguous()
+        lkeys = (b_of * G + owner) * N + nodes                                               # ascending by construction
+        bidx = torch.arange(E, device=dev, dtype=torch.int64) // B
+
+        def local(x):
+            k = (bidx * G + (x % G)) * N + x
+            return entry_lid[torch.searchsorted(lkeys, k)].contiguous()
+
+        return dict(nodes=nodes, counts=counts, offsets=offsets, tot=tot, unpack_ids=unpack_ids,
+                    pack_ids=(nodes // G).contiguous(), src=local(src), dst=local(dst),
+                    neg=local(neg) if neg is not None else None)
 
     def run_stream(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
-        """Same contract as RandomProjectionModule.run_stream, over all ranks.  Returns (feat_pos, feat_neg): complete
-        on every rank if merge_outputs (one all-reduce of disjoint rows at the end), otherwise each rank holds the
-        rows of the pairs whose src node it owns and zeros elsewhere (a sharded consumer needs no merge)."""
+        """Same contract as RandomProjectionModule.run_stream (global node ids in, per-edge features out), over all ranks.
+        Returns (feat_pos, feat_neg): complete on every rank if merge_outputs (one all-reduce of disjoint rows at the end),
+        otherwise each rank holds the rows of the pairs whose src node it owns and zeros elsewhere."""
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
         dev = rp._dev()
-        E = int(src.numel())
-        B = int(batch_size)
+        E, B = int(src.numel()), int(batch_size)
         nb = (E + B - 1) // B
-        L, d, N = rp.num_layer, rp.dim, rp.node_num
-        row = L * d
+        L, d = rp.num_layer, rp.dim
+        bundle = (L + 1) * d
         NG = rp.pair_wise_feature_dim
         lam = float(rp.time_decay_weight)
         out_pos = torch.zeros((E, NG), dtype=torch.float32, device=dev)
         out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
         if E == 0:
             return out_pos, out_neg
-        nodes, counts, offsets = plan_touched(src, dst, neg, B, N, G)
-        # clock after each batch (host copy: one small device->host transfer per stream)
+        if int(torch.stack([src.min(), dst.min()]).min()) < 0 or int(torch.stack([src.max(), dst.max()]).max()) >= self.N:
+            raise IndexError(f"node id out of range for {self.N} nodes")
+        R = self.relabel(src, dst, neg, B)
+        counts, offsets, tot = R["counts"], R["offsets"], R["tot"]
         last_idx = torch.clamp(torch.arange(1, nb + 1, device=dev) * B, max=E) - 1
         t_last = t[last_idx].cpu().numpy() if t_host_last is None else np.asarray(t_host_last, dtype=np.float64)
         ws = rp._workspace(E, B)
         st = rp._state()
         stream = rp._stream()
         flags = _lib.FLAG_NOT_SCALE if rp.not_scale else 0
-        _lib.check(lib.tpnet_plan_stream(C.byref(st), src.data_ptr(), dst.data_ptr(), t.data_ptr(), E, B, rp._now_host,
+        ls, ld, ln = R["src"], R["dst"], R["neg"]
+        _lib.check(lib.tpnet_plan_stream(C.byref(st), ls.data_ptr(), ld.data_ptr(), t.data_ptr(), E, B, rp._now_host,
                                          lam, flags, ws.data_ptr(), ws.numel(), stream), "plan_stream")
         lid0 = rp._next_launch_ids(nb)
-        maxc_all = int(counts.max()) if counts.size else 0
-        send = torch.zeros((max(maxc_all, 1), row), dtype=torch.float32, device=dev)
-        recv_all = torch.empty((G, max(maxc_all, 1), row), dtype=torch.float32, device=dev)
-        offs_rel = torch.from_numpy(offsets - offsets[:, :1]).to(dev).contiguous()   # [nb, G] owner runs inside a batch
-        tot = counts.sum(axis=1)
+        maxc_all = max(int(counts.max()), 1)
+        send = torch.zeros((maxc_all, bundle), dtype=torch.float32, device=dev)
+        recv_all = torch.empty((G, maxc_all, bundle), dtype=torch.float32, device=dev)
+        offs_rel = torch.from_numpy(offsets - offsets[:, :1]).to(dev).contiguous()          # [nb, G] owner runs inside a batch
         now = rp._now_host
-        nccl = (G > 1 or _FORCE) and dist.get_backend(self.group) == "nccl"
+        exchange = G > 1 or _FORCE
+        nccl = exchange and dist.get_backend(self.group) == "nccl"
         # host-side loop: everything per batch is precomputed as plain ints / raw pointers (the loop issues 3 kernel
         # launches + 1 collective per batch and must not be the bottleneck)
         stp = C.byref(st)
-        nodes_ptr, send_ptr, recv_ptr = nodes.data_ptr(), send.data_ptr(), recv_all.data_ptr()
-        offs_ptr = offs_rel.data_ptr()
+        pack_ptr, unpack_ptr = R["pack_ids"].data_ptr(), R["unpack_ids"].data_ptr()
+        send_ptr, recv_ptr, offs_ptr = send.data_ptr(), recv_all.data_ptr(), offs_rel.data_ptr()
         cnt_me = counts[:, me].tolist(); off_me = offsets[:, me].tolist(); off_0 = offsets[:, 0].tolist()
         maxcs = counts.max(axis=1).tolist(); tots = tot.tolist(); t_last_l = [float(x) for x in t_last]
-        src_p, dst_p, t_p = src.data_ptr(), dst.data_ptr(), t.data_ptr()
-        neg_p = neg.data_ptr() if neg is not None else None
+        ls_p, ld_p, t_p = ls.data_ptr(), ld.data_ptr(), t.data_ptr()
+        ln_p = ln.data_ptr() if ln is not None else None
         op_p = out_pos.data_ptr(); on_p = out_neg.data_ptr() if out_neg is not None else None
         ws_p, ws_n = ws.data_ptr(), ws.numel()
-        pack, unpack, step = lib.tpnet_pack_rows, lib.tpnet_unpack_gathered, lib.tpnet_step_batch
+        pack, unpack, step = lib.tpnet_pack_bundles, lib.tpnet_unpack_bundles, lib.tpnet_step_batch
         flat_recv = recv_all.view(-1)
+        n_own = self.n_cap
         for b in range(nb):
             maxc = maxcs[b]
-            if (G > 1 or _FORCE) and maxc > 0:
-                rc = pack(stp, nodes_ptr + 8 * off_me[b], cnt_me[b], now, lam, send_ptr, stream)
+            if exchange and maxc > 0:
+                rc = pack(stp, pack_ptr + 8 * off_me[b], cnt_me[b], now, lam, send_ptr, stream)
                 if rc:
-                    _lib.check(rc, "pack_rows")
-                # one all-gather of the padded [maxc, L*d] bundles -> recv[G][maxc][L*d] (a dense prefix of recv_all)
-                recv = flat_recv[:G * maxc * row]
+                    _lib.check(rc, "pack_bundles")
+                # one all-gather of the padded [maxc, (L+1)*d] bundles -> recv[G][maxc][(L+1)*d] (a dense prefix of recv_all)
+                recv = flat_recv[:G * maxc * bundle]
                 if nccl:
                     dist.all_gather_into_tensor(recv, send[:maxc].view(-1), group=self.group)
                 else:
-                    dist.all_gather(list(recv.view(G, maxc * row).unbind(0)), send[:maxc].view(-1), group=self.group)
-                # one launch scatters every peer's rows into the local table
-                rc = unpack(stp, nodes_ptr + 8 * off_0[b], tots[b], now, recv_ptr, maxc, offs_ptr + 8 * G * b, G, me, stream)
+                    dist.all_gather(list(recv.view(G, maxc * bundle).unbind(0)), send[:maxc].view(-1), group=self.group)
+                # one launch writes every peer's bundles into this batch's halo rows
+                rc = unpack(stp, unpack_ptr + 8 * off_0[b], tots[b], now, recv_ptr, maxc, offs_ptr + 8 * G * b, G, stream)
                 if rc:
-                    _lib.check(rc, "unpack_gathered")
-            rc = step(stp, src_p, dst_p, neg_p, t_p, E, B, b, lam, lid0 + b, flags, G, me, op_p, on_p, ws_p, ws_n, stream)
+                    _lib.check(rc, "unpack_bundles")
+            rc = step(stp, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, 0, n_own, op_p, on_p, ws_p, ws_n, stream)
             if rc:
                 _lib.check(rc, "step_batch")
             now = t_last_l[b]
         rp._now_host = now
         rp._params_valid = False
-        rp._parameters["now_time"].data.fill_(now)
+        rp._now_dirty = True
         if G > 1 and merge_outputs:
             dist.all_reduce(out_pos, group=self.group)          # disjoint rows: the sum is a merge
             if out_neg is not None:
                 dist.all_reduce(out_neg, group=self.group)
         return out_pos, out_neg
 
-    def sync_full_state(self):
-        """Make every rank's table complete (all-gather of all owned rows), e.g. before a checkpoint."""
-        rp, G, me = self.rp, self.G, self.me
-        rp._ensure_engine()
-        if G == 1:
-            return
-        lib = _lib.load()
-        st = rp._state()
-        stream = rp._stream()
+    def gather_full_layers(self):
+        """All ranks' owned rows interleaved back into global order: [L+1, N, d] on every rank (tests / checkpoints of small
+        tables: N * d * (L+1) * 4 bytes)."""
+        rp, G, N, n_cap = self.rp, self.G, self.N, self.n_cap
         dev = rp._dev()
-        row = rp.num_layer * rp.dim
-        lam = float(rp.time_decay_weight)
-        cnt = [(rp.node_num - r + G - 1) // G for r in range(G)]
-        maxc = max(cnt)
-        send = torch.zeros((maxc, row), dtype=torch.float32, device=dev)
-        ids_me = self.owned_nodes()
-        _lib.check(lib.tpnet_pack_rows(C.byref(st), ids_me.data_ptr(), ids_me.numel(), rp._now_host, lam,
-                                       send.data_ptr(), stream), "pack_rows")
-        recv = exchange_rows(send, maxc, self.group)
+        rows = rp.get_random_projections(torch.arange(n_cap, dtype=torch.int64, device=dev))   # owned rows (+ padding)
+        local = torch.stack(rows).contiguous()                                                  # [L+1, n_cap, d]
+        if G == 1:
+            return local[:, :N]
+        parts = [torch.empty_like(local) for _ in range(G)]
+        dist.all_gather(parts, local, group=self.group)
+        full = torch.empty((local.shape[0], n_cap * G, local.shape[2]), dtype=local.dtype, device=dev)
         for r in range(G):
-            if r == me:
-                continue
-            ids_r = torch.arange(r, rp.node_num, G, dtype=torch.int64, device=dev)
-            _lib.check(lib.tpnet_unpack_rows(C.byref(st), ids_r.data_ptr(), ids_r.numel(), rp._now_host,
-                                             recv[r].data_ptr(), stream), "unpack_rows")
-        rp._params_valid = False
+            full[:, r::G] = parts[r]
+        return full[:, :N]
 
 
 # =====================================================================================================================
