@@ -31,8 +31,10 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 3 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
-                               3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream) */
+#define TPNET_ABI_VERSION 4 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
+                               3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream);
+                               4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
+                                    (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -128,6 +130,49 @@ int tpnet_pair_gram(const tpnet_state* st, const int64_t* u, const int64_t* v, i
  * neighbour is paired with the edge's src AND dst (models/TPNet.py:311-316). */
 int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_t* v1, const int64_t* v2, int64_t n,
                            double now_time, double lambda, uint32_t flags, float* out1, float* out2, void* stream);
+
+/* self.mlp = Linear(F, 4F) -> ReLU -> Linear(4F, F), F = (2L+2)^2 (models/TPNet.py:63-65), as device arrays in the layout
+ * the fused kernel reads coalesced: w1t[k][j] = mlp[0].weight[j][k] ([F][H]), w2t[k][o] = mlp[2].weight[o][k] ([H][F]). */
+typedef struct tpnet_mlp {
+    const float* w1t; /* [F][H] */
+    const float* b1;  /* [H] */
+    const float* w2t; /* [H][F] */
+    const float* b2;  /* [F] */
+    int32_t F;        /* (2L+2)^2 */
+    int32_t H;        /* 4 F */
+} tpnet_mlp;
+
+/* get_pair_wise_feature INCLUDING self.mlp (models/TPNet.py:112-129) in one launch: the features of tpnet_pair_gram stay
+ * in LDS and go through both dense layers in fp32 (vector ALUs; differs from the torch layers in summation order only).
+ * out: device float[n][F]; out_gram (optional, may be NULL): the pre-mlp features [n][F], what a backward pass needs.
+ * Meant for the decoder's short pair lists (models/modules.py:112: n = batch size); any L in 1..4. */
+int tpnet_pair_feature(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
+                       double lambda, uint32_t flags, const tpnet_mlp* mlp, float* out_gram, float* out, void* stream);
+
+/* ---- host-array entry points: what the reference's per-batch calls hand over are HOST numpy arrays (models/TPNet.py:
+ * 74-77, 107, 117; train_link_prediction.py:359-373).  These variants take host pointers, check the ids on the host
+ * (TPNET_ERR_INDEX for an id outside [-N, N); negative ids wrap like ATen indexing), copy them into a slot of a pinned,
+ * device-mapped staging ring and launch kernels that read the slot directly -- no separate host->device copy is enqueued,
+ * and a call costs one FFI crossing.  A tpnet_stage is the ONLY object this library allocates (pinned host memory + one
+ * event per slot); a slot is reused only after the launch that read it has finished (the call waits if the ring wrapped). */
+typedef struct tpnet_stage tpnet_stage;
+int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out);
+int tpnet_stage_destroy(tpnet_stage* stage);
+/* largest n / B the host entry points accept for a stage (slot_bytes / 16, slot_bytes / 24 capped at 2048) */
+int64_t tpnet_stage_max_pairs(const tpnet_stage* stage);
+int64_t tpnet_stage_max_batch(const tpnet_stage* stage);
+
+/* get_pair_wise_feature from host ids: mlp == NULL -> out = the pre-mlp features (tpnet_pair_gram); else out = mlp(features)
+ * and out_gram (optional) the pre-mlp features (tpnet_pair_feature). */
+int tpnet_host_pair_feature(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_u, const int64_t* h_v, int64_t n,
+                            double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* out_gram,
+                            float* out, void* stream);
+
+/* update (models/TPNet.py:67-99) from host arrays, B <= tpnet_stage_max_batch: ONE plan kernel (a single workgroup sorts
+ * the batch's 2B contributions in LDS and writes the item lists) + the step kernel.  workspace: tpnet_workspace_bytes(B, B). */
+int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst,
+                      const double* h_t, int64_t B, double now_time, double lambda, uint32_t launch_id, uint32_t flags,
+                      void* workspace, size_t ws_bytes, void* stream);
 
 /* Workspace for tpnet_update / tpnet_run_stream with at most max_edges edges per call. */
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);

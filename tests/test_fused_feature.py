@@ -1,0 +1,180 @@
+"""get_pair_wise_feature in one launch (tpnet_pair_feature / tpnet_host_pair_feature: readout + self.mlp fused in fp32) and
+the host-array update (tpnet_host_update: one single-workgroup plan kernel + the step kernel), against the separate
+kernels, the torch layers and the numpy oracle.  models/TPNet.py:63-65, 67-99, 112-129."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+
+def _module(N, d, L, lam=1e-6, **kw):
+    from tpnet_amd import RandomProjectionModule
+    args = dict(node_num=N, edge_num=4 * N, dim_factor=10, num_layer=L, time_decay_weight=lam, device="cuda:0",
+                use_matrix=False, beginning_time=np.float64(0.0), not_scale=False, enforce_dim=d)
+    args.update(kw)
+    return RandomProjectionModule(**args).to("cuda:0")
+
+
+def _stream(rng, N, B, nb, hubs=True):
+    out, t0 = [], 0.0
+    for _ in range(nb):
+        src = rng.randint(1, N, B)
+        dst = rng.randint(1, N, B)
+        if hubs:
+            src[rng.rand(B) < 0.3] = 3                       # a hub: > heavy threshold contributions per batch
+            dst[rng.rand(B) < 0.1] = 5
+        t = np.sort(rng.uniform(t0, t0 + 2e5, B))
+        t0 = t[-1]
+        out.append((src.astype(np.int64), dst.astype(np.int64), t))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,L", [(128, 3), (64, 3), (256, 3), (512, 3), (16, 3), (32, 2), (120, 3), (128, 1), (128, 4),
+                                 (256, 4), (30, 3)])
+def test_fused_feature_equals_readout_then_torch_mlp(d, L):
+    """One launch (readout + both dense layers, fp32 fmaf) vs tpnet_pair_gram followed by the torch layers: the features
+    entering the mlp are the same bits, so only the f32 summation order of the two GEMVs differs."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from oracle import tpnet_oracle as O
+    rng = np.random.RandomState(d * 7 + L)
+    N = 300
+    use_matrix = d == 30
+    rp = _module(30 if use_matrix else N, d, L, use_matrix=use_matrix)
+    N = rp.node_num
+    st = O.OracleState(rp.random_projections[0].detach().cpu().numpy(), L, 1e-6, 0.0)
+    for src, dst, t in _stream(rng, N, 100, 3):
+        rp.update(src, dst, t)
+        O.update(st, src, dst, t)
+    for n in (1, 7, 8, 9, 64, 333):
+        u, v = rng.randint(0, N, n).astype(np.int64), rng.randint(0, N, n).astype(np.int64)
+        with torch.no_grad():
+            gram = rp.pair_gram(u, v)
+            want = rp.mlp(gram)
+            got = rp.get_pair_wise_feature(u, v)
+        # the pre-mlp features against the oracle (models/TPNet.py:119-128), the rest against the torch layers
+        np.testing.assert_allclose(gram.cpu().numpy(), O.pair_gram(st, u, v), rtol=1e-4, atol=1e-4)
+        assert got.shape == want.shape
+        err = (got - want).abs().max().item()
+        assert err <= 2e-5 * max(1.0, want.abs().max().item()), (n, err)
+
+
+@pytest.mark.gpu
+def test_fused_feature_gradients_match_autograd():
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    rng = np.random.RandomState(3)
+    rp = _module(200, 128, 3)
+    for src, dst, t in _stream(rng, 200, 64, 2):
+        rp.update(src, dst, t)
+    u, v = rng.randint(0, 200, 500).astype(np.int64), rng.randint(0, 200, 500).astype(np.int64)
+    got = rp.get_pair_wise_feature(u, v)                       # grad mode: fused forward + saved pre-mlp features
+    assert got.requires_grad
+    want = rp.mlp(rp.pair_gram(u, v))
+    gy = torch.randn_like(want)
+    gw = torch.autograd.grad(want, list(rp.mlp.parameters()), gy)
+    gf = torch.autograd.grad(got, list(rp.mlp.parameters()), gy)
+    for a, b in zip(gf, gw):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # an optimizer step changes the weights in place: the fused path must pick the new ones up
+    with torch.no_grad():
+        for p in rp.mlp.parameters():
+            p.add_(0.01)
+        np.testing.assert_allclose(rp.get_pair_wise_feature(u, v).cpu().numpy(), rp.mlp(rp.pair_gram(u, v)).cpu().numpy(),
+                                   rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_non_reference_mlp_keeps_torch():
+    """self.mlp replaced by something the fused kernel does not implement (the goldens use Identity): torch applies it."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    rp = _module(100, 64, 3)
+    rp.mlp = torch.nn.Identity()
+    u = np.arange(1, 50, dtype=np.int64)
+    with torch.no_grad():
+        assert torch.equal(rp.get_pair_wise_feature(u, u[::-1].copy()), rp.pair_gram(u, u[::-1].copy()))
+
+
+@pytest.mark.gpu
+def test_host_entry_points_check_ids_and_wrap_negatives():
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    N = 120
+    rp = _module(N, 64, 3)
+    rng = np.random.RandomState(0)
+    src, dst, t = _stream(rng, N, 50, 1)[0]
+    rp.update(src, dst, t)
+    before = [rp.random_projections[i].detach().clone() for i in range(1, 4)]
+    bad = src.copy(); bad[7] = N
+    with pytest.raises(IndexError):
+        rp.update(bad, dst, t + 1e6)
+    with pytest.raises(IndexError):
+        rp.get_pair_wise_feature(bad, dst)
+    with pytest.raises(IndexError):
+        rp.pair_gram(src, np.full_like(dst, -N - 1))
+    for i in range(3):                                          # a rejected call changes nothing
+        assert torch.equal(rp.random_projections[i + 1].detach(), before[i])
+    rp.check_device_errors()
+    with torch.no_grad():                                       # python-style negative ids index from the end, as ATen does
+        a = rp.get_pair_wise_feature(src - N, dst)
+        b = rp.get_pair_wise_feature(src, dst)
+    assert torch.equal(a, b)
+    rp2 = _module(N, 64, 3)
+    rp2.random_projections[0].data.copy_(rp.random_projections[0].data)
+    rp2.update(src - N, dst - N, t)
+    for i in range(1, 4):
+        assert torch.equal(rp2.random_projections[i].detach(), before[i - 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,L,B", [(128, 3, 1000), (64, 3, 200), (256, 2, 2048), (16, 3, 700), (512, 3, 300), (120, 3, 257),
+                                   (128, 4, 64), (128, 3, 1)])
+def test_single_batch_plan_equals_chunk_planner_and_oracle(d, L, B):
+    """update() from host arrays (tpnet_host_update: k_plan_one) and from device tensors (tpnet_update: k_plan_one) against
+    run_stream on the per-batch schedule (chunk planner: keys + device sort + k_finish): identical item contents, so
+    identical bits; and against the numpy oracle (models/TPNet.py:67-99)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from oracle import tpnet_oracle as O
+    rng = np.random.RandomState(B + d)
+    N = 400
+    rp_h, rp_d, rp_s = _module(N, d, L), _module(N, d, L), _module(N, d, L)
+    P0 = rp_h.random_projections[0].data
+    rp_d.random_projections[0].data.copy_(P0)
+    rp_s.random_projections[0].data.copy_(P0)
+    st = O.OracleState(P0.cpu().numpy(), L, 1e-6, 0.0)
+    batches = _stream(rng, N, B, 4)
+    for src, dst, t in batches:
+        rp_h.update(src, dst, t)
+        rp_d.update(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), t)
+        O.update(st, src, dst, t)
+    cat = lambda k: torch.from_numpy(np.concatenate([b[k] for b in batches])).cuda()
+    rp_s.run_stream(cat(0), cat(1), None, cat(2), B, want_pos=False, want_neg=False, schedule="batch")
+    for i in range(1, L + 1):
+        h = rp_h.random_projections[i].detach()
+        assert torch.equal(h, rp_d.random_projections[i].detach())
+        assert torch.equal(h, rp_s.random_projections[i].detach())
+        np.testing.assert_allclose(h.cpu().numpy(), st.P[i], rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(st.P[i]).max())))
+    assert float(rp_h.now_time) == batches[-1][2][-1]
+    rp_h.check_device_errors()
+
+
+@pytest.mark.gpu
+def test_staging_ring_wraps_under_load():
+    """More calls in flight than the ring has slots, results consumed late: every call must have read ITS ids."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    N = 500
+    rp = _module(N, 128, 3)
+    rng = np.random.RandomState(1)
+    for src, dst, t in _stream(rng, N, 300, 2):
+        rp.update(src, dst, t)
+    pairs = [(rng.randint(0, N, 777).astype(np.int64), rng.randint(0, N, 777).astype(np.int64)) for _ in range(40)]
+    with torch.no_grad():
+        outs = [rp.pair_gram(u, v) for u, v in pairs]           # 40 launches enqueued back to back, ring of 8 slots
+        torch.cuda.synchronize()
+        for (u, v), o in zip(pairs, outs):
+            assert torch.equal(o, rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()))

@@ -29,6 +29,12 @@ class State(C.Structure):
                 ("L", C.c_int32), ("err", C.c_void_p)]
 
 
+class Mlp(C.Structure):
+    """tpnet_mlp: device arrays of self.mlp in the fused kernel's layout (include/tpnet_hip.h)."""
+    _fields_ = [("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2t", C.c_void_p), ("b2", C.c_void_p), ("F", C.c_int32),
+                ("H", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/tpnet_hip.h declares (tests check this)
 _P = C.c_void_p
 _SP = C.POINTER(State)
@@ -70,6 +76,15 @@ SIGNATURES = {
     "tpnet_gram_finish": (C.c_int, [_P, C.c_int64, _P]),
     "tpnet_gram_unpack": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_uint32, _P, _P]),
     "tpnet_check_errors": (C.c_int, [_SP, _P]),
+    "tpnet_pair_feature": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp), _P, _P, _P]),
+    "tpnet_stage_create": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(_P)]),
+    "tpnet_stage_destroy": (C.c_int, [_P]),
+    "tpnet_stage_max_pairs": (C.c_int64, [_P]),
+    "tpnet_stage_max_batch": (C.c_int64, [_P]),
+    "tpnet_host_pair_feature": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp),
+                                          _P, _P, _P]),
+    "tpnet_host_update": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,
+                                    C.c_size_t, _P]),
     "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                     C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),

@@ -320,6 +320,22 @@ int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, 
     if (B < 1 || !src || !dst || !t) return TPNET_ERR_BAD_ARG;  // the reference raises on an empty batch (t[-1])
     if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
     if (plan_bytes(B, B) > ws_bytes) return TPNET_ERR_WORKSPACE;
+    if (B <= plan_one_max_batch()) {
+        // one batch: the plan is ONE single-workgroup kernel (plan.hip, k_plan_one) instead of keys + device sort + finish
+        Plan p{};
+        rc = plan_carve(workspace, ws_bytes, B, B, &p);
+        if (rc) return rc;
+        hipStream_t s = (hipStream_t)stream;
+        rc = plan_one(*st, p, src, dst, t, B, now_time, lambda, flags, s);
+        if (rc) return rc;
+        if (flags & TPNET_FLAG_EAGER_DECAY) {
+            rc = launch_decay_desc(*st, p, 0, s);
+            if (rc) return rc;
+        }
+        StreamArgs a{};
+        a.own_mod = 1;
+        return launch_step(*st, a, p, 0, B, (int32_t)B, lambda, launch_id, flags | ROLE_UPDATE, s);
+    }
     return run_stream_impl(*st, src, dst, nullptr, t, B, B, now_time, lambda, launch_id, flags, nullptr, nullptr,
                            workspace, ws_bytes, (hipStream_t)stream, nullptr);
 }

@@ -1,0 +1,171 @@
+// Host-array entry points of the per-batch API (include/tpnet_hip.h: tpnet_stage_*, tpnet_host_pair_feature,
+// tpnet_host_update).  The reference's callers hand HOST numpy arrays to every call (models/TPNet.py:74-77, 107, 117;
+// train_link_prediction.py:359-373) and the stock path pays one pageable host->device copy per array.  Here the ids are
+// checked and copied into a slot of a pinned, device-mapped ring on the host, and the kernels read the slot directly: the
+// per-batch call is host-bound (a batch is microseconds of GPU work), so what counts is the number of runtime calls per
+// API call -- one kernel launch + one event record for a readout, two launches + one event record for an update.
+#include "tpnet_common.h"
+
+#include <cstring>
+#include <new>
+
+struct tpnet_stage {
+    char* base = nullptr;        // hipHostMalloc'ed (mapped, portable)
+    char* dev_base = nullptr;    // its device address
+    size_t slot_bytes = 0;
+    int32_t n_slots = 0;
+    int32_t pos = 0;
+    hipEvent_t* ev = nullptr;    // recorded behind the launch that reads the slot
+    bool* used = nullptr;
+};
+
+namespace tpnet {
+
+static int stage_acquire(tpnet_stage* sg, size_t bytes, char** host, char** dev) {
+    if (!sg || bytes > sg->slot_bytes) return TPNET_ERR_BAD_ARG;
+    const int k = sg->pos;
+    if (sg->used[k]) TPNET_HIP_TRY(hipEventSynchronize(sg->ev[k]));   // the launch that read this slot last is done
+    *host = sg->base + (size_t)k * sg->slot_bytes;
+    *dev = sg->dev_base + (size_t)k * sg->slot_bytes;
+    return TPNET_OK;
+}
+
+static int stage_release(tpnet_stage* sg, hipStream_t s) {
+    const int k = sg->pos;
+    TPNET_HIP_TRY(hipEventRecord(sg->ev[k], s));
+    sg->used[k] = true;
+    sg->pos = (k + 1) % sg->n_slots;
+    return TPNET_OK;
+}
+
+// ids -> the slot, range-checked; python-style negative ids wrap (ATen indexing semantics, as the reference's P[i][ids])
+static bool copy_ids(int64_t* dst, const int64_t* src, int64_t n, int64_t N) {
+    bool ok = true;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t x = src[i];
+        if (x < 0) x += N;
+        ok &= (uint64_t)x < (uint64_t)N;
+        dst[i] = x;
+    }
+    return ok;
+}
+
+}  // namespace tpnet
+
+using namespace tpnet;
+
+extern "C" {
+
+int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out) {
+    if (!out || slots < 2 || slots > 1024 || slot_bytes < 64) return TPNET_ERR_BAD_ARG;
+    *out = nullptr;
+    tpnet_stage* sg = new (std::nothrow) tpnet_stage();
+    if (!sg) return TPNET_ERR_BAD_ARG;
+    sg->slot_bytes = (slot_bytes + 255) / 256 * 256;
+    sg->n_slots = slots;
+    void* mem = nullptr;
+    if (hipHostMalloc(&mem, sg->slot_bytes * (size_t)slots, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+        delete sg;
+        return TPNET_ERR_HIP;
+    }
+    sg->base = reinterpret_cast<char*>(mem);
+    void* dptr = nullptr;
+    if (hipHostGetDevicePointer(&dptr, mem, 0) != hipSuccess) { (void)hipHostFree(mem); delete sg; return TPNET_ERR_HIP; }
+    sg->dev_base = reinterpret_cast<char*>(dptr);
+    sg->ev = new (std::nothrow) hipEvent_t[slots];
+    sg->used = new (std::nothrow) bool[slots];
+    if (!sg->ev || !sg->used) { (void)hipHostFree(mem); delete[] sg->ev; delete[] sg->used; delete sg; return TPNET_ERR_BAD_ARG; }
+    for (int i = 0; i < slots; ++i) {
+        sg->used[i] = false;
+        if (hipEventCreateWithFlags(&sg->ev[i], hipEventDisableTiming) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipEventDestroy(sg->ev[j]);
+            (void)hipHostFree(mem);
+            delete[] sg->ev; delete[] sg->used; delete sg;
+            return TPNET_ERR_HIP;
+        }
+    }
+    *out = sg;
+    return TPNET_OK;
+}
+
+int tpnet_stage_destroy(tpnet_stage* sg) {
+    if (!sg) return TPNET_OK;
+    for (int i = 0; i < sg->n_slots; ++i) {
+        if (sg->used[i]) (void)hipEventSynchronize(sg->ev[i]);
+        (void)hipEventDestroy(sg->ev[i]);
+    }
+    (void)hipHostFree(sg->base);
+    delete[] sg->ev;
+    delete[] sg->used;
+    delete sg;
+    return TPNET_OK;
+}
+
+int64_t tpnet_stage_max_pairs(const tpnet_stage* sg) { return sg ? (int64_t)(sg->slot_bytes / 16) : 0; }
+
+int64_t tpnet_stage_max_batch(const tpnet_stage* sg) {
+    if (!sg) return 0;
+    const int64_t fit = (int64_t)(sg->slot_bytes / 24), cap = plan_one_max_batch();
+    return fit < cap ? fit : cap;
+}
+
+int tpnet_pair_feature(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
+                       double lambda, uint32_t flags, const tpnet_mlp* mlp, float* out_gram, float* out, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (n < 0 || !mlp || (n > 0 && (!u || !v || !out))) return TPNET_ERR_BAD_ARG;
+    return launch_pair_feature(*st, u, v, n, now_time, lambda, flags, *mlp, out_gram, out, (hipStream_t)stream);
+}
+
+int tpnet_host_pair_feature(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_u, const int64_t* h_v, int64_t n,
+                            double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* out_gram,
+                            float* out, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (n < 0 || (n > 0 && (!h_u || !h_v || !out)) || !stage) return TPNET_ERR_BAD_ARG;
+    if (n == 0) return TPNET_OK;
+    char *host = nullptr, *dev = nullptr;
+    int rc = stage_acquire(stage, (size_t)n * 16, &host, &dev);
+    if (rc) return rc;
+    int64_t* hu = reinterpret_cast<int64_t*>(host);
+    if (!copy_ids(hu, h_u, n, st->N) || !copy_ids(hu + n, h_v, n, st->N)) return TPNET_ERR_INDEX;   // slot not consumed
+    const int64_t* du = reinterpret_cast<const int64_t*>(dev);
+    hipStream_t s = (hipStream_t)stream;
+    if (mlp)
+        rc = launch_pair_feature(*st, du, du + n, n, now_time, lambda, flags, *mlp, out_gram, out, s);
+    else
+        rc = launch_pair_gram(*st, du, du + n, n, now_time, lambda, flags, out, s);
+    if (rc) return rc;
+    return stage_release(stage, s);
+}
+
+int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst,
+                      const double* h_t, int64_t B, double now_time, double lambda, uint32_t launch_id, uint32_t flags,
+                      void* workspace, size_t ws_bytes, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (B < 1 || !h_src || !h_dst || !h_t || !stage) return TPNET_ERR_BAD_ARG;
+    if (B > tpnet_stage_max_batch(stage)) return TPNET_ERR_BAD_ARG;
+    if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
+    if (flags & TPNET_FLAG_EAGER_DECAY) return TPNET_ERR_BAD_ARG;     // (the exact mode's dense decay is tpnet_decay, before this call)
+    Plan p{};
+    int rc = plan_carve(workspace, ws_bytes, B, B, &p);
+    if (rc) return rc;
+    char *host = nullptr, *dev = nullptr;
+    rc = stage_acquire(stage, (size_t)B * 24, &host, &dev);
+    if (rc) return rc;
+    int64_t* hs = reinterpret_cast<int64_t*>(host);
+    if (!copy_ids(hs, h_src, B, st->N) || !copy_ids(hs + B, h_dst, B, st->N)) return TPNET_ERR_INDEX;
+    memcpy(hs + 2 * B, h_t, (size_t)B * 8);
+    const int64_t* ds = reinterpret_cast<const int64_t*>(dev);
+    hipStream_t s = (hipStream_t)stream;
+    rc = plan_one(*st, p, ds, ds + B, reinterpret_cast<const double*>(ds + 2 * B), B, now_time, lambda, flags, s);
+    if (rc) return rc;
+    rc = stage_release(stage, s);                                      // the plan kernel is the only reader of the slot
+    if (rc) return rc;
+    StreamArgs a{};
+    a.own_mod = 1;
+    return launch_step(*st, a, p, 0, B, (int32_t)B, lambda, launch_id, flags | ROLE_UPDATE, s);
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -301,6 +302,161 @@ __global__ void k_finish(Plan p, const K* __restrict__ keys_out, const int64_t* 
     }
 }
 
+static uint32_t heavy_threshold_for(int64_t batch, uint32_t flags) {
+    static const char* thr_env = getenv("TPNET_DEV_HEAVY_THRESHOLD");
+    uint32_t thr = (uint32_t)(batch / 300);
+    thr = thr < HEAVY_THRESHOLD ? HEAVY_THRESHOLD : (thr > 128u ? 128u : thr);
+    if (thr_env) thr = (uint32_t)atoi(thr_env);
+    if (flags & TPNET_FLAG_SEQUENTIAL) thr = 0xFFFFFFFFu;
+    return thr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The plan of ONE batch of up to PLAN_ONE_MAX edges in ONE workgroup (tpnet_update / tpnet_host_update: the per-batch call
+// of the reference's loop, train_link_prediction.py:372): edges staged in LDS, the 2B (target, contribution) keys sorted
+// by rocPRIM's block-level radix sort (stable: the reference's summation order inside a target survives), then exactly
+// what k_make_keys + the device sort + k_finish produce for batch 0 of a chunk -- sorted partner / weight / target arrays,
+// light and heavy item lists, the batch descriptor -- from one launch instead of four.  src / dst / t may live in
+// device-mapped HOST memory (tpnet_host_update): each is read once, coalesced.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BS, int IPT>
+__global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                                 const double* __restrict__ t, int32_t B, int64_t N, int node_bits,
+                                                 double now_time, double lambda, int L, uint32_t heavy_threshold,
+                                                 uint32_t* err) {
+    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
+    constexpr int NC = BS * IPT;
+    __shared__ union U {
+        typename Sort::storage_type sort;
+        struct { uint32_t key[NC]; uint32_t val[NC]; } s;
+    } u;
+    __shared__ uint32_t e_src[NC / 2], e_dst[NC / 2];   // endpoint (0 if out of range) | bit 31: the EDGE has a bad endpoint
+    __shared__ float e_w[NC / 2];
+    __shared__ uint32_t n_light, n_heavy;
+    static_assert(sizeof(U) + 3 * (NC / 2) * 4 + 8 <= 64 * 1024, "k_plan_one: LDS budget");
+    const int tid = threadIdx.x;
+    const int nc = 2 * B;
+    const double t_last = t[B - 1];                      // next_time = node_interact_times[-1]   (TPNet.py:76)
+    if (tid == 0) { n_light = 0; n_heavy = 0; }
+    for (int e = tid; e < B; e += BS) {
+        const int64_t s = src[e], dd = dst[e];
+        const bool oks = (uint64_t)s < (uint64_t)N, okd = (uint64_t)dd < (uint64_t)N;
+        const uint32_t bad = (oks && okd) ? 0u : 0x80000000u;
+        if (bad) atomicAdd(err, 1u);                     // once per bad edge
+        e_src[e] = (oks ? (uint32_t)s : 0u) | bad;
+        e_dst[e] = (okd ? (uint32_t)dd : 0u) | bad;
+        // time weight with the reference's casts (models/TPNet.py:77-78), as contribution()
+        const float x = (float)t_last - (float)t[e];
+        e_w[e] = bad ? 0.0f : expf((float)(-lambda) * x);
+    }
+    __syncthreads();
+    uint32_t keys[IPT], vals[IPT];
+    const uint32_t pad_key = 1u << node_bits;            // above every node id: padding sorts last
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int j = tid * IPT + q;
+        vals[q] = (uint32_t)j;
+        if (j < nc) {
+            const bool side = j >= B;                    // first the src-side scatter-adds, then the dst-side ones (TPNet.py:93-96)
+            const int e = side ? j - B : j;
+            keys[q] = (side ? e_dst[e] : e_src[e]) & 0x7FFFFFFFu;
+        } else {
+            keys[q] = pad_key;
+        }
+    }
+    Sort().sort(keys, vals, u.sort, 0u, (unsigned)(node_bits + 1));
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        u.s.key[tid * IPT + q] = keys[q];
+        u.s.val[tid * IPT + q] = vals[q];
+    }
+    __syncthreads();
+    auto contrib = [&](uint32_t val, int32_t& partner, float& w) {
+        const bool side = val >= (uint32_t)B;
+        const int e = side ? (int)val - B : (int)val;
+        const uint32_t es = e_src[e], ed = e_dst[e];
+        const bool ok = !(es & 0x80000000u);
+        partner = ok ? (int32_t)((side ? es : ed) & 0x7FFFFFFFu) : 0;
+        w = ok ? e_w[e] : 0.0f;
+    };
+    for (int j = tid; j < nc; j += BS) {
+        const uint32_t key = u.s.key[j];
+        int32_t partner;
+        float w;
+        contrib(u.s.val[j], partner, w);
+        p.s_partner[j] = partner;
+        p.s_coef[j] = w;
+        p.s_target[j] = (int32_t)key;
+        if (j == 0 || u.s.key[j - 1] != key) {
+            // run length by galloping + binary search on the sorted keys (LDS)
+            int lo = j, hi, step = 1;
+            for (;;) {
+                const int nx = lo + step;
+                if (nx >= nc) { hi = nc; break; }
+                if (u.s.key[nx] != key) { hi = nx; break; }
+                lo = nx;
+                step <<= 1;
+            }
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (u.s.key[mid] == key) lo = mid; else hi = mid;
+            }
+            Item it;
+            it.j0 = (uint32_t)j;
+            it.cnt = (uint32_t)(hi - j);
+            it.target = (int32_t)key;
+            it.p0 = partner;
+            it.w0 = w;
+            it.p1 = 0;
+            it.w1 = 0.0f;
+            it.pad = 0;
+            if (it.cnt >= 2) contrib(u.s.val[j + 1], it.p1, it.w1);
+            if (it.cnt > heavy_threshold) p.heavy[atomicAdd(&n_heavy, 1u)] = it;
+            else p.light[atomicAdd(&n_light, 1u)] = it;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        BatchDesc D;
+        D.e0 = 0;
+        D.ne = B;
+        D.pad = 0;
+        D.t_last = t_last;
+        D.now = now_time;
+        D.n_light = n_light;
+        D.n_heavy = n_heavy;
+        const double g = exp(-lambda * (t_last - now_time));
+        for (int i = 0; i < TPNET_MAX_LAYERS; ++i)
+            D.decay[i] = (i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;
+        p.desc[0] = D;
+    }
+}
+
+int64_t plan_one_max_batch() {
+    static const int off = getenv("TPNET_DEV_NO_PLAN_ONE") ? 1 : 0;     // developer override: always the chunk planner
+    return off ? 0 : PLAN_ONE_MAX;
+}
+
+int plan_one(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
+             double now_time, double lambda, uint32_t flags, hipStream_t s) {
+    if (B < 1 || B > PLAN_ONE_MAX) return TPNET_ERR_BAD_ARG;
+    const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
+    if (node_bits > 31) return TPNET_ERR_BAD_ARG;
+    const uint32_t thr = heavy_threshold_for(B, flags);
+    if (2 * B <= 256 * 4)
+        hipLaunchKernelGGL((k_plan_one<256, 4>), dim3(1), dim3(256), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits, now_time,
+                           lambda, (int)st.L, thr, st.err);
+    else if (2 * B <= 256 * 8)
+        hipLaunchKernelGGL((k_plan_one<256, 8>), dim3(1), dim3(256), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits, now_time,
+                           lambda, (int)st.L, thr, st.err);
+    else
+        hipLaunchKernelGGL((k_plan_one<256, 16>), dim3(1), dim3(256), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits, now_time,
+                           lambda, (int)st.L, thr, st.err);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t,
                int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda, uint32_t flags,
                hipStream_t s) {
@@ -344,11 +500,7 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     // bound by the longest dependent chain, so the bar is low (8); big batches are bound by throughput and by the serial
     // loop of the reserved heavy workgroups, so only real hubs qualify (measured optimum ~B/300 on Reddit- and
     // LastFM-shaped streams at B = 10 000).
-    static const char* thr_env = getenv("TPNET_DEV_HEAVY_THRESHOLD");
-    uint32_t thr = (uint32_t)(batch / 300);
-    thr = thr < HEAVY_THRESHOLD ? HEAVY_THRESHOLD : (thr > 128u ? 128u : thr);
-    if (thr_env) thr = (uint32_t)atoi(thr_env);
-    if (flags & TPNET_FLAG_SEQUENTIAL) thr = 0xFFFFFFFFu;
+    const uint32_t thr = heavy_threshold_for(batch, flags);
     const int fuse = ((flags & PLAN_FUSE) && p.fuse_src) ? 1 : 0;
     if (fuse) TPNET_HIP_TRY(hipMemsetAsync(p.fuse_src, 0, 2 * (size_t)Ec, s));   // after the sort: the bytes were keys_in
     if (narrow)

@@ -141,6 +141,15 @@ int launch_pack_bundles(const tpnet_state& st, const int64_t* ids, int64_t n, do
 int launch_unpack_bundles(const tpnet_state& st, const int64_t* local_ids, int64_t n, double now, const float* recv,
                           int64_t maxc, const int64_t* offs, int G, hipStream_t s);
 
+int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
+                        uint32_t flags, const tpnet_mlp& m, float* out_gram, float* out, hipStream_t s);
+
+// the plan of ONE batch by one workgroup (plan.hip, k_plan_one): same Plan contents as plan_build for batch 0 of a chunk
+static constexpr int64_t PLAN_ONE_MAX = 2048;
+int64_t plan_one_max_batch();      // PLAN_ONE_MAX (0 with the developer override TPNET_DEV_NO_PLAN_ONE)
+int plan_one(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
+             double now_time, double lambda, uint32_t flags, hipStream_t s);
+
 size_t plan_bytes(int64_t max_edges, int64_t batch);
 int plan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, Plan* out);
 int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t,

@@ -22,8 +22,35 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import fused_feature as _ff
 
 _MAX_LAUNCH_ID = 0x7FFFFFFF - (1 << 24)
+
+
+# the current stream's raw handle without building a torch.cuda.Stream object (the hot methods need it every call)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+
+
+class _Stage:
+    """The pinned, device-mapped staging ring of the host-array entry points (tpnet_stage_*): 8 slots of 256 KB, i.e. up to
+    16 384 pairs or one batch of up to 2 048 edges per call.  The only thing the C library allocates; freed with the engine."""
+
+    def __init__(self, lib, dev, slots: int = 8, slot_bytes: int = 256 * 1024):
+        self._lib = lib
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(lib.tpnet_stage_create(slots, slot_bytes, C.byref(h)), "stage_create")
+        self.handle = h
+        self.max_pairs = int(lib.tpnet_stage_max_pairs(h))
+        self.max_batch = int(lib.tpnet_stage_max_batch(h))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.tpnet_stage_destroy(self.handle)
+                self.handle = None
+        except Exception:       # interpreter shutdown: the runtime may be gone already
+            pass
 
 
 class RandomProjectionModule(nn.Module):
@@ -144,9 +171,48 @@ class RandomProjectionModule(nn.Module):
                 q = torch.empty(lib.tpnet_q_bytes(N, d, L) // 4, dtype=torch.float32, device=dev)
                 meta = torch.empty(lib.tpnet_meta_bytes(N), dtype=torch.uint8, device=dev)
                 err = torch.zeros(4, dtype=torch.int32, device=dev)
-            self._eng = dict(dev=dev, q=q, meta=meta, err=err, ws=None)
+            self._eng = dict(dev=dev, dev_index=dev.index if dev.index is not None else torch.cuda.current_device(), q=q,
+                             meta=meta, err=err, ws=None, stage=_Stage(lib, dev))
             self._engine_valid = False
+            self.__dict__["_st_cache"] = None
         return self._eng
+
+    def _st_ref(self):
+        """byref of the tpnet_state struct, rebuilt only when P[0]'s storage or the engine buffers changed."""
+        ptr = self._plist()[0].data_ptr()
+        c = self.__dict__.get("_st_cache")
+        if c is None or c[0] != ptr or c[1] is not self._eng:
+            st = self._state()
+            c = (ptr, self._eng, st, C.byref(st))
+            self.__dict__["_st_cache"] = c
+        return c[3]
+
+    @staticmethod
+    def _host_ids(ids, what):
+        """Host ids as a contiguous one-dimensional int64 numpy array (no copy when they already are: the reference's callers
+        pass exactly that), or None for a torch tensor.  The range check happens in the C call that stages them."""
+        if type(ids) is not np.ndarray:
+            if isinstance(ids, torch.Tensor):
+                return None
+            ids = np.asarray(ids)
+        if ids.dtype != np.int64 or not ids.flags.c_contiguous:
+            ids = np.ascontiguousarray(ids, dtype=np.int64)
+        if ids.ndim != 1:
+            raise ValueError(f"{what} must be one-dimensional")
+        return ids
+
+    def _host_readout(self, u, v, n, flags, width, mlp_ref=None, out_gram=None):
+        """One FFI call: ids checked + staged on the host, ONE kernel (readout, or readout + self.mlp when mlp_ref)."""
+        eng = self._eng
+        out = torch.empty((n, width), dtype=torch.float32, device=eng["dev"])
+        if n:
+            rc = _lib.load().tpnet_host_pair_feature(
+                self._st_ref(), eng["stage"].handle, u.ctypes.data, v.ctypes.data, n, self._now_host,
+                float(self.time_decay_weight), flags, mlp_ref, out_gram.data_ptr() if out_gram is not None else None,
+                out.data_ptr(), _raw_stream(eng["dev_index"]))
+            if rc:
+                _lib.check(rc, "host_pair_feature")
+        return out
 
     def _state(self) -> _lib.State:
         eng = self._engine()
@@ -279,7 +345,7 @@ class RandomProjectionModule(nn.Module):
         if self._eng is not None and not self._params_valid:
             self._materialize()                                    # the Parameters carry the state into the copy
         d = dict(self.__dict__)
-        for k in ("_eng", "_pin_ring", "_param_refs"):
+        for k in ("_eng", "_pin_ring", "_param_refs", "_st_cache"):
             d.pop(k, None)
         d["_eng"] = None
         d["_engine_valid"] = False
@@ -329,24 +395,41 @@ class RandomProjectionModule(nn.Module):
             raise ValueError("src_node_ids, dst_node_ids and node_interact_times must have the same length")
         self._ensure_engine()
         lib = _lib.load()
-        src, dst, t_dev = self._to_device(self._check_ids(src_node_ids, "src_node_ids"),
-                                          self._check_ids(dst_node_ids, "dst_node_ids"), t)
         next_time = float(t[-1])
         B = int(t.size)
-        st = self._state()
         lam = float(self.time_decay_weight)
         flags = 0
+        src_h, dst_h = self._host_ids(src_node_ids, "src_node_ids"), self._host_ids(dst_node_ids, "dst_node_ids")
+        host = src_h is not None and dst_h is not None and B <= self._eng["stage"].max_batch
+        if host and self.exact:
+            # range check BEFORE anything is enqueued (the exact mode's decay below is a state change; otherwise the C call
+            # checks the ids on the host before it launches anything)
+            for ids, what in ((src_h, "src_node_ids"), (dst_h, "dst_node_ids")):
+                if ids.min() < -self.node_num or ids.max() >= self.node_num:
+                    raise IndexError(f"{what}: index out of range for {self.node_num} nodes")
+        elif not host:
+            src, dst, t_dev = self._to_device(self._check_ids(src_node_ids, "src_node_ids"),
+                                              self._check_ids(dst_node_ids, "dst_node_ids"), t)
         if self.exact:
             # the factor exactly as the reference forms it: f64 numpy, rounded to f32 once (TPNet.py:84-85)
             g = np.exp(-self.time_decay_weight * (np.float64(next_time) - np.float64(self._now_host)))
             fac = (C.c_float * self.num_layer)(*[np.float32(np.power(g, i)) for i in range(1, self.num_layer + 1)])
-            _lib.check(lib.tpnet_decay(C.byref(st), fac, next_time, self._stream()), "decay")
+            _lib.check(lib.tpnet_decay(self._st_ref(), fac, next_time, self._stream()), "decay")
             flags |= _lib.FLAG_SEQUENTIAL
         ws = self._workspace(B, B)
         lid = self._next_launch_ids(1)
-        _lib.check(lib.tpnet_update(C.byref(st), src.data_ptr(), dst.data_ptr(), t_dev.data_ptr(), B, self._now_host,
-                                    lam, lid, flags, ws.data_ptr(), ws.numel(), self._stream()),
-                   "update")
+        if host:
+            # host arrays (what the reference's loop passes, train_link_prediction.py:372): one FFI call = staging + one
+            # single-workgroup plan kernel + the step kernel
+            rc = lib.tpnet_host_update(self._st_ref(), self._eng["stage"].handle, src_h.ctypes.data, dst_h.ctypes.data,
+                                       t.ctypes.data, B, self._now_host, lam, lid, flags, ws.data_ptr(), ws.numel(),
+                                       _raw_stream(self._eng["dev_index"]))
+            if rc:
+                _lib.check(rc, "host_update")
+        else:
+            _lib.check(lib.tpnet_update(self._st_ref(), src.data_ptr(), dst.data_ptr(), t_dev.data_ptr(), B, self._now_host,
+                                        lam, lid, flags, ws.data_ptr(), ws.numel(), self._stream()),
+                       "update")
         self._now_host = next_time
         self._params_valid = False
         self._now_dirty = True
@@ -377,6 +460,13 @@ class RandomProjectionModule(nn.Module):
         self._ensure_engine()
         if len(src_node_ids) != len(dst_node_ids):
             raise ValueError("src_node_ids and dst_node_ids must have the same length")
+        uh, vh = self._host_ids(src_node_ids, "src_node_ids"), self._host_ids(dst_node_ids, "dst_node_ids")
+        if uh is not None and vh is not None and uh.size <= self._eng["stage"].max_pairs:
+            flags = _lib.FLAG_NOT_SCALE if (self.not_scale or raw or packed) else 0
+            if packed:
+                flags |= _lib.FLAG_PACKED
+            return self._host_readout(uh, vh, uh.size, flags,
+                                      self.packed_feature_dim if packed else self.pair_wise_feature_dim)
         u, v = self._to_device(self._check_ids(src_node_ids, "src_node_ids"),
                                self._check_ids(dst_node_ids, "dst_node_ids"))
         n = u.numel()
@@ -418,6 +508,11 @@ class RandomProjectionModule(nn.Module):
             return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
         src = np.asarray(src_node_ids)
         n = len(src)
+        if n <= _ff.MAX_PAIRS and not self.fused_mlp and not isinstance(dst_node_ids, torch.Tensor):
+            # the decoder's call (models/modules.py:112: n = batch size): readout AND self.mlp in one launch, fp32
+            fused = self._fused_feature(src, dst_node_ids, n)
+            if fused is not None:
+                return fused
         # (rows of <= 128 floats: the generic kernel's 16-lane geometry is as fast on long lists; measured)
         if self.dim > 128 and n >= 2 and n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:]):
             dst = np.asarray(dst_node_ids)
@@ -431,6 +526,26 @@ class RandomProjectionModule(nn.Module):
         row order (all (node, first) pairs, then all (node, second) pairs)."""
         g1, g2 = self.pair_gram_shared(node_ids, first_ids, second_ids)
         return self._apply_mlp(torch.cat([g1, g2], dim=0))
+
+    def _fused_feature(self, src, dst, n):
+        """tpnet_host_pair_feature with self.mlp (None if self.mlp is not the reference's Linear-ReLU-Linear on this GPU)."""
+        NG = self.pair_wise_feature_dim
+        mlp = self.mlp
+        if len(dst) != n:
+            raise ValueError("src_node_ids and dst_node_ids must have the same length")
+        if self._plist()[0].device.type != "cuda":
+            return None
+        prep = _ff.prepared(mlp, NG)
+        if prep is None:
+            return None
+        self._ensure_engine()
+        if n > self._eng["stage"].max_pairs:
+            return None
+        uh, vh = self._host_ids(src, "src_node_ids"), self._host_ids(dst, "dst_node_ids")
+        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        if _ff.needs_grad(prep[4]):
+            return _ff.apply_with_grad(mlp, lambda gram: self._host_readout(uh, vh, n, flags, NG, prep[2], gram), n, NG)
+        return self._host_readout(uh, vh, n, flags, NG, prep[2])
 
     def _apply_mlp(self, feats: torch.Tensor) -> torch.Tensor:
         if self.fused_mlp:
