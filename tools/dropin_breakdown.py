@@ -35,3 +35,18 @@ for what, name in ((3, "both"), (1, "readouts only"), (2, "update only"), (3, "b
     loop(what)
     w, h, f, u = loop(what)
     print(f"{cfg} {name}: wall {w:.1f} us/batch, host enqueue {h:.1f} (2 readouts {f:.1f}, update {u:.1f})")
+# pure host cost per call: bursts of 2 batches (6 calls < 8 ring slots, so no call waits for the GPU), GPU idle at the start
+rp.reset_random_projections()
+acc = [0.0, 0.0]; reps = 60
+with torch.no_grad():
+    for r in range(reps):
+        torch.cuda.synchronize()
+        for b in (2 * r, 2 * r + 1):
+            s = slice(b * B, (b + 1) * B)
+            a = time.perf_counter()
+            rp.get_pair_wise_feature(src[s], dst[s]); rp.get_pair_wise_feature(src[s], neg[s])
+            m = time.perf_counter()
+            rp.update(src[s], dst[s], t[s])
+            z = time.perf_counter()
+            acc[0] += m - a; acc[1] += z - m
+print(f"{cfg} host-only enqueue cost: get_pair_wise_feature {acc[0] / (4 * reps) * 1e6:.1f} us per call, update {acc[1] / (2 * reps) * 1e6:.1f} us per call")

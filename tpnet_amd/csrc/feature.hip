@@ -16,60 +16,141 @@ template <int LPP, int VPL, int W, int L, bool FULL>
 __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_t* __restrict__ u,
                                                      const int64_t* __restrict__ v, int64_t n, double now, double lambda,
                                                      uint32_t flags, tpnet_mlp M, float* __restrict__ out_gram,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, int ppb) {
     using C = GramCfg<LPP, L>;
     constexpr int GPB = FB / LPP;                 // pairs per pass of the readout
     constexpr int NG = C::NG, H = 4 * NG;
     constexpr int SUB = GPB < FSUB ? GPB : FSUB;
-    // (the readout's reduction through LDS only where its tile, the feature tile and the hidden tile fit 64 KB together)
-    constexpr bool LR = C::template lds_reduce<FB>() &&
-                        (C::template stage_floats<FB>() + GPB * NG + SUB * H) * 4 <= 64 * 1024;
+    constexpr int KQ = FB / NG;                   // layer 2: the hidden axis is cut into KQ slices, one per group of NG threads
+    constexpr int KCH = (H + KQ - 1) / KQ;        // hidden units per slice
+    // (the readout's reduction through LDS only where its tile and the dense layers' tiles fit 64 KB together)
+    constexpr int MLP_WORDS = GPB * NG + SUB * H + KQ * SUB * NG;
+    constexpr bool LR = C::template lds_reduce<FB>() && (C::template stage_floats<FB>() + MLP_WORDS) * 4 <= 64 * 1024;
     __shared__ __attribute__((aligned(16))) float stage[(LR || LPP < 16) ? C::template stage_floats<FB>() : 1];
     __shared__ __attribute__((aligned(16))) float feat[GPB * NG];
-    __shared__ __attribute__((aligned(16))) float hid[SUB * H];
+    __shared__ __attribute__((aligned(16))) float hid[SUB * H];          // [hidden unit][pair of the pass]
+    __shared__ __attribute__((aligned(16))) float part[KQ * SUB * NG];   // [slice][pair][output]
     const int tid = threadIdx.x;
     const int gl = tid % LPP, g = tid / LPP;
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
     const float* __restrict__ w1t = M.w1t;        // [NG][H]: w1t[k][j] = mlp[0].weight[j][k]
     const float* __restrict__ w2t = M.w2t;        // [H][NG]: w2t[k][o] = mlp[2].weight[o][k]
-    for (int64_t base = (int64_t)blockIdx.x * GPB; base < n; base += (int64_t)gridDim.x * GPB) {
+    // L = 3 (H == FB): thread j IS hidden unit j and thread (kq, o) owns one slice of one output for the whole kernel, so
+    // its 64 + 64 weights are loaded ONCE, ahead of the first readout (whose memory round trips hide the loads), and stay
+    // in registers for every tile of the block: the dense layers then touch only LDS
+#ifndef TPNET_FEATURE_WREG
+#define TPNET_FEATURE_WREG 0      // (measured at C2, 1000 pairs: 13.9 us without, 17.6 us with -- the 128 KB of weights per
+#endif                            //  workgroup queue up in front of the readout's own loads; kept for long pair lists only)
+    constexpr bool WREG = TPNET_FEATURE_WREG && (H == FB) && (KQ * NG == FB) && (VPL == 1);
+    float w1r[WREG ? NG : 1], w2r[WREG ? KCH : 1];
+    float b1r = 0.0f;
+    if constexpr (WREG) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) w1r[k] = w1t[k * H + tid];
+        const int kq = tid / NG, o = tid - kq * NG;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) w2r[i] = w2t[(kq * KCH + i) * NG + o];
+        b1r = M.b1[tid];
+    }
+    // ppb = pairs per workgroup and pass (<= GPB): a short list is spread over more workgroups with idle lane groups rather
+    // than over few full ones (200 pairs at d=64: 13 workgroups of 16 pairs and two dense passes each, or 25 of 8 and one)
+    for (int64_t base = (int64_t)blockIdx.x * ppb; base < n; base += (int64_t)gridDim.x * ppb) {
         const int64_t p = base + g;
-        const bool valid = p < n;
+        const bool valid = g < ppb && p < n;
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
         gram_pair<LPP, VPL, W, L, FULL, false, false, LR>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
                                                           feat + g * NG, gl, nullptr, stage);
         __syncthreads();
-        const int npair = (n - base < GPB) ? (int)(n - base) : GPB;
+        const int npair = (n - base < ppb) ? (int)(n - base) : ppb;
         if (out_gram) {                           // the pre-mlp features, for a backward pass (training)
             for (int i = tid; i < npair * NG; i += FB) out_gram[base * NG + i] = feat[i];
         }
         for (int p0 = 0; p0 < npair; p0 += SUB) {
-            // ---- hidden = relu(W1 f + b1): thread j owns hidden unit j for the SUB pairs of this pass
-            for (int j = tid; j < H; j += FB) {
+            // ---- hidden = relu(W1 f + b1): thread j owns hidden unit j for the SUB pairs of this pass.  Its NG weights are
+            // fetched in bursts of 32 independent loads (a k loop with a load per step is a chain of L2 round trips)
+            if constexpr (WREG) {
                 float acc[SUB];
 #pragma unroll
                 for (int q = 0; q < SUB; ++q) acc[q] = 0.0f;
-#pragma unroll 4
-                for (int k = 0; k < NG; ++k) {
-                    const float w = w1t[k * H + j];
 #pragma unroll
-                    for (int q = 0; q < SUB; ++q) acc[q] = fmaf(feat[(p0 + q) * NG + k], w, acc[q]);
+                for (int k = 0; k < NG; ++k) {
+#pragma unroll
+                    for (int q = 0; q < SUB; ++q) acc[q] = fmaf(feat[(p0 + q) * NG + k], w1r[k], acc[q]);
                 }
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) {
+                    const float h = acc[q] + b1r;
+                    hid[tid * SUB + q] = (h < 0.0f) ? 0.0f : h;      // (NaN < 0 is false: NaN passes, as torch.relu)
+                }
+            } else
+            for (int j = tid; j < H; j += FB) {
                 const float b = M.b1[j];
+                float acc[SUB];
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) acc[q] = 0.0f;
+                constexpr int W1CH = 32;          // weights per burst
+#pragma unroll 1
+                for (int kb = 0; kb < NG; kb += W1CH) {
+                    float w[W1CH];
+#pragma unroll
+                    for (int i = 0; i < W1CH; ++i) w[i] = (kb + i < NG) ? w1t[(kb + i) * H + j] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < W1CH; ++i) {
+                        const int k = (kb + i < NG) ? kb + i : 0;
+#pragma unroll
+                        for (int q = 0; q < SUB; ++q) acc[q] = fmaf(feat[(p0 + q) * NG + k], w[i], acc[q]);
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < SUB; ++q) {
                     const float h = acc[q] + b;
-                    hid[q * H + j] = (h < 0.0f) ? 0.0f : h;          // (NaN < 0 is false: NaN passes, as torch.relu)
+                    hid[j * SUB + q] = (h < 0.0f) ? 0.0f : h;        // (NaN < 0 is false: NaN passes, as torch.relu)
                 }
             }
             __syncthreads();
-            // ---- out = W2 hidden + b2: one output element per thread and round
+            // ---- out = W2 hidden + b2: thread (slice kq, output o) sums its slice of the hidden axis for all SUB pairs,
+            // weights again in bursts of up to 32 independent loads; the KQ partial sums meet in LDS
+            if constexpr (WREG) {
+                const int kq = tid / NG, o = tid - kq * NG;
+                float acc[SUB];
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) acc[q] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+#pragma unroll
+                    for (int q = 0; q < SUB; ++q) acc[q] = fmaf(hid[(kq * KCH + i) * SUB + q], w2r[i], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) part[(kq * SUB + q) * NG + o] = acc[q];
+            } else if (tid < KQ * NG) {
+                const int kq = tid / NG, o = tid - kq * NG;
+                const int k0 = kq * KCH, k1 = (k0 + KCH < H) ? k0 + KCH : H;
+                float acc[SUB];
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) acc[q] = 0.0f;
+                constexpr int WCH = KCH < 32 ? KCH : 32;
+#pragma unroll 1
+                for (int kb = k0; kb < k1; kb += WCH) {
+                    float w[WCH];
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) w[i] = (kb + i < k1) ? w2t[(kb + i) * NG + o] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) {
+                        const int k = (kb + i < k1) ? kb + i : k0;
+#pragma unroll
+                        for (int q = 0; q < SUB; ++q) acc[q] = fmaf(hid[k * SUB + q], w[i], acc[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SUB; ++q) part[(kq * SUB + q) * NG + o] = acc[q];
+            }
+            __syncthreads();
             for (int idx = tid; idx < SUB * NG; idx += FB) {
                 const int q = idx / NG, o = idx - q * NG;
-                float acc = 0.0f;
-#pragma unroll 8
-                for (int k = 0; k < H; ++k) acc = fmaf(hid[q * H + k], w2t[k * NG + o], acc);
-                if (p0 + q < npair) out[(base + p0 + q) * NG + o] = acc + M.b2[o];
+                float sum = part[idx];
+#pragma unroll
+                for (int kq = 1; kq < KQ; ++kq) sum += part[kq * SUB * NG + idx];
+                if (p0 + q < npair) out[(base + p0 + q) * NG + o] = sum + M.b2[o];
             }
             __syncthreads();
         }
@@ -83,9 +164,11 @@ int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* 
     if (m.F != NN * NN || m.H != 4 * NN * NN || !m.w1t || !m.b1 || !m.w2t || !m.b2) return TPNET_ERR_BAD_ARG;
     if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
     TPNET_DISPATCH(({
-        const int grid = grid_for(n, FB / LPP, 256 * 8);
+        constexpr int GPB = FB / LPP;
+        const int ppb = (GPB > FSUB && n <= 256 * FSUB) ? FSUB : GPB;
+        const int grid = grid_for(n, ppb, 256 * 8);
         hipLaunchKernelGGL((k_pair_feature<LPP, VPL, W, L, FULL>), dim3(grid), dim3(FB), 0, s, st, u, v, n, now, lambda,
-                           flags, m, out_gram, out);
+                           flags, m, out_gram, out, ppb);
     }));
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;

@@ -336,18 +336,34 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
     static_assert(sizeof(U) + 3 * (NC / 2) * 4 + 8 <= 64 * 1024, "k_plan_one: LDS budget");
     const int tid = threadIdx.x;
     const int nc = 2 * B;
-    const double t_last = t[B - 1];                      // next_time = node_interact_times[-1]   (TPNet.py:76)
     if (tid == 0) { n_light = 0; n_heavy = 0; }
-    for (int e = tid; e < B; e += BS) {
-        const int64_t s = src[e], dd = dst[e];
-        const bool oks = (uint64_t)s < (uint64_t)N, okd = (uint64_t)dd < (uint64_t)N;
-        const uint32_t bad = (oks && okd) ? 0u : 0x80000000u;
-        if (bad) atomicAdd(err, 1u);                     // once per bad edge
-        e_src[e] = (oks ? (uint32_t)s : 0u) | bad;
-        e_dst[e] = (okd ? (uint32_t)dd : 0u) | bad;
-        // time weight with the reference's casts (models/TPNet.py:77-78), as contribution()
-        const float x = (float)t_last - (float)t[e];
-        e_w[e] = bad ? 0.0f : expf((float)(-lambda) * x);
+    // every thread's edges in ONE burst of independent loads (src / dst / t may sit in host memory: a load is microseconds)
+    constexpr int EPT = IPT / 2;
+    int64_t rs[EPT], rd[EPT];
+    double rt[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * BS + tid;
+        const int ec = e < B ? e : B - 1;
+        rs[q] = src[ec];
+        rd[q] = dst[ec];
+        rt[q] = t[ec];
+    }
+    const double t_last = t[B - 1];                      // next_time = node_interact_times[-1]   (TPNet.py:76)
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * BS + tid;
+        if (e < B) {
+            const int64_t s = rs[q], dd = rd[q];
+            const bool oks = (uint64_t)s < (uint64_t)N, okd = (uint64_t)dd < (uint64_t)N;
+            const uint32_t bad = (oks && okd) ? 0u : 0x80000000u;
+            if (bad) atomicAdd(err, 1u);                 // once per bad edge
+            e_src[e] = (oks ? (uint32_t)s : 0u) | bad;
+            e_dst[e] = (okd ? (uint32_t)dd : 0u) | bad;
+            // time weight with the reference's casts (models/TPNet.py:77-78), as contribution()
+            const float x = (float)t_last - (float)rt[q];
+            e_w[e] = bad ? 0.0f : expf((float)(-lambda) * x);
+        }
     }
     __syncthreads();
     uint32_t keys[IPT], vals[IPT];
@@ -444,15 +460,21 @@ int plan_one(const tpnet_state& st, const Plan& p, const int64_t* src, const int
     const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
     if (node_bits > 31) return TPNET_ERR_BAD_ARG;
     const uint32_t thr = heavy_threshold_for(B, flags);
-    if (2 * B <= 256 * 4)
-        hipLaunchKernelGGL((k_plan_one<256, 4>), dim3(1), dim3(256), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits, now_time,
-                           lambda, (int)st.L, thr, st.err);
-    else if (2 * B <= 256 * 8)
-        hipLaunchKernelGGL((k_plan_one<256, 8>), dim3(1), dim3(256), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits, now_time,
-                           lambda, (int)st.L, thr, st.err);
-    else
-        hipLaunchKernelGGL((k_plan_one<256, 16>), dim3(1), dim3(256), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits, now_time,
-                           lambda, (int)st.L, thr, st.err);
+    static const int bs_env = getenv("TPNET_DEV_PLAN_ONE_BS") ? atoi(getenv("TPNET_DEV_PLAN_ONE_BS")) : 0;   // developer override
+#define TPNET_PLAN_ONE(BS_, IPT_)                                                                                         \
+    hipLaunchKernelGGL((k_plan_one<BS_, IPT_>), dim3(1), dim3(BS_), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits,   \
+                       now_time, lambda, (int)st.L, thr, st.err)
+    const int64_t nc = 2 * B;
+    if (nc <= 512) {
+        if (bs_env == 512) TPNET_PLAN_ONE(256, 2); else TPNET_PLAN_ONE(256, 2);
+    } else if (nc <= 1024) {
+        if (bs_env == 256) TPNET_PLAN_ONE(256, 4); else TPNET_PLAN_ONE(512, 2);
+    } else if (nc <= 2048) {
+        if (bs_env == 256) TPNET_PLAN_ONE(256, 8); else if (bs_env == 512) TPNET_PLAN_ONE(512, 4); else TPNET_PLAN_ONE(1024, 2);
+    } else {
+        if (bs_env == 256) TPNET_PLAN_ONE(256, 16); else if (bs_env == 512) TPNET_PLAN_ONE(512, 8); else TPNET_PLAN_ONE(1024, 4);
+    }
+#undef TPNET_PLAN_ONE
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }
