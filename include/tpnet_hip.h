@@ -34,7 +34,7 @@ extern "C" {
 #define TPNET_ABI_VERSION 4 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
                                3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream);
                                4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
-                                    (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update) */
+                                    (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -173,6 +173,18 @@ int tpnet_host_pair_feature(const tpnet_state* st, tpnet_stage* stage, const int
 int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst,
                       const double* h_t, int64_t B, double now_time, double lambda, uint32_t launch_id, uint32_t flags,
                       void* workspace, size_t ws_bytes, void* stream);
+
+/* The encoder's readout (models/TPNet.py:311-324): row i has two anchors a1[i], a2[i] (the edge's src and dst) and K sampled
+ * neighbours neigh[i*K .. i*K+K); out1[(i*K + k)] = G(neigh[i*K+k], a1[i]), out2[(i*K + k)] = G(neigh[i*K+k], a2[i]), rows of
+ * (2L+2)^2 floats laid out and scaled like tpnet_pair_gram's -- with out2 = out1 + n_rows*K*(2L+2)^2 this IS the reference's
+ * get_pair_wise_feature(tile(neigh, 2), concat(repeat(a1, K), repeat(a2, K))) before self.mlp.  One lane group walks a row:
+ * the anchors' rows are fetched once per row (not once per pair) and stay in registers, their own Gram blocks are reduced
+ * once per row.  Needs rows of exactly one chunk of 16-byte vectors (d = 64, 128, 256, 512: tpnet_pair_gram_anchored_supported
+ * returns 1); other shapes take tpnet_pair_gram_shared / tpnet_pair_gram. */
+int tpnet_pair_gram_anchored(const tpnet_state* st, const int64_t* neigh, const int64_t* a1, const int64_t* a2,
+                             int64_t n_rows, int32_t K, double now_time, double lambda, uint32_t flags, float* out1,
+                             float* out2, void* stream);
+int tpnet_pair_gram_anchored_supported(const tpnet_state* st);
 
 /* Workspace for tpnet_update / tpnet_run_stream with at most max_edges edges per call. */
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);

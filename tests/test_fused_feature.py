@@ -178,3 +178,67 @@ def test_staging_ring_wraps_under_load():
         torch.cuda.synchronize()
         for (u, v), o in zip(pairs, outs):
             assert torch.equal(o, rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,L,K", [(256, 3, 20), (128, 3, 20), (64, 3, 7), (512, 3, 10), (128, 2, 4), (256, 4, 5), (128, 1, 32)])
+def test_anchored_encoder_readout(d, L, K):
+    """tpnet_pair_gram_anchored (one lane group per row, anchors in registers) against the oracle on the reference's pair
+    list get_pair_wise_feature(tile(neigh, 2), concat(repeat(src, K), repeat(dst, K))) (models/TPNet.py:311-321), incl.
+    padding id 0 among the neighbours, rows whose two anchors coincide, and equal anchors in consecutive rows."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from oracle import tpnet_oracle as O
+    rng = np.random.RandomState(K * 31 + d)
+    N = 250
+    rp = _module(N, d, L)
+    st = O.OracleState(rp.random_projections[0].detach().cpu().numpy(), L, 1e-6, 0.0)
+    for src, dst, t in _stream(rng, N, 120, 3):
+        rp.update(src, dst, t)
+        O.update(st, src, dst, t)
+    n = 37
+    neigh = rng.randint(0, N, (n, K)).astype(np.int64)
+    neigh[rng.rand(n, K) < 0.2] = 0                          # left zero-padding of short histories (utils/utils.py:211-219)
+    a1 = rng.randint(1, N, n).astype(np.int64)
+    a2 = rng.randint(1, N, n).astype(np.int64)
+    a2[3] = a1[3]
+    a1[10] = a1[9]; a1[11] = a1[9]                           # runs of equal anchors across rows
+    u = np.tile(neigh.reshape(-1), 2)
+    v = np.concatenate([np.repeat(a1, K), np.repeat(a2, K)])
+    want = O.pair_gram(st, u, v)
+    got = rp.pair_gram_anchored(neigh, a1, a2).view(-1, rp.pair_wise_feature_dim).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    # and equal to the generic kernel far below the parity bar (same products, another order of the partial sums)
+    gen = rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, gen, rtol=2e-5, atol=2e-5)
+    rp.check_device_errors()
+
+
+@pytest.mark.gpu
+def test_encoder_pattern_takes_the_anchored_kernel_and_matches():
+    """get_pair_wise_feature recognises the encoder's index pattern on a long pair list and must return what the generic
+    path returns for the same arrays."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    rng = np.random.RandomState(5)
+    N, K, n = 400, 20, 300
+    rp = _module(N, 256, 3)
+    for src, dst, t in _stream(rng, N, 200, 3):
+        rp.update(src, dst, t)
+    neigh = rng.randint(0, N, (n, K)).astype(np.int64)
+    a1, a2 = rng.randint(1, N, n).astype(np.int64), rng.randint(1, N, n).astype(np.int64)
+    u = np.tile(neigh.reshape(-1), 2)
+    v = np.concatenate([np.repeat(a1, K), np.repeat(a2, K)])
+    assert u.size > 8192
+    runs = rp._anchor_runs(v[: n * K])
+    assert runs is not None and runs[1] % K == 0 or K % runs[1] == 0
+    with torch.no_grad():
+        got = rp.get_pair_wise_feature(u, v)
+        want = rp.mlp(rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()))
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # a pair list that only LOOKS tiled (second half of dst not made of runs) keeps the generic path and is right too
+    v2 = v.copy(); v2[n * K + 1] = (v2[n * K + 1] % (N - 1)) + 1
+    with torch.no_grad():
+        got2 = rp.get_pair_wise_feature(u, v2)
+        want2 = rp.mlp(rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v2).cuda()))
+    np.testing.assert_allclose(got2.cpu().numpy(), want2.cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -52,6 +52,9 @@ SIGNATURES = {
     "tpnet_gather_rows": (C.c_int, [_SP, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "tpnet_pair_gram": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P]),
     "tpnet_pair_gram_shared": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P, _P]),
+    "tpnet_pair_gram_anchored": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_uint32, _P, _P,
+                                           _P]),
+    "tpnet_pair_gram_anchored_supported": (C.c_int, [_SP]),
     "tpnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_stream_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,

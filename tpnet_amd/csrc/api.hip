@@ -295,6 +295,26 @@ int tpnet_pair_gram_shared(const tpnet_state* st, const int64_t* u, const int64_
     return launch_pair_gram_shared(*st, u, v1, v2, n, now_time, lambda, flags, out1, out2, (hipStream_t)stream);
 }
 
+int tpnet_pair_gram_anchored(const tpnet_state* st, const int64_t* neigh, const int64_t* a1, const int64_t* a2,
+                             int64_t n_rows, int32_t K, double now_time, double lambda, uint32_t flags, float* out1,
+                             float* out2, void* stream) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (n_rows < 0 || K < 0 || (n_rows > 0 && K > 0 && (!neigh || !a1 || !a2 || !out1 || !out2))) return TPNET_ERR_BAD_ARG;
+    if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
+    if (n_rows > 0 && K > 0 && !pair_gram_anchored_supported(*st)) {
+        // rows that are not one chunk of 16-byte vectors (d = 120, 140, use_matrix ...): the generic kernel, one launch per
+        // anchor side, on index arrays the caller would otherwise build -- not available without them: report it
+        return TPNET_ERR_BAD_ARG;
+    }
+    return launch_pair_gram_anchored(*st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, out1, out2, (hipStream_t)stream);
+}
+
+int tpnet_pair_gram_anchored_supported(const tpnet_state* st) {
+    if (check_state(st)) return 0;
+    return pair_gram_anchored_supported(*st) ? 1 : 0;
+}
+
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
 
 size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch) {

@@ -573,4 +573,204 @@ __device__ __forceinline__ void gram_shared(const tpnet_state& S, int64_t u, int
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// The encoder's readout (models/TPNet.py:311-324): row i of the call has TWO anchors (the edge's src and dst) and K
+// sampled neighbours w_0..w_{K-1}; the pair list is [G(w_k, src_i) for all i, k] followed by [G(w_k, dst_i)].  ONE lane
+// group walks a row: the anchors' 2(L+1) rows are loaded once and stay in registers for all K neighbours, their own
+// blocks <a,a> are reduced once per row, and per neighbour only its L+1 rows are fetched (instead of 3(L+1) per
+// (w, src, dst) unit) and only the neighbour's blocks are formed and reduced:
+//   slots = [ w.w (tri) | w.a1 (R*R) | w.a2 (R*R) ],  R = L+1, tri = R(R+1)/2    (42 slots at L = 3 against 62)
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int L>
+struct AnchorCfg {
+    static constexpr int R = L + 1;
+    static constexpr int TRI = R * (R + 1) / 2;
+    static constexpr int O_WW = 0, O_WA1 = TRI, O_WA2 = TRI + R * R;
+    static constexpr int NS = TRI + 2 * R * R;
+    static constexpr int MPS = ((NS + LPP - 1) / LPP) * LPP;
+    static constexpr int PERS = MPS / LPP;
+    static constexpr __host__ __device__ int tri(int i, int j) { return i * R - i * (i - 1) / 2 + (j - i); }   // i <= j
+};
+
+// all-reduce of one value over the LPP lanes of a group (butterfly; used once per row for the anchors' own blocks)
+template <int LPP>
+__device__ __forceinline__ float group_allreduce(float v) {
+#pragma unroll
+    for (int o = LPP / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, LPP);
+    return v;
+}
+
+template <int LPP, int VPL, int W, int L, bool FULL>
+__device__ __forceinline__ void gram_anchored(const tpnet_state& S, const int64_t* __restrict__ neigh, int64_t a1, int64_t a2,
+                                              int k_begin, int k_end, bool valid, double now, double lambda, bool do_scale,
+                                              float* __restrict__ out1, float* __restrict__ out2, int gl) {
+    using C = GramCfg<LPP, L>;
+    using AC = AnchorCfg<LPP, L>;
+    constexpr int NR = C::NR, NN = C::NN, F = VPL * W;
+    static_assert(FULL, "gram_anchored: rows of exactly one chunk");
+    const int d = S.d;
+    const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(S.meta);
+    bool aok = valid && (uint64_t)a1 < (uint64_t)S.N && (uint64_t)a2 < (uint64_t)S.N;
+    if (valid && !aok && gl == 0) atomicAdd(S.err, 1u);
+    if (!aok) { a1 = 0; a2 = 0; }
+    // ---- the anchors: rows (decay applied) and their own blocks, once per row
+    float fa[2][NR][F];
+    {
+        const int64_t ids[2] = {a1, a2};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const MetaView m = read_meta(meta, ids[s], READER_BID, now, lambda);
+            const float* qb = S.q + ((int64_t)m.copy * S.N + ids[s]) * ((int64_t)L * d);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) ldv<W>(S.p0 + ids[s] * (int64_t)d, j * LPP + gl, &fa[s][0][j * W]);
+            float g = 1.0f;
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+                g *= m.g;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) ldv<W>(qb + (int64_t)(i - 1) * d, j * LPP + gl, &fa[s][i][j * W]);
+#pragma unroll
+                for (int k = 0; k < F; ++k) fa[s][i][k] *= g;
+            }
+        }
+    }
+    float aa[2][AC::TRI];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+#pragma unroll
+            for (int b = a; b < NR; ++b) aa[s][AC::tri(a, b)] = group_allreduce<LPP>(dot_chunk<F, false>(fa[s][a], fa[s][b]));
+        }
+    }
+    // per-lane output plan (loop-invariant): where each of this lane's PER output elements comes from; the anchors' own
+    // block is finished (clamp, log) once per row
+    int o_s1[C::PER], o_s2[C::PER];
+    bool o_aa[C::PER], o_in[C::PER];
+    float o_y1[C::PER], o_y2[C::PER];
+#pragma unroll
+    for (int kk = 0; kk < C::PER; ++kk) {
+        int idx = gl * C::PER + kk;
+        o_in[kk] = idx < C::NG;
+        idx = o_in[kk] ? idx : 0;
+        const int a = idx / NN, b = idx - a * NN;
+        o_aa[kk] = false;
+        o_y1[kk] = 0.0f;
+        o_y2[kk] = 0.0f;
+        if (a < NR && b < NR) {
+            const int i = a < b ? a : b, j = a < b ? b : a;
+            o_s1[kk] = o_s2[kk] = AC::O_WW + AC::tri(i, j);
+        } else if (a < NR) {                       // (w row a, anchor row b-NR)
+            o_s1[kk] = AC::O_WA1 + a * NR + (b - NR);
+            o_s2[kk] = AC::O_WA2 + a * NR + (b - NR);
+        } else if (b < NR) {                       // mirrored
+            o_s1[kk] = AC::O_WA1 + b * NR + (a - NR);
+            o_s2[kk] = AC::O_WA2 + b * NR + (a - NR);
+        } else {
+            const int x = a - NR, y = b - NR;
+            const int ta = AC::tri(x < y ? x : y, x < y ? y : x);
+            o_aa[kk] = true;
+            o_s1[kk] = o_s2[kk] = 0;
+            float y1 = 0.0f, y2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < AC::TRI; ++q) {     // (register arrays: a select chain, no dynamic indexing)
+                y1 = (ta == q) ? aa[0][q] : y1;
+                y2 = (ta == q) ? aa[1][q] : y2;
+            }
+            if (do_scale) {
+                y1 = (y1 < 0.0f) ? 0.0f : y1;
+                y2 = (y2 < 0.0f) ? 0.0f : y2;
+                y1 = logf(y1 + 1.0f);
+                y2 = logf(y2 + 1.0f);
+            }
+            o_y1[kk] = y1;
+            o_y2[kk] = y2;
+        }
+    }
+    // ---- the neighbours [k_begin, k_end) of the row.  Software pipeline: ids and meta records of up to LPP neighbours are
+    // fetched lane-parallel (two round trips for the whole chunk), and the rows of neighbour k+1 are in flight while
+    // neighbour k's 42 inner products are formed and reduced
+    for (int kc = k_begin; kc < k_end; kc += LPP) {
+        const int nk = (k_end - kc < LPP) ? k_end - kc : LPP;
+        int64_t my_w = (valid && gl < nk) ? neigh[kc + gl] : 0;
+        const bool my_ok = aok && (uint64_t)my_w < (uint64_t)S.N;
+        if (valid && aok && gl < nk && !my_ok) atomicAdd(S.err, 1u);
+        if (!my_ok) my_w = 0;
+        const MetaView my_m = read_meta(meta, my_w, READER_BID, now, lambda);
+        float fn[NR][F];                                   // rows of the NEXT neighbour (raw)
+        auto issue = [&](int j) {
+            const int64_t w = __shfl(my_w, j, LPP);
+            const int cp = __shfl(my_m.copy, j, LPP);
+            const float* qb = S.q + ((int64_t)cp * S.N + w) * ((int64_t)L * d);
+#pragma unroll
+            for (int jj = 0; jj < VPL; ++jj) ldv<W>(S.p0 + w * (int64_t)d, jj * LPP + gl, &fn[0][jj * W]);
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < VPL; ++jj) ldv<W>(qb + (int64_t)(i - 1) * d, jj * LPP + gl, &fn[i][jj * W]);
+            }
+        };
+        issue(0);
+        for (int j = 0; j < nk; ++j) {
+        const int k = kc + j;
+        const bool wok = __shfl((int)my_ok, j, LPP) != 0;
+        const float mg = __shfl(my_m.g, j, LPP);
+        float fw[NR][F];
+#pragma unroll
+        for (int x = 0; x < F; ++x) fw[0][x] = fn[0][x];
+        {
+            float g = 1.0f;
+#pragma unroll
+            for (int i = 1; i <= L; ++i) {
+                g *= mg;
+#pragma unroll
+                for (int x = 0; x < F; ++x) fw[i][x] = fn[i][x] * g;
+            }
+        }
+        if (j + 1 < nk) issue(j + 1);
+        float acc[AC::MPS];
+#pragma unroll
+        for (int i = 0; i < AC::MPS; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+#pragma unroll
+            for (int b = a; b < NR; ++b) acc[AC::O_WW + AC::tri(a, b)] = dot_chunk<F, false>(fw[a], fw[b]);
+#pragma unroll
+            for (int b = 0; b < NR; ++b) {
+                acc[AC::O_WA1 + a * NR + b] = dot_chunk<F, false>(fw[a], fa[0][b]);
+                acc[AC::O_WA2 + a * NR + b] = dot_chunk<F, false>(fw[a], fa[1][b]);
+            }
+        }
+        Halve<AC::MPS, LPP / 2>::run(acc, gl);        // lane gl now holds the complete sums of slots [gl*PERS, ...)
+        // output elements of the two Gram matrices [w rows | anchor rows]^2 from their slots (or the anchors' block)
+#pragma unroll
+        for (int kk = 0; kk < C::PER; ++kk) {
+            const int idx = o_in[kk] ? gl * C::PER + kk : 0;
+            const bool in = o_in[kk];
+            float x1 = 0.0f, x2 = 0.0f;
+#pragma unroll
+            for (int j2 = 0; j2 < AC::PERS; ++j2) {
+                const float t1 = __shfl(acc[j2], o_s1[kk] / AC::PERS, LPP);
+                const float t2 = __shfl(acc[j2], o_s2[kk] / AC::PERS, LPP);
+                x1 = (o_s1[kk] % AC::PERS == j2) ? t1 : x1;
+                x2 = (o_s2[kk] % AC::PERS == j2) ? t2 : x2;
+            }
+            if (do_scale) {
+                x1 = (x1 < 0.0f) ? 0.0f : x1;          // NaN < 0 is false: NaN passes through (:127)
+                x2 = (x2 < 0.0f) ? 0.0f : x2;
+                x1 = logf(x1 + 1.0f);                  // log(x + 1), not log1p (:128)
+                x2 = logf(x2 + 1.0f);
+            }
+            if (o_aa[kk]) { x1 = o_y1[kk]; x2 = o_y2[kk]; }
+            if (!wok) { x1 = __builtin_nanf(""); x2 = x1; }
+            if (valid && in) {
+                __builtin_nontemporal_store(x1, out1 + (int64_t)k * C::NG + idx);
+                __builtin_nontemporal_store(x2, out2 + (int64_t)k * C::NG + idx);
+            }
+        }
+        }
+    }
+}
+
+
 }  // namespace tpnet

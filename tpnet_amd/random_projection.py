@@ -514,11 +514,78 @@ class RandomProjectionModule(nn.Module):
             if fused is not None:
                 return fused
         # (rows of <= 128 floats: the generic kernel's 16-lane geometry is as fast on long lists; measured)
+        if self.dim > 128 and n >= 4 and n % 2 == 0 and n > _ff.MAX_PAIRS and np.array_equal(src[: n // 2], src[n // 2:]):
+            # the encoder's pattern: neighbours tiled twice, each half of dst a np.repeat of the row's anchor
+            # (models/TPNet.py:313-316): one lane group per row with the anchors in registers (rows of <= 128 floats: the
+            # generic kernel is as fast on long lists -- measured, tools/encoder_readout.py)
+            dst = np.asarray(dst_node_ids)
+            if self._plist()[0].device.type == "cuda":
+                self._ensure_engine()
+                r1 = self._anchor_runs(dst[: n // 2])
+                r2 = self._anchor_runs(dst[n // 2:]) if r1 is not None else None
+                if r1 is not None and r2 is not None and _lib.load().tpnet_pair_gram_anchored_supported(self._st_ref()):
+                    K = int(np.gcd(r1[1], r2[1]))
+                    if K >= 4:
+                        m = (n // 2) // K
+                        g = self.pair_gram_anchored(src[: n // 2].reshape(m, K), dst[: n // 2: K], dst[n // 2:: K])
+                        return self._apply_mlp(g.view(-1, self.pair_wise_feature_dim))
         if self.dim > 128 and n >= 2 and n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:]):
             dst = np.asarray(dst_node_ids)
             g1, g2 = self.pair_gram_shared(src[: n // 2], dst[: n // 2], dst[n // 2:])
             return self._apply_mlp(torch.cat([g1, g2], dim=0))
         return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
+
+    def pair_gram_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids):
+        """The encoder's readout before self.mlp (models/TPNet.py:311-324): neighbor_ids [n, K] (the sampled neighbours of n
+        rows), two anchors per row (the edge's src and dst).  Returns [2, n*K, (2L+2)^2]: G(neighbour, first anchor) for every
+        (row, neighbour), then G(neighbour, second anchor) -- viewed as [2*n*K, .] this is the reference's
+        get_pair_wise_feature(tile(neighbours, 2), concat(repeat(first, K), repeat(second, K))) pair order.  One lane group per
+        row keeps both anchors' rows in registers for its K neighbours (tpnet_pair_gram_anchored)."""
+        self._ensure_engine()
+        if isinstance(neighbor_ids, torch.Tensor):
+            if neighbor_ids.dim() != 2:
+                raise ValueError("neighbor_ids must be [n, K]")
+            n, K = neighbor_ids.shape
+            w = neighbor_ids.reshape(-1)
+        else:
+            nb = np.asarray(neighbor_ids)
+            if nb.ndim != 2:
+                raise ValueError("neighbor_ids must be [n, K]")
+            n, K = nb.shape
+            w = nb.reshape(-1)
+        if len(first_anchor_ids) != n or len(second_anchor_ids) != n:
+            raise ValueError("one first and one second anchor per row of neighbor_ids")
+        lib = _lib.load()
+        if not lib.tpnet_pair_gram_anchored_supported(self._st_ref()):
+            raise _lib.TPNetHipError(f"pair_gram_anchored needs dim in (64, 128, 256, 512), not {self.dim}: use pair_gram_shared")
+        wd = self._to_device(self._check_ids(w, "neighbor_ids"))[0]
+        a1, a2 = self._to_device(self._check_ids(first_anchor_ids, "first_anchor_ids"),
+                                 self._check_ids(second_anchor_ids, "second_anchor_ids"))
+        out = torch.empty((2, n * K, self.pair_wise_feature_dim), dtype=torch.float32, device=self._dev())
+        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        _lib.check(lib.tpnet_pair_gram_anchored(self._st_ref(), wd.data_ptr(), a1.data_ptr(), a2.data_ptr(), n, K,
+                                                self._now_host, float(self.time_decay_weight), flags, out[0].data_ptr(),
+                                                out[1].data_ptr(), self._stream()), "pair_gram_anchored")
+        return out
+
+    def get_pair_wise_feature_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids):
+        """Extension: the encoder's call (models/TPNet.py:313-316) from its natural arguments; [2*n*K, (2L+2)^2] in the
+        reference's row order, self.mlp applied."""
+        g = self.pair_gram_anchored(neighbor_ids, first_anchor_ids, second_anchor_ids)
+        return self._apply_mlp(g.view(-1, self.pair_wise_feature_dim))
+
+    @staticmethod
+    def _anchor_runs(half):
+        """If `half` is repeat(anchors, K) for some K >= 2 (np.repeat of the encoder's call): (anchors, K); else None.
+        Any K whose blocks are constant serves: the gcd of the positions where the value changes and of the length."""
+        m = half.size
+        if m < 2:
+            return None
+        ch = np.flatnonzero(half[1:] != half[:-1]) + 1
+        K = int(np.gcd.reduce(ch, initial=m)) if ch.size else m
+        if K < 2:
+            return None
+        return half[::K], K
 
     def get_pair_wise_feature_shared(self, node_ids, first_ids, second_ids):
         """Extension: get_pair_wise_feature(tile(node_ids, 2), concat(first_ids, second_ids)) -- the encoder's pattern
