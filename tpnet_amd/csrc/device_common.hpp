@@ -57,7 +57,7 @@ static constexpr int BLOCK_SMALL = TPNET_BLOCK_SMALL;
 constexpr int min_waves_per_simd(int lpp, int vpl, int w) {
     return (w != 4) ? 2 : (lpp < 16) ? 4 : (lpp == 16 && vpl == 1) ? TPNET_MINW16 : (lpp == 32 && vpl == 1) ? TPNET_MINW32 : 2;
 }
-static constexpr int HEAVY_BLOCKS_SMALL = 40, HEAVY_BLOCKS_LARGE = 128;
+static constexpr int HEAVY_BLOCKS_SMALL = 48, HEAVY_BLOCKS_LARGE = 128;
 
 // ---------------------------------------------------------------------------------------------------------------
 // helpers

@@ -554,7 +554,7 @@ int wplan_window_batches(int64_t batch, int d, int L) {
     (void)L;
     if (d % 4 != 0 || d < 4 || batch < 1) return 0;             // scalar-load rows (use_matrix, odd d) keep the per-batch path
     if (batch > 4096) return 0;                                 // such batches are bandwidth-bound one launch at a time already
-    int64_t K = 16384 / batch;                                  // ~16 K edges per window (measured: C2 4.9 us per batch at 16 K, 5.4 at 8 K and at 32 K)
+    int64_t K = 24576 / batch;                                  // ~24 K edges per window (C2, four degree laws, tools/degree_sensitivity.py: 3.44-3.78 us per batch at 24 K, 3.55-3.90 at 16 K, 3.35-4.12 at 32 K)
     if (env) K = atoi(env);
     if (K > WIN_MAX_BATCHES) K = WIN_MAX_BATCHES;
     return K >= 2 ? (int)K : 0;
@@ -912,7 +912,7 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     }
     TPNET_HIP_TRY(hipGetLastError());
     static const char* thr_env = getenv("TPNET_DEV_WIN_HEAVY");
-    const uint32_t thr = thr_env ? (uint32_t)atoi(thr_env) : 64u;   // contributions per (node, window) above which a workgroup per column part walks the chain
+    const uint32_t thr = thr_env ? (uint32_t)atoi(thr_env) : 96u;   // contributions per (node, window) above which a workgroup per column part walks the chain
     const int egrid = (int)(((want_readout ? 3 : 0) * Ec + 255) / 256) > 4096 ? 4096 : (int)(((want_readout ? 3 : 0) * Ec + 255) / 256);
     const int win_bits = ceil_log2_u64((uint64_t)nw + 1) < 1 ? 1 : ceil_log2_u64((uint64_t)nw + 1);
     if (win_bits + 9 > 31) return TPNET_ERR_BAD_ARG;

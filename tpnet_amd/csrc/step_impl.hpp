@@ -47,6 +47,12 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     // AFTER those vector loads have been issued: it is a scalar load whose wait (lgkmcnt) would otherwise sit in front
     // of them and put one more memory round trip on every wave's critical path.
     const BatchDesc* __restrict__ Dp = p.desc + b;
+    // Reserved workgroups without a hub unit (a batch with few or no hubs: HEAVY_BLOCKS is a launch parameter, the number of
+    // hubs a device-side fact) do not idle: reserved workgroup number units + k takes overflow chunk k, and the regular
+    // workgroups skip the chunks taken this way in their later rounds.  Both sides decide from the batch descriptor alone
+    // (no atomics, no hand-off); a regular workgroup's FIRST unit is untouched, so the one-pass batches the grid is sized for
+    // run exactly as before.  Only the small-batch kernels (no STEP_ITEMS_FIRST remap) use it.
+    int surplus = -1;
     if ((int)blockIdx.x < HEAVY_BLOCKS) {
         if (flags & ROLE_UPDATE) {
             // heavy work unit = (item, layer, column part): the layers of the update are independent sums and so are the
@@ -60,7 +66,12 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
                 const Item I = heavy[h / (L * CP)];
                 const uint32_t n_heavy = Dp->n_heavy;
                 const double t_last = Dp->t_last;
-                if (h / (L * CP) >= n_heavy) break;
+                if (h / (L * CP) >= n_heavy) {
+                    // a reserved workgroup that has NO hub unit at all takes one chunk of the OVERFLOW of the work index
+                    // space (what the other workgroups would walk in a second grid-stride round): see `surplus` below
+                    if (h == blockIdx.x) surplus = (int)(blockIdx.x - n_heavy * (uint32_t)(L * CP));
+                    break;
+                }
                 if (!owns(a, I.target)) continue;
                 update_item_block<LPH, VPL, W, L, FULL, NT, BS>(S, p.s_partner, p.s_coef, I.target, I.j0, I.cnt,
                                                                 (int)((h / CP) % L), bid, t_last, lambda, part,
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
                 STAMP(7);
             }
         }
-        return;
+        if (surplus < 0 || FUSE || !(flags & ROLE_UPDATE)) return;
     }
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
@@ -103,7 +114,35 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
         }
     }
 
-    for (int64_t base = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB; base < total_w; base += nblk * GPB) {
+    // overflow chunk c (c >= 0) = work indices [(nblk + c) * GPB, ...): taken by reserved workgroup (hub units + c) if that
+    // one exists.  first_free = the first overflow chunk NOT taken by a reserved workgroup.
+    int64_t base0 = ((int64_t)blockIdx.x - HEAVY_BLOCKS) * GPB;
+    int64_t round_stride = nblk * GPB;
+    int64_t first_free = 0;
+    if constexpr (!FUSE) {
+        if (surplus >= 0) {
+            base0 = (nblk + surplus) * (int64_t)GPB;       // exactly one chunk
+            round_stride = total_w;                        // (leaves the loop after it)
+        } else if (flags & ROLE_UPDATE) {
+            constexpr int CPh = (BS == BLOCK_SMALL && FULL && W == 4 && LPP > 16) ? LPP / 16 : 1;
+            // (only a workgroup that HAS a later round needs the hub count: read behind its first unit's loads)
+            first_free = -1;                               // decided lazily below
+            (void)CPh;
+        }
+    }
+    for (int64_t base = base0; base < total_w; base += round_stride) {
+        if constexpr (!FUSE) {
+            if (surplus < 0 && (flags & ROLE_UPDATE) && base != base0) {
+                // later rounds of a regular workgroup: chunks [nblk, nblk + idle reserved workgroups) are gone
+                constexpr int CPh = (BS == BLOCK_SMALL && FULL && W == 4 && LPP > 16) ? LPP / 16 : 1;
+                if (first_free < 0) {
+                    const int64_t units = (int64_t)Dp->n_heavy * (L * CPh);
+                    first_free = units < HEAVY_BLOCKS ? (int64_t)HEAVY_BLOCKS - units : 0;
+                }
+                const int64_t chunk = base / GPB - nblk;   // overflow chunk number of this round (>= 0)
+                if (chunk < first_free) continue;
+            }
+        }
         int64_t w = base + g;
         int64_t wave0 = base + (g / GPW) * GPW;        // first work index of this wave: decides the wave's role
         if constexpr (FUSE) {

@@ -14,14 +14,16 @@ CONFIGS = {
 }
 
 
-def synthetic_stream(U: int, I: int, E: int, span: float, seed: int = 0):
+def synthetic_stream(U: int, I: int, E: int, span: float, seed: int = 0, pu: float = 2.0, pi: float = 3.0):
     """S(U, I, E, span, seed): bipartite power-law stream.  ids: users 1..U, items U+1..U+I, row 0 = padding
-    (preprocess_data/preprocess_data.py:56-81,101-108).  Returns src, dst (int64), t (sorted float64), N."""
+    (preprocess_data/preprocess_data.py:56-81,101-108).  Returns src, dst (int64), t (sorted float64), N.
+    pu / pi: exponents of the degree law of users / items (SURVEY.md section 8d fixes 2.0 / 3.0; 1.0 = uniform; other
+    values are for the sensitivity runs of tools/degree_sensitivity.py)."""
     rng = np.random.RandomState(seed)
     perm_u = np.random.RandomState(seed + 100).permutation(U)
     perm_i = np.random.RandomState(seed + 200).permutation(I)
-    su = np.minimum(np.floor(U * rng.random_sample(E) ** 2.0).astype(np.int64), U - 1)
-    si = np.minimum(np.floor(I * rng.random_sample(E) ** 3.0).astype(np.int64), I - 1)
+    su = np.minimum(np.floor(U * rng.random_sample(E) ** pu).astype(np.int64), U - 1)
+    si = np.minimum(np.floor(I * rng.random_sample(E) ** pi).astype(np.int64), I - 1)
     src = (1 + perm_u[su]).astype(np.int64)
     dst = (U + 1 + perm_i[si]).astype(np.int64)
     t = np.sort(rng.uniform(0, span, E)).astype(np.float64)
