@@ -240,7 +240,9 @@ def main():
             runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last, merge_outputs=False)
         el = time_leg(run, k_steps)
         runner.rp.check_device_errors()
-        return el, runner.table_bytes()
+        tb = runner.table_bytes()
+        runner.close()
+        return el, tb
 
     def cols_leg(k_steps):
         from tpnet_amd.sharded import ColumnShardedRunner

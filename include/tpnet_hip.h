@@ -263,6 +263,21 @@ int tpnet_pack_bundles(const tpnet_state* st, const int64_t* ids, int64_t n, dou
 int tpnet_unpack_bundles(const tpnet_state* st, const int64_t* local_ids, int64_t n, double now_time, const float* recv,
                          int64_t maxc, const int64_t* offs, int32_t G, void* stream);
 
+/* One batch of the compact row-sharded stream in ONE call, the exchange included: tpnet_pack_bundles(pack_ids, n_pack) into
+ * `send` ([maxc][(L+1)*d], padded), ONE RCCL all-gather into `recv` ([G][maxc][(L+1)*d]) on `stream`, tpnet_unpack_bundles
+ * (unpack_ids, n_unpack, offs), then tpnet_step_batch(b) with own_mod = 0, own_rem = n_owned.  comm: a communicator from
+ * tpnet_rccl_comm_create (NULL, or maxc = 0: no exchange, just the step).  RCCL is resolved at run time (dlopen of lib_path,
+ * else "librccl.so" -- the library PyTorch already loaded): tpnet_rccl_unique_id on one rank, the 128 bytes broadcast by the
+ * caller, tpnet_rccl_comm_create on every rank (collective: ncclCommInitRank). */
+int tpnet_rccl_unique_id(const char* lib_path, void* id128);
+int tpnet_rccl_comm_create(const char* lib_path, const void* id128, int32_t nranks, int32_t rank, void** comm);
+int tpnet_rccl_comm_destroy(void* comm);
+int tpnet_rows_step(const tpnet_state* st, void* comm, const int64_t* pack_ids, int64_t n_pack, float* send, float* recv,
+                    int64_t maxc, const int64_t* unpack_ids, int64_t n_unpack, const int64_t* offs, int32_t G,
+                    double now_time, const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
+                    int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
+                    float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
  * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,
  * per node sorted by time (stable: ties keep the reference's append order), neighbours strictly BEFORE the query
@@ -307,19 +322,6 @@ int tpnet_gram_unpack(const float* packed, int64_t n, int32_t L, uint32_t flags,
 /* Copies st->err to the host (synchronises the stream): returns TPNET_ERR_INDEX if any bad id was seen since
  * the last call (and clears the words), TPNET_OK otherwise. */
 int tpnet_check_errors(const tpnet_state* st, void* stream);
-
-/* Timing aid for bench.py (not part of the drop-in surface): elapsed milliseconds of `reps` back-to-back tpnet_run_stream
- * calls measured with hipEvents recorded on `stream` (the stream the kernels run on).  The state is advanced `reps` times;
- * the caller resets it.  For the LAST rep, hipEvent pairs around each chunk's loop of launches of the dominant kernel (planning
- * kernels and the write-back excluded) give: kernel_ms_out = their summed time / the number of launches, i.e. the average
- * launch PERIOD (kernel duration + inter-kernel boundary) of k_step (per-batch schedule: one launch per batch) or k_wpipe
- * (windowed schedule: one launch per pipeline step); launches_out = those launches; edges_out = the edges they covered
- * (up to 256 chunks).  Any of the out pointers may be NULL. */
-int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
-                      const double* t, int64_t E, int64_t batch, double now_time, double lambda,
-                      uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
-                      void* workspace, size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out,
-                      int64_t* launches_out, int64_t* edges_out, void* stream);
 
 #ifdef __cplusplus
 }

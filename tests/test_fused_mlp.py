@@ -75,3 +75,40 @@ def test_module_uses_fused_mlp_when_asked():
     assert (out - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
     out.sum().backward()
     assert rp.mlp[2].weight.grad is not None
+
+
+@pytest.mark.gpu
+def test_config5_end_to_end_bf16_mlp_on_its_own_features():
+    """BASELINE config 5 (LastFM shape: N = 1981, d = 512, B = 10 000, lambda = 1e-7) end to end: batches of the C5 stream
+    through update(), then get_pair_wise_feature on a whole batch with self.mlp on the bf16 matrix cores
+    (fused_mlp = True) against the fp32 path, on the features this config really produces (heavy reuse: log(x+1) features
+    reach far beyond the O(10) range of random inputs)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import RandomProjectionModule
+    from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+    c = CONFIGS["C5"]
+    B, nb = c["B"], 4
+    E = nb * B
+    src, dst, t, N = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
+    neg = synthetic_negatives(c["U"], N, E, B, 1)
+    torch.manual_seed(0)
+    rp = RandomProjectionModule(node_num=N, edge_num=c["E"], dim_factor=10, num_layer=3, time_decay_weight=c["lam"],
+                                device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0), not_scale=False,
+                                enforce_dim=c["d"]).to("cuda:0")
+    for b in range(nb - 1):
+        s = slice(b * B, (b + 1) * B)
+        rp.update(src[s], dst[s], t[s])
+    s = slice((nb - 1) * B, nb * B)
+    with torch.no_grad():
+        feats = rp.pair_gram(src[s], dst[s])
+        assert float(feats.max()) > 12.0                       # the range the bf16 inputs have to carry at this config
+        for u, v in ((src[s], dst[s]), (src[s], neg[s])):
+            rp.fused_mlp = False
+            want = rp.get_pair_wise_feature(u, v)
+            rp.fused_mlp = True
+            got = rp.get_pair_wise_feature(u, v)
+            assert got.shape == want.shape == (B, 64)
+            err = float((got - want).abs().max())
+            assert err < 2e-2 * max(1.0, float(want.abs().max())), err
+    rp.check_device_errors()

@@ -211,6 +211,60 @@ def test_sharded_stream_equals_single_gpu(cfg):
         assert cmp[6] < 0.6 * cmp[7], cmp
 
 
+def _c_loop_worker(port, cfg, use_c, q):
+    """One rank on RCCL with the collectives forced: the batch loop as ONE C call per batch with RCCL called from C
+    (tpnet_rows_step), or through torch.distributed -- same results as the plain single-GPU stream."""
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["TPNET_DEV_FORCE_COLLECTIVES"] = "1"
+    os.environ["TPNET_ROWS_C_LOOP"] = "1" if use_c else "0"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        import tpnet_amd
+        from tpnet_amd.sharded import ShardedStreamRunner
+        N, d, L, E, B, lam = cfg
+        src, dst, neg, t = _stream(5, N, E)
+        P0 = torch.from_numpy((np.random.RandomState(77).randn(N, d) / np.sqrt(d)).astype(np.float32))
+        runner = ShardedStreamRunner.create(node_num=N, edge_num=E, dim=d, num_layer=L, time_decay_weight=lam, device=dev,
+                                            beginning_time=np.float64(t[0]), halo_rows=3 * B)
+        runner.set_full_p0(P0)
+        D = lambda x: torch.from_numpy(x).to(dev)
+        fp, fn = runner.run_stream(D(src), D(dst), D(neg), D(t), B)
+        have_comm = bool(getattr(runner, "_comm", None))
+        layers = runner.gather_full_layers()
+        ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L, time_decay_weight=lam,
+                                               device="cuda:0", use_matrix=False, beginning_time=np.float64(t[0]),
+                                               not_scale=False, enforce_dim=d)
+        ref.random_projections[0].data = P0.clone()
+        ref = ref.to(dev)
+        rfp, rfn = ref.run_stream(D(src), D(dst), D(neg), D(t), B, schedule="batch")
+        rl = torch.stack([ref.random_projections[i].detach() for i in range(0, L + 1)])
+        runner.rp.check_device_errors()
+        runner.close()
+        q.put((have_comm, bool(torch.equal(fp, rfp)), bool(torch.equal(fn, rfn)), bool(torch.equal(layers, rl))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_c", [True, False])
+def test_row_sharded_batch_loop_with_rccl_from_c(use_c):
+    """tpnet_rows_step: pack -> RCCL all-gather (called from C through a communicator the library created from a broadcast
+    unique id) -> unpack -> step, one FFI call per batch.  With one rank every row is owned, so the results must equal the
+    plain stream BIT FOR BIT; the torch.distributed variant of the same loop is the control."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_c_loop_worker, args=(_free_port(), (500, 128, 3, 1200, 100, 2e-6), use_c, q))
+    p.start()
+    have_comm, e1, e2, e3 = q.get(timeout=300)
+    p.join(timeout=120)
+    assert have_comm == use_c
+    assert e1 and e2 and e3
+
+
 # =========================================================================================================
 # column (dim) sharding: tpnet_amd.sharded.ColumnShardedRunner
 # =========================================================================================================

@@ -26,4 +26,6 @@ for rep in range(3):
     run.run_stream(ds, dd, dn, dt, B, t_host_last=t_last, merge_outputs=False)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"rep {rep}: relabel alone {1e6 * (t1 - t0) / nb:.1f} us/step; run_stream (incl. its own relabel) {1e6 * (t2 - t1) / nb:.1f} us/step")
+print("C-side RCCL communicator:", "yes" if getattr(run, "_comm", None) else "no (torch.distributed collective)")
+run.close()
 dist.destroy_process_group()

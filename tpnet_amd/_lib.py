@@ -70,6 +70,12 @@ SIGNATURES = {
     "tpnet_pack_bundles": (C.c_int, [_SP, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),
     "tpnet_unpack_bundles": (C.c_int, [_SP, _P, C.c_int64, C.c_double, _P, C.c_int64, _P, C.c_int32, _P]),
     "tpnet_unpack_gathered": (C.c_int, [_SP, _P, C.c_int64, C.c_double, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P]),
+    "tpnet_rccl_unique_id": (C.c_int, [C.c_char_p, _P]),
+    "tpnet_rccl_comm_create": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "tpnet_rccl_comm_destroy": (C.c_int, [_P]),
+    "tpnet_rows_step": (C.c_int, [_SP, _P, _P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int64, _P, C.c_int32, C.c_double, _P, _P,
+                                  _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_uint32, C.c_uint32, C.c_int32, _P,
+                                  _P, _P, C.c_size_t, _P]),
     "tpnet_sampler_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_sampler_build": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "tpnet_sample_recent": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
@@ -88,6 +94,10 @@ SIGNATURES = {
                                           _P, _P, _P]),
     "tpnet_host_update": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,
                                     C.c_size_t, _P]),
+}
+
+# measurement aids (tpnet_amd/csrc/tpnet_dev.h): exported by the library, not part of the drop-in boundary
+DEV_SIGNATURES = {
     "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                     C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
@@ -110,7 +120,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). tpnet_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEV_SIGNATURES.items()):
         try:
             fn = getattr(lib, name)
         except AttributeError:

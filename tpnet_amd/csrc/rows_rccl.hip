@@ -1,0 +1,108 @@
+// Row-sharded stream, one batch per FFI call (include/tpnet_hip.h: tpnet_rccl_*, tpnet_rows_step): pack the owned rows the
+// batch touches -> ONE RCCL all-gather over xGMI -> unpack the other ranks' rows into the halo -> the fused step on the local
+// table, all enqueued from C on the caller's stream.  The Python runner (tpnet_amd/sharded.py) issued these as three ctypes
+// calls plus a torch.distributed collective per batch; the collective's own bookkeeping was most of the host time.
+// RCCL is resolved at run time from the library the process already has (PyTorch's librccl.so): no link-time dependency, and
+// a build without RCCL still loads.  The communicator is created here from a 128-byte unique id that the caller broadcasts
+// with whatever channel it has (torch.distributed in tpnet_amd/sharded.py).
+#include "tpnet_common.h"
+
+#include <dlfcn.h>
+#include <cstring>
+
+namespace tpnet {
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*get_unique_id)(void*) = nullptr;                                         // ncclGetUniqueId(ncclUniqueId*)
+    int (*comm_init_rank)(void**, int, void*, int) = nullptr;                      // resolved through a by-value shim below
+    int (*comm_destroy)(void*) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    void* init_sym = nullptr;
+};
+
+struct UniqueId { char internal[128]; };      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+static constexpr int kNcclFloat32 = 7;        // rccl.h: ncclFloat32 = 7
+
+static RcclApi g_rccl;
+
+static int rccl_load(const char* lib_path) {
+    if (g_rccl.handle) return TPNET_OK;
+    void* h = nullptr;
+    if (lib_path && lib_path[0]) h = dlopen(lib_path, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return TPNET_ERR_NO_DEVICE;
+    g_rccl.get_unique_id = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    g_rccl.init_sym = dlsym(h, "ncclCommInitRank");
+    g_rccl.comm_destroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
+    if (!g_rccl.get_unique_id || !g_rccl.init_sym || !g_rccl.comm_destroy || !g_rccl.all_gather) {
+        dlclose(h);
+        return TPNET_ERR_NO_DEVICE;
+    }
+    g_rccl.handle = h;
+    return TPNET_OK;
+}
+
+}  // namespace tpnet
+
+using namespace tpnet;
+
+extern "C" {
+
+int tpnet_rccl_unique_id(const char* lib_path, void* id128) {
+    if (!id128) return TPNET_ERR_BAD_ARG;
+    int rc = rccl_load(lib_path);
+    if (rc) return rc;
+    UniqueId id;
+    memset(&id, 0, sizeof(id));
+    if (g_rccl.get_unique_id(&id) != 0) return TPNET_ERR_HIP;
+    memcpy(id128, &id, sizeof(id));
+    return TPNET_OK;
+}
+
+int tpnet_rccl_comm_create(const char* lib_path, const void* id128, int32_t nranks, int32_t rank, void** comm) {
+    if (!id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks) return TPNET_ERR_BAD_ARG;
+    int rc = rccl_load(lib_path);
+    if (rc) return rc;
+    UniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    auto init = reinterpret_cast<int (*)(void**, int, UniqueId, int)>(g_rccl.init_sym);
+    void* c = nullptr;
+    if (init(&c, nranks, id, rank) != 0 || !c) return TPNET_ERR_HIP;
+    *comm = c;
+    return TPNET_OK;
+}
+
+int tpnet_rccl_comm_destroy(void* comm) {
+    if (!comm) return TPNET_OK;
+    if (!g_rccl.handle) return TPNET_ERR_BAD_ARG;
+    return g_rccl.comm_destroy(comm) == 0 ? TPNET_OK : TPNET_ERR_HIP;
+}
+
+int tpnet_rows_step(const tpnet_state* st, void* comm, const int64_t* pack_ids, int64_t n_pack, float* send, float* recv,
+                    int64_t maxc, const int64_t* unpack_ids, int64_t n_unpack, const int64_t* offs, int32_t G,
+                    double now_time, const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
+                    int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
+                    float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (G < 1 || maxc < 0 || n_pack < 0 || n_pack > maxc || n_unpack < 0) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (comm && maxc > 0) {
+        if (!g_rccl.handle || !pack_ids || !send || !recv || !unpack_ids || !offs) return TPNET_ERR_BAD_ARG;
+        const size_t bundle = (size_t)(st->L + 1) * (size_t)st->d;
+        rc = launch_pack_bundles(*st, pack_ids, n_pack, now_time, lambda, send, s);
+        if (rc) return rc;
+        // recv = [G][maxc][bundle]: every rank's padded block, in rank order (same layout as all_gather_into_tensor)
+        if (g_rccl.all_gather(send, recv, (size_t)maxc * bundle, kNcclFloat32, comm, s) != 0) return TPNET_ERR_HIP;
+        rc = launch_unpack_bundles(*st, unpack_ids, n_unpack, now_time, recv, maxc, offs, G, s);
+        if (rc) return rc;
+    }
+    return tpnet_step_batch(st, src, dst, neg, t, E, batch, b, lambda, launch_id, flags, 0, n_owned, out_pos, out_neg,
+                            workspace, ws_bytes, stream);
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/tpnet_hip.h"
+#include "tpnet_dev.h"
 
 namespace tpnet {
 

@@ -130,6 +130,48 @@ class ShardedStreamRunner:
         lib = _lib.load()
         return rp.node_num * rp.dim * 4 + lib.tpnet_q_bytes(rp.node_num, rp.dim, rp.num_layer) + lib.tpnet_meta_bytes(rp.node_num)
 
+    # ---- RCCL from C -----------------------------------------------------------------------------------------------
+    def _c_comm(self):
+        """An RCCL communicator owned by the C library (tpnet_rccl_comm_create), so that a batch's pack -> all-gather ->
+        unpack -> step is ONE FFI call (tpnet_rows_step) instead of three plus a torch.distributed collective.  The
+        128-byte unique id travels over the existing process group.  None if the group is not on RCCL or RCCL cannot be
+        resolved (the runner then issues the collective through torch.distributed)."""
+        if hasattr(self, "_comm"):
+            return self._comm
+        self._comm = None
+        if os.environ.get("TPNET_ROWS_C_LOOP", "1") == "0" or dist.get_backend(self.group) != "nccl":
+            return None
+        lib = _lib.load()
+        dev = self.rp._dev()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path_b = path.encode() if os.path.exists(path) else None
+        idbuf = (C.c_ubyte * 128)()
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        if self.me == 0 and lib.tpnet_rccl_unique_id(path_b, idbuf) != 0:
+            ok.zero_()
+        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=dev)
+        src_rank = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(t, src=src_rank, group=self.group)
+        dist.broadcast(ok, src=src_rank, group=self.group)
+        if int(ok.item()) == 0:
+            return None
+        idb = (C.c_ubyte * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            rc = lib.tpnet_rccl_comm_create(path_b, idb, self.G, self.me, C.byref(h))
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN, group=self.group)      # all ranks take the same path
+        if int(good.item()) == 1:
+            self._comm = h
+        elif rc == 0:
+            lib.tpnet_rccl_comm_destroy(h)
+        return self._comm
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            _lib.load().tpnet_rccl_comm_destroy(self._comm)
+            self._comm = None
+
     # ---- the stream -----------------------------------------------------------------------------------------------
     def relabel(self, src, dst, neg, batch_size: int):
         """Everything the per-batch loop needs, derived from the stream by every rank on its own (no request round):
@@ -217,7 +259,21 @@ class ShardedStreamRunner:
         pack, unpack, step = lib.tpnet_pack_bundles, lib.tpnet_unpack_bundles, lib.tpnet_step_batch
         flat_recv = recv_all.view(-1)
         n_own = self.n_cap
-        for b in range(nb):
+        comm = self._c_comm() if nccl else None
+        if comm is not None:
+            # RCCL from C: one call per batch enqueues pack -> all-gather -> unpack -> step on the current stream
+            rows_step = lib.tpnet_rows_step
+            for b in range(nb):
+                rc = rows_step(stp, comm, pack_ptr + 8 * off_me[b], cnt_me[b], send_ptr, recv_ptr, maxcs[b],
+                               unpack_ptr + 8 * off_0[b], tots[b], offs_ptr + 8 * G * b, G, now, ls_p, ld_p, ln_p, t_p, E, B, b,
+                               lam, lid0 + b, flags, n_own, op_p, on_p, ws_p, ws_n, stream)
+                if rc:
+                    _lib.check(rc, "rows_step")
+                now = t_last_l[b]
+            nb_done = nb
+        else:
+            nb_done = 0
+        for b in range(nb_done, nb):
             maxc = maxcs[b]
             if exchange and maxc > 0:
                 rc = pack(stp, pack_ptr + 8 * off_me[b], cnt_me[b], now, lam, send_ptr, stream)
