@@ -132,3 +132,29 @@ def test_module_copy_and_pickle_on_cpu():
     assert rp2.random_projections[0].data_ptr() != rp.random_projections[0].data_ptr()
     rp3 = pickle.loads(pickle.dumps(rp))
     assert sorted(rp3.state_dict().keys()) == sorted(rp.state_dict().keys())
+
+
+def test_layer_list_is_lazy_about_layers_1_to_L():
+    """random_projections[0], len() and .device do not count as reading layers 1..L (no dense export, no re-import);
+    reading an entry >= 1 or iterating does."""
+    rp = _mk()
+    assert isinstance(rp.random_projections, torch.nn.ParameterList) and len(rp.random_projections) == 4
+    rp._params_exposed = False
+    rp.random_projections[0]
+    rp.random_projections[-4]
+    len(rp.random_projections)
+    assert rp._params_exposed is False
+    rp.random_projections[1]
+    assert rp._params_exposed is True
+    rp._params_exposed = False
+    list(rp.random_projections)
+    assert rp._params_exposed is True
+    import copy
+    rp2 = copy.deepcopy(rp)
+    rp2._params_exposed = False
+    rp2.random_projections[2]
+    assert rp2._params_exposed is True and rp._params_exposed is True
+    rp._params_exposed = False
+    rp2.random_projections[3]
+    assert rp._params_exposed is False                       # the copy's list belongs to the copy
+    assert sorted(rp2.state_dict().keys()) == sorted(rp.state_dict().keys())

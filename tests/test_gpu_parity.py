@@ -889,3 +889,38 @@ def test_in_place_writes_through_data_are_seen():
     s = slice(3 * B, 4 * B)
     rp.update(src[s], dst[s], t[s]); O.update(st, src[s], dst[s], t[s])
     _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "after a write through state_dict()")
+
+
+@pytest.mark.parametrize("d,B,N", [(16, 100000, 48), (64, 60000, 40), (128, 40000, 64)])
+def test_version_protocol_under_multi_pass_grids(d, B, N):
+    """The ping-pong / version protocol under the worst interleaving the per-batch kernel can produce: a batch far larger
+    than the grid (several grid-stride rounds) on a graph so small that EVERY node is rewritten early in the launch (by
+    the hub workgroups, which lead the grid) and read by pairs that start many rounds later, when the writers are long
+    done -- the case the launch-id check of a reader exists for (device_common.hpp meta_view: a ver stamped by THIS launch
+    means the other copy is the pre-batch one).  Every readout must see pre-batch rows (oracle), run to run bit-identical."""
+    _need_gpu()
+    L, lam = 3, 1e-6
+    rng = np.random.RandomState(d + N)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    E = 2 * B
+    src = rng.randint(1, N, E).astype(np.int64)
+    dst = rng.randint(1, N, E).astype(np.int64)
+    neg = rng.randint(1, N, E).astype(np.int64)
+    t = np.sort(rng.uniform(0, 5e5, E))
+    D = lambda x: torch.from_numpy(x).to(DEV)
+    outs = []
+    for rep in range(2):
+        rp = _module(N, d, L, lam, 0.0, P0)
+        fp, fn = rp.run_stream(D(src), D(dst), D(neg), D(t), B, schedule="batch")
+        outs.append((fp.clone(), fn.clone(), _layers(rp)))
+        rp.check_device_errors()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    st = O.OracleState(P0, L, lam, 0.0)
+    for b in range(2):
+        s = slice(b * B, (b + 1) * B)
+        sub = rng.choice(B, 3000, replace=False) + b * B           # a sample of the batch's pairs against the oracle
+        _assert_features(outs[0][0][sub].cpu().numpy(), st, src[sub], dst[sub], f"batch {b} pos")
+        _assert_features(outs[0][1][sub].cpu().numpy(), st, src[sub], neg[sub], f"batch {b} neg")
+        O.update(st, src[s], dst[s], t[s])
+    _assert_state(outs[0][2], np.stack(st.P[1:]), 2e-4, "state")

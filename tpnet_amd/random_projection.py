@@ -16,6 +16,7 @@ How the state is held:
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -29,6 +30,35 @@ _MAX_LAUNCH_ID = 0x7FFFFFFF - (1 << 24)
 
 # the current stream's raw handle without building a torch.cuda.Stream object (the hot methods need it every call)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+
+
+_OWNERS = weakref.WeakValueDictionary()      # id(module) -> module, for the lazy layer list below
+
+
+class _LazyLayers(nn.ParameterList):
+    """`random_projections` as the reference has it (an nn.ParameterList of L+1 [N, d] Parameters, models/TPNet.py:39-62)
+    whose entries 1..L are brought up to date only when somebody actually reads one of THEM: the engine keeps those layers
+    in its own layout, and the dense export (N*L*d floats) is not something a caller that touches `random_projections[0]`,
+    `len(...)` or `.device` once per batch should pay for.  Reading an entry >= 1 (or iterating) materialises them and marks
+    them as handed out (they may then be written in place through `.data`: the next engine call re-imports them)."""
+
+    def _tp_owner(self):
+        return _OWNERS.get(self.__dict__.get("_tp_owner_key"))
+
+    def _tp_touch(self, idx):
+        if isinstance(idx, int) and (idx == 0 or idx == -len(self)):
+            return                                   # layer 0 IS the kernels' buffer: always current
+        o = self._tp_owner()
+        if o is not None:
+            o._layers_read()
+
+    def __getitem__(self, idx):
+        self._tp_touch(idx)
+        return super().__getitem__(idx)
+
+    def __iter__(self):
+        self._tp_touch(None)
+        return super().__iter__()
 
 
 class _Stage:
@@ -77,7 +107,7 @@ class RandomProjectionModule(nn.Module):
         self.begging_time = nn.Parameter(torch.tensor(beginning_time), requires_grad=False)
         self.now_time = nn.Parameter(torch.tensor(beginning_time), requires_grad=False)
         self.device = device
-        self.random_projections = nn.ParameterList()
+        self.random_projections = _LazyLayers()
         self.use_matrix = use_matrix
         self.node_feature_dim = 128
         self.not_scale = not_scale
@@ -122,22 +152,31 @@ class RandomProjectionModule(nn.Module):
         # looked up once: nn.ParameterList.__getitem__ costs microseconds and the hot methods need them every call
         refs = self.__dict__.get("_param_refs")
         if refs is None or len(refs) != self.num_layer + 1:
-            refs = list(self._modules["random_projections"])
+            refs = list(nn.ParameterList.__iter__(self._modules["random_projections"]))   # (not the lazy list's own iterator)
             self.__dict__["_param_refs"] = refs
         return refs
 
     def __getattr__(self, name):
         # external readers of `random_projections` / `now_time` see the reference's eager values
         if name == "random_projections" and "_modules" in self.__dict__:
-            # whoever gets the ParameterList may write its tensors in place through `.data` (p.data.copy_(), p.data[i] = ...:
-            # the idiom of the reference's MatrixMemory), which changes neither data_ptr nor _version: the next engine call
-            # re-imports the layers (see _ensure_engine)
-            self.__dict__["_params_exposed"] = True
-            if not self.__dict__.get("_params_valid", True):
-                self._materialize()
+            # the list itself is handed out as is; its entries 1..L are materialised when one of them is read (_LazyLayers)
+            pl = self.__dict__["_modules"].get("random_projections")
+            if isinstance(pl, _LazyLayers):
+                pl.__dict__["_tp_owner_key"] = id(self)
+                _OWNERS[id(self)] = self
+            else:                                    # (a plain list put there by somebody else: the eager behaviour)
+                self._layers_read()
         elif name == "now_time" and self.__dict__.get("_now_dirty", False):
             self._sync_now_time()
         return super().__getattr__(name)
+
+    def _layers_read(self):
+        """An entry 1..L of `random_projections` is being handed out: bring the Parameters up to date, and remember that
+        whoever got one may write it in place through `.data` (p.data.copy_(), p.data[i] = ...: the idiom of the reference's
+        MatrixMemory), which changes neither data_ptr nor _version -- the next engine call re-imports the layers."""
+        self.__dict__["_params_exposed"] = True
+        if not self.__dict__.get("_params_valid", True):
+            self._materialize()
 
     def _sync_now_time(self):
         """The clock Parameter is written lazily: the hot methods keep the clock on the host (`_now_host`) and mark the
