@@ -311,6 +311,9 @@ static uint32_t heavy_threshold_for(int64_t batch, uint32_t flags) {
     return thr;
 }
 
+int plan_blocks(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t, int64_t Ec,
+                int64_t B, double now_time, const double* t_prev_dev, double lambda, uint32_t flags, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------------------------
 // The plan of ONE batch of up to PLAN_ONE_MAX edges in ONE workgroup (tpnet_update / tpnet_host_update: the per-batch call
 // of the reference's loop, train_link_prediction.py:372): edges staged in LDS, the 2B (target, contribution) keys sorted
@@ -320,10 +323,23 @@ static uint32_t heavy_threshold_for(int64_t batch, uint32_t flags) {
 // device-mapped HOST memory (tpnet_host_update): each is read once, coalesced.
 // ---------------------------------------------------------------------------------------------------------------
 template <int BS, int IPT>
-__global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
-                                                 const double* __restrict__ t, int32_t B, int64_t N, int node_bits,
-                                                 double now_time, double lambda, int L, uint32_t heavy_threshold,
-                                                 uint32_t* err) {
+__global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restrict__ src_c, const int64_t* __restrict__ dst_c,
+                                                 const double* __restrict__ t_c, int64_t Ec, int32_t Bfull, int64_t N,
+                                                 int node_bits, double now_time, const double* __restrict__ t_prev,
+                                                 double lambda, int L, uint32_t heavy_threshold, uint32_t* err) {
+    // workgroup b plans batch b of the chunk: edges [b * Bfull, ...), sorted positions [2 * b * Bfull, ...) (as plan_build lays
+    // a chunk out); a single-batch call is the chunk of one batch
+    const int64_t bb = blockIdx.x;
+    const int64_t e0 = bb * Bfull;
+    const int32_t B = (int32_t)((Ec - e0 < Bfull) ? (Ec - e0) : Bfull);
+    const int64_t* __restrict__ src = src_c + e0;
+    const int64_t* __restrict__ dst = dst_c + e0;
+    const double* __restrict__ t = t_c + e0;
+    p.s_partner += 2 * e0;
+    p.s_coef += 2 * e0;
+    p.s_target += 2 * e0;
+    p.light += 2 * e0;
+    p.heavy += 2 * e0;
     using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
     constexpr int NC = BS * IPT;
     __shared__ union U {
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
                 if (u.s.key[mid] == key) lo = mid; else hi = mid;
             }
             Item it;
-            it.j0 = (uint32_t)j;
+            it.j0 = (uint32_t)(2 * e0 + j);                    // chunk-relative position in the sorted arrays
             it.cnt = (uint32_t)(hi - j);
             it.target = (int32_t)key;
             it.p0 = partner;
@@ -435,17 +451,17 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
     __syncthreads();
     if (tid == 0) {
         BatchDesc D;
-        D.e0 = 0;
+        D.e0 = e0;
         D.ne = B;
         D.pad = 0;
         D.t_last = t_last;
-        D.now = now_time;
+        D.now = (bb == 0) ? (t_prev ? *t_prev : now_time) : t_c[e0 - 1];   // clock left by the previous batch (TPNet.py:99)
         D.n_light = n_light;
         D.n_heavy = n_heavy;
-        const double g = exp(-lambda * (t_last - now_time));
+        const double g = exp(-lambda * (t_last - D.now));
         for (int i = 0; i < TPNET_MAX_LAYERS; ++i)
             D.decay[i] = (i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;
-        p.desc[0] = D;
+        p.desc[bb] = D;
     }
 }
 
@@ -456,14 +472,22 @@ int64_t plan_one_max_batch() {
 
 int plan_one(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
              double now_time, double lambda, uint32_t flags, hipStream_t s) {
-    if (B < 1 || B > PLAN_ONE_MAX) return TPNET_ERR_BAD_ARG;
+    return plan_blocks(st, p, src, dst, t, B, B, now_time, nullptr, lambda, flags, s);
+}
+
+// every batch of a chunk by its own workgroup, ONE launch (batches of up to PLAN_ONE_MAX edges)
+int plan_blocks(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t, int64_t Ec,
+                int64_t B, double now_time, const double* t_prev_dev, double lambda, uint32_t flags, hipStream_t s) {
+    if (B < 1 || B > PLAN_ONE_MAX || Ec < 1) return TPNET_ERR_BAD_ARG;
+    const int64_t nbl = (Ec + B - 1) / B;
+    if (nbl > 0x7FFFFFFF) return TPNET_ERR_BAD_ARG;
     const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
     if (node_bits > 31) return TPNET_ERR_BAD_ARG;
     const uint32_t thr = heavy_threshold_for(B, flags);
     static const int bs_env = getenv("TPNET_DEV_PLAN_ONE_BS") ? atoi(getenv("TPNET_DEV_PLAN_ONE_BS")) : 0;   // developer override
 #define TPNET_PLAN_ONE(BS_, IPT_)                                                                                         \
-    hipLaunchKernelGGL((k_plan_one<BS_, IPT_>), dim3(1), dim3(BS_), 0, s, p, src, dst, t, (int32_t)B, st.N, node_bits,   \
-                       now_time, lambda, (int)st.L, thr, st.err)
+    hipLaunchKernelGGL((k_plan_one<BS_, IPT_>), dim3((unsigned)nbl), dim3(BS_), 0, s, p, src, dst, t, Ec, (int32_t)B, st.N,   \
+                       node_bits, now_time, t_prev_dev, lambda, (int)st.L, thr, st.err)
     const int64_t nc = 2 * B;
     if (nc <= 512) {
         if (bs_env == 512) TPNET_PLAN_ONE(256, 2); else TPNET_PLAN_ONE(256, 2);
@@ -487,6 +511,10 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
     const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
     const int batch_bits = ceil_log2_u64((uint64_t)nb) < 1 ? 1 : ceil_log2_u64((uint64_t)nb);
     if (node_bits + batch_bits > 64) return TPNET_ERR_BAD_ARG;
+    // batches that fit one workgroup's LDS: every batch planned by its own workgroup in ONE launch (keys, sort, item lists and
+    // descriptors; no device-wide sort, no second pass over the sorted keys) -- a 20-batch call at C2: 65 -> ~25 us of planning
+    if (batch <= plan_one_max_batch() && !(flags & PLAN_FUSE) && node_bits <= 31)
+        return plan_blocks(st, p, src, dst, t, Ec, batch, now_time, t_prev_dev, lambda, flags, s);
 
     int grid = (int)((nc + 255) / 256);
     if (grid > 4096) grid = 4096;
