@@ -88,7 +88,7 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
         const int64_t nw0 = (nb + Kmax - 1) / Kmax;
         const int K = (int)((nb + nw0 - 1) / nw0);
         WPlan p{};
-        int rc = wplan_carve(ws, ws_bytes, Ec, batch, st.d, st.L, K, &p);
+        int rc = wplan_carve(ws, ws_bytes, Ec, batch, st.N, st.d, st.L, K, &p);
         if (rc) return rc;
         const bool have_readout = out_pos || out_neg;
         rc = wplan_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,

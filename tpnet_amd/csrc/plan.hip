@@ -599,7 +599,7 @@ int64_t wplan_max_chunk_edges(int64_t batch, int d, int L) {
     return e < batch ? batch : e;
 }
 
-static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int d, int L, int K) {
+static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int L, int K) {
     const size_t nc = 2 * (size_t)Ec;
     const int64_t Ew = (int64_t)K * batch;
     const size_t nw = (size_t)((Ec + Ew - 1) / Ew);
@@ -609,25 +609,25 @@ static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int d, int L, int K) 
     tot += align_up(nw * sizeof(WinDesc), 256) + 256;           // wdesc, wb_count
     tot += align_up(3 * (size_t)Ec * 4, 256) * 2;               // e_ref, e_g
     tot += align_up(nc * (size_t)L * (size_t)d * 4, 256);       // version log
+    tot += align_up((size_t)N * 4, 256) * 2;                    // node_lo, node_hi
     return tot + 256;
 }
 
 size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L) {
-    (void)N;
     if (max_edges < 1) max_edges = 1;
     if (batch < 1) batch = 1;
     const int K = wplan_window_batches(batch, d, L);
     if (K == 0) return plan_bytes(max_edges, batch);
-    return plan_bytes(max_edges, batch) + wplan_extra_bytes(max_edges, batch, d, L, K);
+    return plan_bytes(max_edges, batch) + wplan_extra_bytes(max_edges, batch, N, d, L, K);
 }
 
-int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int L, int K, WPlan* out) {
+int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out) {
     if (K < 1 || K > WIN_MAX_BATCHES || K > wplan_window_batches(batch, d, L)) return TPNET_ERR_BAD_ARG;
     if (Ec > wplan_max_chunk_edges(batch, d, L)) return TPNET_ERR_BAD_ARG;
     int rc = plan_carve(ws, ws_bytes, Ec, batch, &out->base);
     if (rc) return rc;
     const size_t base_bytes = plan_bytes(Ec, batch);
-    if (base_bytes + wplan_extra_bytes(Ec, batch, d, L, K) > ws_bytes) return TPNET_ERR_WORKSPACE;
+    if (base_bytes + wplan_extra_bytes(Ec, batch, N, d, L, K) > ws_bytes) return TPNET_ERR_WORKSPACE;
     char* p = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(ws), 256)) + align_up(base_bytes, 256);
     // (plan_carve aligned the base the same way; plan_bytes includes its slack)
     auto take = [&](size_t bytes) -> void* {
@@ -647,6 +647,8 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int
     out->e_ref = (uint32_t*)take(3 * (size_t)Ec * 4);
     out->e_g = (float*)take(3 * (size_t)Ec * 4);
     out->log = (float*)take(nc * (size_t)L * (size_t)d * 4);
+    out->node_lo = (uint32_t*)take((size_t)N * 4);
+    out->node_hi = (uint32_t*)take((size_t)N * 4);
     out->chains = reinterpret_cast<Chain*>(out->base.light);
     out->chains_sparse = reinterpret_cast<Chain*>(out->base.heavy);
     // the second sort's keys live where the first sort's unsorted keys were (8 bytes per contribution, dead by then), its
@@ -705,10 +707,15 @@ template <typename K>
 __device__ __forceinline__ void resolve_version(const K* __restrict__ keys, int64_t nc, int batch_bits, int64_t node,
                                                 int64_t b, const BatchDesc* __restrict__ desc,
                                                 const NodeMeta* __restrict__ meta, double lambda, double t_to,
-                                                uint32_t& ref, float& g) {
+                                                uint32_t& ref, float& g, const uint32_t* __restrict__ node_lo,
+                                                const uint32_t* __restrict__ node_hi) {
     const K skey = (K)(((uint64_t)node << batch_bits) | (uint64_t)b);
-    const int64_t pos = lower_bound_keys(keys, (int64_t)0, nc, skey);
-    if (pos > 0) {
+    // the node's own range of sorted positions bounds the search (k_node_ranges): a handful of steps for a typical node
+    // instead of log2(2 * Ec) dependent loads over the whole chunk; [0, 0) for a node that is no target in this chunk
+    const int64_t lo = node_lo[node], hi = node_hi[node];
+    const int64_t pos = lower_bound_keys(keys, lo, hi, skey);
+    (void)nc;
+    if (pos > lo) {
         const K pk = keys[pos - 1];
         if ((pk >> batch_bits) == (skey >> batch_bits)) {
             ref = (uint32_t)(pos - 1);                              // the run's tail position = its log slot
@@ -784,7 +791,7 @@ __device__ __forceinline__ void finish_w(uint32_t bx, uint32_t nbx, WPlan p, con
             const int64_t ri = j - h;
             uint32_t ref;
             float g;
-            resolve_version(keys, nc, batch_bits, (int64_t)partner, b, desc, meta, lambda, Tb, ref, g);
+            resolve_version(keys, nc, batch_bits, (int64_t)partner, b, desc, meta, lambda, Tb, ref, g, p.node_lo, p.node_hi);
             uint32_t fl = 0;
             if (run_head) fl |= WREF_RUN_HEAD;
             if (run_tail) fl |= WREF_RUN_TAIL;
@@ -889,9 +896,21 @@ __device__ __forceinline__ void edge_refs(uint32_t bx, uint32_t nbx, WPlan p, co
         const int64_t b = e / B;
         uint32_t ref;
         float g;
-        resolve_version(keys, nc, batch_bits, node, b, p.base.desc, meta, lambda, p.base.desc[b].now, ref, g);
+        resolve_version(keys, nc, batch_bits, node, b, p.base.desc, meta, lambda, p.base.desc[b].now, ref, g, p.node_lo, p.node_hi);
         p.e_ref[x] = ref;
         p.e_g[x] = g;
+    }
+}
+
+// [node_lo[n], node_hi[n]) = the sorted positions of node n's contributions in the chunk (both 0 for a node without any:
+// the arrays are zeroed first)
+template <typename K>
+__global__ void k_node_ranges(const K* __restrict__ keys, int64_t nc, int batch_bits, uint32_t* __restrict__ node_lo,
+                              uint32_t* __restrict__ node_hi) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
+        const K node = keys[j] >> batch_bits;
+        if (j == 0 || (keys[j - 1] >> batch_bits) != node) node_lo[node] = (uint32_t)j;
+        if (j == nc - 1 || (keys[j + 1] >> batch_bits) != node) node_hi[node] = (uint32_t)(j + 1);
     }
 }
 
@@ -948,6 +967,13 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     // (the second sort's payload array is the first sort's payload INPUT: dead since the first sort ran; its OUTPUT is read
     // by k_finish_w, which writes position j to lv_in[j] -- a different array)
     const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(st.meta);
+    TPNET_HIP_TRY(hipMemsetAsync(p.node_lo, 0, (size_t)st.N * 4, s));
+    TPNET_HIP_TRY(hipMemsetAsync(p.node_hi, 0, (size_t)st.N * 4, s));
+    if (narrow)
+        hipLaunchKernelGGL(k_node_ranges<uint32_t>, dim3(grid), dim3(256), 0, s, k32_out, nc, batch_bits, p.node_lo, p.node_hi);
+    else
+        hipLaunchKernelGGL(k_node_ranges<uint64_t>, dim3(grid), dim3(256), 0, s, p.base.keys_out, nc, batch_bits, p.node_lo,
+                           p.node_hi);
     if (narrow)
         hipLaunchKernelGGL(k_plan_w<uint32_t>, dim3(grid + (want_readout ? egrid : 0)), dim3(256), 0, s, p, k32_out, src, dst,
                            neg, t, Ec, batch, st.N, batch_bits, lambda, p.lk_in, p.lv_in, lk_none, meta, st.err, (uint32_t)grid);

@@ -227,6 +227,8 @@ struct WPlan {
     uint32_t* e_ref;      // [3][Ec] readout: version of src / dst / neg of every edge before its batch
     float* e_g;           // [3][Ec]
     float* log;           // [2*Ec][L][d] version log of the chunk (only the slots of run tails are ever touched)
+    uint32_t* node_lo;    // [N] first / one-past-last sorted position of every node's contributions in the chunk (0, 0: none)
+    uint32_t* node_hi;
     int32_t K;            // batches per window
     int64_t Ew;           // edges per full window = K * batch
 };
@@ -234,7 +236,7 @@ struct WPlan {
 size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L);
 int wplan_window_batches(int64_t batch, int d, int L);                 // 0 = the windowed path does not apply
 int64_t wplan_max_chunk_edges(int64_t batch, int d, int L);            // edges one plan (and its log) may cover
-int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int d, int L, int K, WPlan* out);   // K <= wplan_window_batches
+int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out);   // K <= wplan_window_batches
 int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                 const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
                 bool want_readout, hipStream_t s);
