@@ -299,6 +299,15 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
 int tpnet_mlp64_bf16(const float* x, int64_t n, const void* w1_bf16, const float* b1, const void* w2p_bf16,
                      const float* b2, float* y, void* stream);
 
+/* get_pair_wise_feature with self.mlp on the bf16 matrix cores INSIDE the readout kernel (L = 3, d % 4 == 0 and d >= 64):
+ * 8 waves form the features of 32 pairs into an LDS tile, which is the B operand of layer 1; wave w owns hidden units
+ * [32w, 32w+32) of both layers, the 8 partial outputs are added in a fixed order.  The features never touch HBM (out_gram,
+ * optional: a copy for a backward pass).  Weights as for tpnet_mlp64_bf16 (w1_bf16 [256][64], w2p_bf16 [64][256] permuted).
+ * bf16 operands, fp32 accumulation: ~1e-2 relative, opt-in (RandomProjectionModule.fused_mlp). */
+int tpnet_pair_feature_bf16(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
+                            double lambda, uint32_t flags, const void* w1_bf16, const float* b1, const void* w2p_bf16,
+                            const float* b2, float* out_gram, float* out, void* stream);
+
 /* LinkPredictor_v1 (models/modules.py:73-117): out[p] = fc2(relu(fc1(concat[src_emb[p], dst_emb[p], feat[p]]))) with ONE
  * output unit, both layers in one bf16 matrix-core kernel (fp32 accumulate); neither the concatenation nor the hidden
  * layer touches memory.  src_emb, dst_emb: device f32 [n][D] (D % 4 == 0; both NULL = the reference's not_encode mode,

@@ -112,3 +112,86 @@ def test_config5_end_to_end_bf16_mlp_on_its_own_features():
             err = float((got - want).abs().max())
             assert err < 2e-2 * max(1.0, float(want.abs().max())), err
     rp.check_device_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [64, 128, 256, 512, 120, 36])
+def test_readout_with_mlp_on_the_matrix_cores_in_one_kernel(d):
+    """tpnet_pair_feature_bf16 (features formed into LDS, consumed there by the bf16 MFMA layers) against the fp32 path:
+    outputs within the bf16 tolerance, run-to-run identical bits, gradients of the four weight tensors (the exact
+    lane / register / permutation mapping is pinned by the integer test below)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import RandomProjectionModule
+    from tpnet_amd import fused_mlp as fm
+    rng = np.random.RandomState(d)
+    N = 300
+    rp = RandomProjectionModule(node_num=N, edge_num=2000, dim_factor=10, num_layer=3, time_decay_weight=1e-6,
+                                device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0), not_scale=False,
+                                enforce_dim=d).to("cuda:0")
+    t0 = 0.0
+    for _ in range(3):
+        src, dst = rng.randint(1, N, 200), rng.randint(1, N, 200)
+        t = np.sort(rng.uniform(t0, t0 + 1e5, 200)); t0 = t[-1]
+        rp.update(src, dst, t)
+    assert fm.readout_supported(rp)
+    for n in (1, 31, 32, 33, 1000, 4099):
+        u, v = rng.randint(0, N, n).astype(np.int64), rng.randint(0, N, n).astype(np.int64)
+        with torch.no_grad():
+            rp.fused_mlp = False
+            want = rp.get_pair_wise_feature(u, v)
+            gram = rp.pair_gram(u, v)
+            rp.fused_mlp = True
+            got = rp.get_pair_wise_feature(u, v)
+            again = rp.get_pair_wise_feature(u, v)
+        assert got.shape == (n, 64)
+        assert torch.equal(got, again)                                        # fixed summation order over the 8 waves
+        err = float((got - want).abs().max())
+        assert err < 2e-2 * max(1.0, float(want.abs().max())), (n, err)
+    # gradients (grad mode: the kernel also writes the pre-mlp features)
+    rp.fused_mlp = True
+    u, v = rng.randint(0, N, 500).astype(np.int64), rng.randint(0, N, 500).astype(np.int64)
+    got = rp.get_pair_wise_feature(u, v)
+    rp.fused_mlp = False
+    want = rp.mlp(rp.pair_gram(u, v))
+    gy = torch.randn_like(want)
+    gw = torch.autograd.grad(want, list(rp.mlp.parameters()), gy)
+    gf = torch.autograd.grad(got, list(rp.mlp.parameters()), gy)
+    for a, b in zip(gf, gw):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-3)
+    rp.check_device_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [64, 128, 256, 512, 120, 36])
+def test_readout_with_mlp_in_one_kernel_is_exact_on_integers(d):
+    """Sparse +-1 projections (raw Gram entries are small integers: not_scale=True), small-integer weights: every product and
+    sum is exact in bf16 x bf16 -> fp32, so the fused kernel must equal the fp32 torch layers on the fp32 readout BIT FOR BIT
+    -- any wrong lane / register / hidden-tile / permutation mapping shows."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import RandomProjectionModule
+    N = 200
+    rp = RandomProjectionModule(node_num=N, edge_num=2000, dim_factor=10, num_layer=3, time_decay_weight=1e-6,
+                                device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0), not_scale=True,
+                                enforce_dim=d).to("cuda:0")
+    g = torch.Generator().manual_seed(d)
+    P0 = torch.zeros(N, d)
+    for i in range(N):
+        idx = torch.randperm(d, generator=g)[:4]
+        P0[i, idx] = torch.randint(0, 2, (4,), generator=g).float() * 2 - 1
+    rp.random_projections[0].data.copy_(P0.cuda())
+    with torch.no_grad():
+        rp.mlp[0].weight.copy_(torch.randint(-1, 2, (256, 64), generator=g).float())
+        rp.mlp[0].bias.copy_(torch.randint(-8, 9, (256,), generator=g).float())
+        rp.mlp[2].weight.copy_(torch.randint(-2, 3, (64, 256), generator=g).float())
+        rp.mlp[2].bias.copy_(torch.randint(-8, 9, (64,), generator=g).float())
+    rng = np.random.RandomState(d)
+    for n in (1, 31, 32, 33, 1000, 4097):
+        u, v = rng.randint(0, N, n).astype(np.int64), rng.randint(0, N, n).astype(np.int64)
+        with torch.no_grad():
+            rp.fused_mlp = False
+            want = rp.get_pair_wise_feature(u, v)
+            rp.fused_mlp = True
+            got = rp.get_pair_wise_feature(u, v)
+        assert torch.equal(got, want), f"n={n}: max |delta| {(got - want).abs().max().item()}"

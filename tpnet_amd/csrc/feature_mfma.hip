@@ -1,0 +1,180 @@
+// SURVEY.md §8 f-1 as written / BASELINE config 5: self.mlp = Linear(64,256) -> ReLU -> Linear(256,64)
+// (models/TPNet.py:64-65,129) on the bf16 matrix cores INSIDE the readout kernel: a workgroup of 8 waves forms the Gram
+// features of 32 pairs (models/TPNet.py:119-128) into an LDS tile, which is then the B operand (X^T) of layer 1 --
+// wave w owns hidden tile w (32 of the 256 units): H^T = W1[32w.., :] . X^T by v_mfma_f32_32x32x16_bf16, bias + ReLU in
+// registers, and its accumulator tile is directly the B operand of its slice of layer 2 (Y^T += W2[:, 32w..] . H^T, W2
+// pre-permuted as in mlp.hip).  The eight partial Y tiles are added in a FIXED order through LDS (run-to-run identical
+// bits).  The features never leave the chip; the weights of a wave (its 32 rows of W1, its 32 columns of W2: 48 VGPRs)
+// are loaded once per workgroup.  bf16 operands, fp32 accumulation: 2e-2 class like tpnet_mlp64_bf16 -- opt-in.  L = 3.
+#include "readout.hpp"
+
+namespace tpnet {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+static constexpr int MB = 512;            // threads per workgroup: 8 waves = the 8 hidden tiles
+static constexpr int MF = 64, MH = 256;
+static constexpr int TS = 68;             // floats per LDS row of the feature / partial tiles (64 + 4: bank spread)
+
+template <int LPP, int VPL, int W, bool FULL>
+__global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const int64_t* __restrict__ u,
+                                                          const int64_t* __restrict__ v, int64_t n, double now,
+                                                          double lambda, uint32_t flags, const __bf16* __restrict__ w1,
+                                                          const float* __restrict__ b1, const __bf16* __restrict__ w2p,
+                                                          const float* __restrict__ b2, float* __restrict__ out_gram,
+                                                          float* __restrict__ out) {
+    constexpr int L = 3;
+    constexpr int GPB = MB / LPP;             // pairs per readout pass
+    constexpr int PT = 32 / GPB;              // passes per 32-pair tile
+    static_assert(GPB * PT == 32 && LPP >= 16, "k_pair_feature_bf16: 16, 32 or 64 lanes per pair");
+    __shared__ __attribute__((aligned(16))) float feat[32 * TS];
+    __shared__ __attribute__((aligned(16))) float slab[4][32 * TS];
+    __shared__ float stage1[1];
+    const int tid = threadIdx.x;
+    const int gl = tid % LPP, g = tid / LPP;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    // ---- this wave's weights: rows [32 wave, 32 wave + 32) of W1 as A operand, the matching columns of (permuted) W2
+    bf16x8 a1[4], a2[2][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const bf16x8*>(w1 + (wave * 32 + r) * MF + 16 * s + 8 * h);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int off = wave * 32 + 16 * s2 + 8 * h;          // position inside the PERMUTED hidden axis
+        a2[s2][0] = *reinterpret_cast<const bf16x8*>(w2p + r * MH + off);
+        a2[s2][1] = *reinterpret_cast<const bf16x8*>(w2p + (32 + r) * MH + off);
+    }
+    float bias1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bias1[q] = b1[wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h];
+
+    const int64_t ntiles = (n + 31) / 32;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- the features of the tile's 32 pairs -> LDS
+#pragma unroll 1
+        for (int pass = 0; pass < PT; ++pass) {
+            const int pidx = pass * GPB + g;
+            const int64_t p = tile * 32 + pidx;
+            const bool valid = p < n;
+            const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
+            gram_pair<LPP, VPL, W, L, FULL, false, false, false>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
+                                                                 feat + pidx * TS, gl, nullptr, stage1);
+        }
+        __syncthreads();
+        const int npair = (n - tile * 32 < 32) ? (int)(n - tile * 32) : 32;
+        if (out_gram) {                           // the pre-mlp features, for a backward pass (training)
+            for (int i = tid; i < npair * MF; i += MB) out_gram[tile * 32 * MF + i] = feat[(i / MF) * TS + (i % MF)];
+        }
+        // ---- layer 1, hidden tile `wave`: H^T = W1 . X^T; lane (r, h) holds X[pair r][16 s + 8 h + j] as B operand
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* xr = feat + r * TS + 16 * s + 8 * h;
+            const float4 lo = *reinterpret_cast<const float4*>(xr);
+            const float4 hi = *reinterpret_cast<const float4*>(xr + 4);
+            bf16x8 bx;
+            bx[0] = (__bf16)lo.x; bx[1] = (__bf16)lo.y; bx[2] = (__bf16)lo.z; bx[3] = (__bf16)lo.w;
+            bx[4] = (__bf16)hi.x; bx[5] = (__bf16)hi.y; bx[6] = (__bf16)hi.z; bx[7] = (__bf16)hi.w;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bx, acc, 0, 0, 0);
+        }
+        // register q = hidden row 32 wave + (q&3) + 8 (q>>2) + 4 h, column = pair r  ->  bias, ReLU, B operand of layer 2
+        bf16x8 bh[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float x = acc[q] + bias1[q];
+            x = x > 0.0f ? x : 0.0f;
+            bh[q >> 3][q & 7] = (__bf16)x;
+        }
+        f32x16 y0, y1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { y0[q] = 0.0f; y1[q] = 0.0f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][0], bh[s2], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][1], bh[s2], y1, 0, 0, 0);
+        }
+        // ---- the eight partial tiles, added in a fixed order: waves 0..3 park theirs, waves 4..7 add theirs on top, then
+        // every thread sums the four slabs for its outputs.  y0[4i..4i+3] = outputs 8i + 4h + (0..3) of pair r, y1: + 32
+        float* sl = slab[wave & 3] + r * TS;
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = 8 * i + 4 * h;
+                *reinterpret_cast<float4*>(sl + o) = make_float4(y0[4 * i], y0[4 * i + 1], y0[4 * i + 2], y0[4 * i + 3]);
+                *reinterpret_cast<float4*>(sl + 32 + o) = make_float4(y1[4 * i], y1[4 * i + 1], y1[4 * i + 2], y1[4 * i + 3]);
+            }
+        }
+        __syncthreads();
+        if (wave >= 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = 8 * i + 4 * h;
+                float4 a = *reinterpret_cast<float4*>(sl + o), b = *reinterpret_cast<float4*>(sl + 32 + o);
+                a.x += y0[4 * i]; a.y += y0[4 * i + 1]; a.z += y0[4 * i + 2]; a.w += y0[4 * i + 3];
+                b.x += y1[4 * i]; b.y += y1[4 * i + 1]; b.z += y1[4 * i + 2]; b.w += y1[4 * i + 3];
+                *reinterpret_cast<float4*>(sl + o) = a;
+                *reinterpret_cast<float4*>(sl + 32 + o) = b;
+            }
+        }
+        __syncthreads();
+        {
+            const int pair = tid >> 4, o = (tid & 15) * 4;      // 512 threads x 4 outputs = 32 pairs x 64
+            if (pair < npair) {
+                const float4 s0 = *reinterpret_cast<const float4*>(slab[0] + pair * TS + o);
+                const float4 s1 = *reinterpret_cast<const float4*>(slab[1] + pair * TS + o);
+                const float4 s2 = *reinterpret_cast<const float4*>(slab[2] + pair * TS + o);
+                const float4 s3 = *reinterpret_cast<const float4*>(slab[3] + pair * TS + o);
+                const float4 bb = *reinterpret_cast<const float4*>(b2 + o);
+                float4 y;
+                y.x = ((s0.x + s1.x) + (s2.x + s3.x)) + bb.x;
+                y.y = ((s0.y + s1.y) + (s2.y + s3.y)) + bb.y;
+                y.z = ((s0.z + s1.z) + (s2.z + s3.z)) + bb.z;
+                y.w = ((s0.w + s1.w) + (s2.w + s3.w)) + bb.w;
+                *reinterpret_cast<float4*>(out + (tile * 32 + pair) * MF + o) = y;
+            }
+        }
+        __syncthreads();                          // the tiles are reused by the next tile of this workgroup
+    }
+}
+
+int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
+                             uint32_t flags, const void* w1, const float* b1, const void* w2p, const float* b2,
+                             float* out_gram, float* out, hipStream_t s) {
+    if (n == 0) return TPNET_OK;
+    if (st.L != 3 || (flags & TPNET_FLAG_PACKED)) return TPNET_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(b2)) & 15) return TPNET_ERR_BAD_ARG;
+    const Geom gm = pick_geom(st.d);
+    if (gm.w != 4 || gm.lpp < 16) return TPNET_ERR_BAD_ARG;       // narrow / scalar rows: readout kernel + tpnet_mlp64_bf16
+    const bool full = st.d == gm.lpp * gm.vpl * 4;
+    const int64_t tiles = (n + 31) / 32;
+    const int grid = (int)(tiles < 2048 ? tiles : 2048);
+#define TPNET_PF(LPP_, VPL_, FULL_)                                                                                          \
+    hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now, lambda, flags, \
+                       (const __bf16*)w1, b1, (const __bf16*)w2p, b2, out_gram, out)
+    if (gm.lpp == 16 && gm.vpl == 1) { if (full) TPNET_PF(16, 1, true); else TPNET_PF(16, 1, false); }
+    else if (gm.lpp == 16) { if (full) TPNET_PF(16, 2, true); else TPNET_PF(16, 2, false); }
+    else if (gm.lpp == 32 && gm.vpl == 1) { if (full) TPNET_PF(32, 1, true); else TPNET_PF(32, 1, false); }
+    else if (gm.lpp == 32) { if (full) TPNET_PF(32, 2, true); else TPNET_PF(32, 2, false); }
+    else if (gm.vpl == 1) { if (full) TPNET_PF(64, 1, true); else TPNET_PF(64, 1, false); }
+    else { if (full) TPNET_PF(64, 2, true); else TPNET_PF(64, 2, false); }
+#undef TPNET_PF
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+}  // namespace tpnet
+
+using namespace tpnet;
+
+extern "C" int tpnet_pair_feature_bf16(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
+                                       double lambda, uint32_t flags, const void* w1_bf16, const float* b1,
+                                       const void* w2p_bf16, const float* b2, float* out_gram, float* out, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1) return TPNET_ERR_BAD_ARG;
+    if (n < 0 || (n > 0 && (!u || !v || !out || !w1_bf16 || !b1 || !w2p_bf16 || !b2))) return TPNET_ERR_BAD_ARG;
+    return launch_pair_feature_bf16(*st, u, v, n, now_time, lambda, flags, w1_bf16, b1, w2p_bf16, b2, out_gram, out,
+                                    (hipStream_t)stream);
+}

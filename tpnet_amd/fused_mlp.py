@@ -79,3 +79,55 @@ class _FusedMLP(torch.autograd.Function):
 
 def fused_mlp(mlp: torch.nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     return _FusedMLP.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, _prepared(mlp))
+
+
+# ---- readout + mlp in one kernel (tpnet_pair_feature_bf16): the features are formed into an LDS tile and consumed there ----
+class _FusedReadoutMLP(torch.autograd.Function):
+    """forward(w1, b1, w2, b2, launch, n): `launch(out_gram)` enqueues tpnet_pair_feature_bf16 and returns the features;
+    backward as _FusedMLP (fp32 recompute of the hidden layer from the saved pre-mlp features)."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, b2, launch, n):
+        gram = torch.empty((n, F), dtype=torch.float32, device=w1.device)
+        y = launch(gram)
+        ctx.save_for_backward(gram, w1, b1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        pre = torch.addmm(b1, x, w1.t())
+        hid = torch.relu(pre)
+        gw2 = gy.t() @ hid
+        gb2 = gy.sum(0)
+        gh = (gy @ w2) * (pre > 0)
+        gw1 = gh.t() @ x
+        gb1 = gh.sum(0)
+        return gw1, gb1, gw2, gb2, None, None
+
+
+def readout_supported(rp) -> bool:
+    """tpnet_pair_feature_bf16 serves L = 3 and rows of whole 16-byte vectors from 64 floats (16, 32 or 64 lanes per pair)."""
+    return rp.num_layer == 3 and rp.dim % 4 == 0 and rp.dim >= 36 and not rp.use_matrix and supported(rp.mlp)
+
+
+def fused_readout_mlp(rp, u_dev: torch.Tensor, v_dev: torch.Tensor) -> torch.Tensor:
+    """get_pair_wise_feature(u, v) (models/TPNet.py:112-129) for device-resident ids with self.mlp on the bf16 matrix cores
+    inside the readout kernel."""
+    mlp = rp.mlp
+    w1b, b1c, w2p, b2c = _prepared(mlp)
+    n = int(u_dev.numel())
+    lib = _lib.load()
+    flags = _lib.FLAG_NOT_SCALE if rp.not_scale else 0
+
+    def launch(gram):
+        y = torch.empty((n, F), dtype=torch.float32, device=u_dev.device)
+        _lib.check(lib.tpnet_pair_feature_bf16(rp._st_ref(), u_dev.data_ptr(), v_dev.data_ptr(), n, rp._now_host,
+                                               float(rp.time_decay_weight), flags, w1b.data_ptr(), b1c.data_ptr(),
+                                               w2p.data_ptr(), b2c.data_ptr(), gram.data_ptr() if gram is not None else None,
+                                               y.data_ptr(), rp._stream()), "pair_feature_bf16")
+        return y
+
+    if torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters()):
+        return _FusedReadoutMLP.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n)
+    return launch(None)

@@ -543,6 +543,18 @@ class RandomProjectionModule(nn.Module):
         reference, :49-62); self.mlp stays a trainable torch module.
         The encoder calls this with src_node_ids = tile(neighbours, 2) (models/TPNet.py:313-316): when the two halves
         of src_node_ids are equal, each neighbour's rows are fetched once for both of its pairs."""
+        if self.fused_mlp and self._plist()[0].device.type == "cuda":
+            # opt-in: self.mlp on the bf16 matrix cores INSIDE the readout kernel (the features never leave the chip)
+            from . import fused_mlp as fm
+            # (rows of < 256 floats on long lists: the 512-thread workgroups of the one-kernel version cost the readout its
+            # occupancy -- 80 000 pairs at d=128: 89 us against 69 us for readout kernel + mlp kernel -- tools/feature_rate.py)
+            if fm.readout_supported(self) and (self.dim >= 256 or len(src_node_ids) <= 16384):
+                if len(src_node_ids) != len(dst_node_ids):
+                    raise ValueError("src_node_ids and dst_node_ids must have the same length")
+                self._ensure_engine()
+                u, v = self._to_device(self._check_ids(src_node_ids, "src_node_ids"),
+                                       self._check_ids(dst_node_ids, "dst_node_ids"))
+                return fm.fused_readout_mlp(self, u, v)
         if isinstance(src_node_ids, torch.Tensor):
             return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
         src = np.asarray(src_node_ids)
