@@ -38,13 +38,18 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
     // L = 3 (H == FB): thread j IS hidden unit j and thread (kq, o) owns one slice of one output for the whole kernel, so
     // its 64 + 64 weights are loaded ONCE, ahead of the first readout (whose memory round trips hide the loads), and stay
     // in registers for every tile of the block: the dense layers then touch only LDS
+    // Register-resident weights (a thread's 64 + 64 weights in ONE burst of 128 independent loads) were measured and are
+    // compiled out by default: issued ahead of the first readout (TPNET_FEATURE_WREG = 1) they queue up in front of its own
+    // loads (C2, 1000 pairs: 17.6 us against 13.9 us with four bursts of 32 behind the readout); issued right behind the
+    // readout (= 2) the kernel needs ~600 live registers and spills to scratch.
 #ifndef TPNET_FEATURE_WREG
-#define TPNET_FEATURE_WREG 0      // (measured at C2, 1000 pairs: 13.9 us without, 17.6 us with -- the 128 KB of weights per
-#endif                            //  workgroup queue up in front of the readout's own loads; kept for long pair lists only)
-    constexpr bool WREG = TPNET_FEATURE_WREG && (H == FB) && (KQ * NG == FB) && (VPL == 1);
+#define TPNET_FEATURE_WREG 0
+#endif
+    constexpr bool WREG = TPNET_FEATURE_WREG != 0 && (H == FB) && (KQ * NG == FB);
+    constexpr bool WLATE = TPNET_FEATURE_WREG == 2;
     float w1r[WREG ? NG : 1], w2r[WREG ? KCH : 1];
     float b1r = 0.0f;
-    if constexpr (WREG) {
+    if constexpr (WREG && !WLATE) {
 #pragma unroll
         for (int k = 0; k < NG; ++k) w1r[k] = w1t[k * H + tid];
         const int kq = tid / NG, o = tid - kq * NG;
@@ -64,6 +69,14 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
         const int npair = (n - base < ppb) ? (int)(n - base) : ppb;
         if (out_gram) {                           // the pre-mlp features, for a backward pass (training)
             for (int i = tid; i < npair * NG; i += FB) out_gram[base * NG + i] = feat[i];
+        }
+        if constexpr (WREG && WLATE) {
+#pragma unroll
+            for (int k = 0; k < NG; ++k) w1r[k] = w1t[k * H + tid];
+            const int kq = tid / NG, o = tid - kq * NG;
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) w2r[i] = w2t[(kq * KCH + i) * NG + o];
+            b1r = M.b1[tid];
         }
         for (int p0 = 0; p0 < npair; p0 += SUB) {
             // ---- hidden = relu(W1 f + b1): thread j owns hidden unit j for the SUB pairs of this pass.  Its NG weights are
