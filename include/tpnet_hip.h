@@ -299,6 +299,16 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
 int tpnet_mlp64_bf16(const float* x, int64_t n, const void* w1_bf16, const float* b1, const void* w2p_bf16,
                      const float* b2, float* y, void* stream);
 
+/* Backward of self.mlp with respect to its weights on the bf16 matrix cores (training; the projections carry no gradient,
+ * models/TPNet.py:49-62).  x: the pre-mlp features [n][64] f32, gy: the gradient of the output [n][64] f32; w1_bf16 [256][64]
+ * = mlp[0].weight, w2t_bf16 [256][64] = mlp[2].weight transposed.  Every workgroup writes ONE partial result of
+ * tpnet_mlp64_bwd_partial_floats() floats, laid out gW1 [256][64] | gW2 [64][256] | gb1 [256] (gb2 = the column sums of gy is
+ * the caller's); the call returns the
+ * number of partials written (<= n_partial; negative = error) and the caller sums them (fixed order: deterministic). */
+int64_t tpnet_mlp64_bwd_partial_floats(void);
+int tpnet_mlp64_bwd_bf16(const float* x, const float* gy, int64_t n, const void* w1_bf16, const float* b1,
+                         const void* w2t_bf16, float* partial, int32_t n_partial, void* stream);
+
 /* get_pair_wise_feature with self.mlp on the bf16 matrix cores INSIDE the readout kernel (L = 3, d % 4 == 0 and d >= 64):
  * 8 waves form the features of 32 pairs into an LDS tile, which is the B operand of layer 1; wave w owns hidden units
  * [32w, 32w+32) of both layers, the 8 partial outputs are added in a fixed order.  The features never touch HBM (out_gram,

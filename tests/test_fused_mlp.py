@@ -54,7 +54,18 @@ def test_fused_mlp_numerics_and_gradients():
     gy = torch.randn_like(want)
     gw = torch.autograd.grad(want, list(mlp.parameters()), gy)
     gf = torch.autograd.grad(got, list(mlp.parameters()), gy)
+    # the matrix-core backward differentiates the bf16 forward it belongs to: its ReLU mask is the one of the bf16 hidden
+    # layer, which differs from the fp32 one wherever |pre| is below bf16 resolution -- so against fp32 autograd the bar is
+    # a norm-wise one (the exact lane / tile mapping is pinned by the integer test below)
     for a, b in zip(gf, gw):
+        assert float((a - b).norm()) < 5e-2 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
+    import tpnet_amd.fused_mlp as _fm
+    _fm.BACKWARD = "torch"                                        # the fp32 expressions behind the same forward: tight
+    try:
+        gt = torch.autograd.grad(fused_mlp(mlp, x), list(mlp.parameters()), gy)
+    finally:
+        _fm.BACKWARD = "mfma"
+    for a, b in zip(gt, gw):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
@@ -114,6 +125,14 @@ def test_config5_end_to_end_bf16_mlp_on_its_own_features():
     rp.check_device_errors()
 
 
+def _again(rp, u, v):
+    rp.fused_mlp = True
+    try:
+        return rp.get_pair_wise_feature(u, v)
+    finally:
+        rp.fused_mlp = False
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("d", [64, 128, 256, 512, 120, 36])
 def test_readout_with_mlp_on_the_matrix_cores_in_one_kernel(d):
@@ -157,7 +176,18 @@ def test_readout_with_mlp_on_the_matrix_cores_in_one_kernel(d):
     gy = torch.randn_like(want)
     gw = torch.autograd.grad(want, list(rp.mlp.parameters()), gy)
     gf = torch.autograd.grad(got, list(rp.mlp.parameters()), gy)
+    # the matrix-core backward differentiates the bf16 forward it belongs to: its ReLU mask is the one of the bf16 hidden
+    # layer, which differs from the fp32 one wherever |pre| is below bf16 resolution -- so against fp32 autograd the bar is
+    # a norm-wise one (the exact lane / tile mapping is pinned by the integer test below)
     for a, b in zip(gf, gw):
+        assert float((a - b).norm()) < 5e-2 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
+    import tpnet_amd.fused_mlp as _fm
+    _fm.BACKWARD = "torch"                                        # the fp32 expressions behind the same forward: tight
+    try:
+        gt = torch.autograd.grad(_again(rp, u, v), list(rp.mlp.parameters()), gy)
+    finally:
+        _fm.BACKWARD = "mfma"
+    for a, b in zip(gt, gw):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-3)
     rp.check_device_errors()
 
@@ -195,3 +225,32 @@ def test_readout_with_mlp_in_one_kernel_is_exact_on_integers(d):
             rp.fused_mlp = True
             got = rp.get_pair_wise_feature(u, v)
         assert torch.equal(got, want), f"n={n}: max |delta| {(got - want).abs().max().item()}"
+
+
+@pytest.mark.gpu
+def test_mlp_backward_on_the_matrix_cores_is_exact_on_integers():
+    """tpnet_mlp64_bwd_bf16 on small-integer data (every product and sum exact in bf16 x bf16 -> fp32): the four weight
+    gradients must equal autograd's through the fp32 torch layers BIT FOR BIT, for pair counts around the 32-pair tile and
+    beyond one pass of the grid; run-to-run identical."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import fused_mlp as fm
+    g = torch.Generator().manual_seed(3)
+    mlp = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64)).cuda()
+    with torch.no_grad():
+        mlp[0].weight.copy_(torch.randint(-1, 2, (256, 64), generator=g).float())
+        mlp[0].bias.copy_(torch.randint(-8, 9, (256,), generator=g).float())
+        mlp[2].weight.copy_(torch.randint(-2, 3, (64, 256), generator=g).float())
+        mlp[2].bias.copy_(torch.randint(-8, 9, (64,), generator=g).float())
+    prep = fm._prepared(mlp)
+    for n in (1, 31, 32, 33, 1000, 9000):
+        x = torch.randint(0, 3, (n, 64), generator=g).float().cuda()
+        x[:, 8:] *= (torch.rand(n, 56, generator=g) < 0.2).float().cuda()        # sparse: |pre| stays far below 256
+        gy = torch.randint(-1, 2, (n, 64), generator=g).float().cuda()
+        gy *= (torch.rand(n, 64, generator=g) < 0.3).float().cuda()              # |gH| = |sum_o gy W2| <= 64 * 2 * 0.3 ...
+        want = torch.autograd.grad(mlp(x), list(mlp.parameters()), gy)
+        got = fm.weight_grads(x, gy, mlp[0].weight, mlp[0].bias, mlp[2].weight, prep)
+        again = fm.weight_grads(x, gy, mlp[0].weight, mlp[0].bias, mlp[2].weight, prep)
+        for a, b, c, name in zip(got, want, again, ("gW1", "gb1", "gW2", "gb2")):
+            assert torch.equal(a, c), name
+            assert torch.equal(a, b), f"{name}, n={n}: max |delta| {(a - b).abs().max().item()}"

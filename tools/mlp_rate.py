@@ -19,3 +19,11 @@ with torch.no_grad():
         tt = timeit(lambda: mlp(x)); tf = timeit(lambda: fused_mlp(mlp, x))
         fl = n * 2 * (64 * 256 + 256 * 64)
         print(f"n={n}: torch fp32 {tt:.1f} us, fused bf16 MFMA {tf:.1f} us ({fl / tf / 1e6:.1f} TFLOP/s incl. weight prep) -> {tt / tf:.2f}x")
+# backward (weight gradients): tpnet_mlp64_bwd_bf16 + the sum of the workgroups' partials vs the fp32 torch expressions
+import tpnet_amd.fused_mlp as fm
+prep = fm._prepared(mlp)
+for n in (2000, 20000, 200000):
+    x = torch.rand(n, 64, device="cuda") * 10; gy = torch.randn(n, 64, device="cuda")
+    fm.BACKWARD = "torch"; tt = timeit(lambda: fm.weight_grads(x, gy, mlp[0].weight, mlp[0].bias, mlp[2].weight, prep))
+    fm.BACKWARD = "mfma"; tf = timeit(lambda: fm.weight_grads(x, gy, mlp[0].weight, mlp[0].bias, mlp[2].weight, prep))
+    print(f"backward n={n}: torch fp32 {tt:.1f} us, bf16 MFMA kernel + partial sum {tf:.1f} us -> {tt / tf:.2f}x")

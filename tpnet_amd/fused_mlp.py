@@ -43,10 +43,39 @@ def _prepared(mlp):
     if cache is None or cache[0] != key:
         with torch.no_grad():
             prep = (ps[0].detach().to(torch.bfloat16).contiguous(), ps[1].detach().float().contiguous(),
-                    permute_w2(ps[2].detach()).to(torch.bfloat16).contiguous(), ps[3].detach().float().contiguous())
+                    permute_w2(ps[2].detach()).to(torch.bfloat16).contiguous(), ps[3].detach().float().contiguous(),
+                    ps[2].detach().t().to(torch.bfloat16).contiguous())          # [4] = W2^T [256][64]: the backward's operand
         cache = (key, prep)
         mlp._tpnet_prepared = cache
     return cache[1]
+
+
+BACKWARD = "mfma"       # "mfma": tpnet_mlp64_bwd_bf16 (bf16 operands, fp32 accumulation); "torch": the fp32 expressions
+
+
+def weight_grads(x, gy, w1, b1, w2, prep=None):
+    """Gradients of (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias) given the pre-mlp features x [n, 64] and the
+    gradient gy [n, 64] of the mlp's output.  The bf16 forward paths take the matrix-core kernel (one launch + a sum over the
+    workgroups' partial results, deterministic); `BACKWARD = "torch"` or CPU tensors take the fp32 expressions."""
+    if BACKWARD == "mfma" and x.is_cuda and x.shape[0] > 0 and prep is not None:
+        lib = _lib.load()
+        n = int(x.shape[0])
+        x = x.contiguous()
+        gy = gy.contiguous().float()
+        pf = int(lib.tpnet_mlp64_bwd_partial_floats())
+        nblk = min(256, (n + 31) // 32)
+        part = torch.empty((nblk, pf), dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.tpnet_mlp64_bwd_bf16(x.data_ptr(), gy.data_ptr(), n, prep[0].data_ptr(), prep[1].data_ptr(),
+                                      prep[4].data_ptr(), part.data_ptr(), nblk, stream)
+        if rc < 0:
+            _lib.check(rc, "mlp64_bwd_bf16")
+        tot = part[:rc].sum(0)
+        return tot[:H * F].view(H, F), tot[2 * H * F:2 * H * F + H], tot[H * F:2 * H * F].view(F, H), gy.sum(0)
+    pre = torch.addmm(b1, x, w1.t())                 # fp32 recompute of the hidden layer
+    hid = torch.relu(pre)
+    gh = (gy @ w2) * (pre > 0)
+    return gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0)
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -57,23 +86,18 @@ class _FusedMLP(torch.autograd.Function):
         x = x.contiguous()
         n = x.shape[0]
         y = torch.empty((n, F), dtype=torch.float32, device=x.device)
-        w1b, b1c, w2p, b2c = prep
+        w1b, b1c, w2p, b2c = prep[:4]
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(_lib.load().tpnet_mlp64_bf16(x.data_ptr(), n, w1b.data_ptr(), b1c.data_ptr(), w2p.data_ptr(),
                                                 b2c.data_ptr(), y.data_ptr(), stream), "mlp64_bf16")
         ctx.save_for_backward(x, w1, b1, w2)
+        ctx.prep = prep
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w1, b1, w2 = ctx.saved_tensors
-        pre = torch.addmm(b1, x, w1.t())                 # fp32 recompute of the hidden layer
-        hid = torch.relu(pre)
-        gw2 = gy.t() @ hid
-        gb2 = gy.sum(0)
-        gh = (gy @ w2) * (pre > 0)
-        gw1 = gh.t() @ x
-        gb1 = gh.sum(0)
+        gw1, gb1, gw2, gb2 = weight_grads(x, gy, w1, b1, w2, ctx.prep)
         return None, gw1, gb1, gw2, gb2, None
 
 
@@ -87,23 +111,18 @@ class _FusedReadoutMLP(torch.autograd.Function):
     backward as _FusedMLP (fp32 recompute of the hidden layer from the saved pre-mlp features)."""
 
     @staticmethod
-    def forward(ctx, w1, b1, w2, b2, launch, n):
+    def forward(ctx, w1, b1, w2, b2, launch, n, prep):
         gram = torch.empty((n, F), dtype=torch.float32, device=w1.device)
         y = launch(gram)
         ctx.save_for_backward(gram, w1, b1, w2)
+        ctx.prep = prep
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w1, b1, w2 = ctx.saved_tensors
-        pre = torch.addmm(b1, x, w1.t())
-        hid = torch.relu(pre)
-        gw2 = gy.t() @ hid
-        gb2 = gy.sum(0)
-        gh = (gy @ w2) * (pre > 0)
-        gw1 = gh.t() @ x
-        gb1 = gh.sum(0)
-        return gw1, gb1, gw2, gb2, None, None
+        gw1, gb1, gw2, gb2 = weight_grads(x, gy, w1, b1, w2, ctx.prep)
+        return gw1, gb1, gw2, gb2, None, None, None
 
 
 def readout_supported(rp) -> bool:
@@ -115,7 +134,8 @@ def fused_readout_mlp(rp, u_dev: torch.Tensor, v_dev: torch.Tensor) -> torch.Ten
     """get_pair_wise_feature(u, v) (models/TPNet.py:112-129) for device-resident ids with self.mlp on the bf16 matrix cores
     inside the readout kernel."""
     mlp = rp.mlp
-    w1b, b1c, w2p, b2c = _prepared(mlp)
+    prep = _prepared(mlp)
+    w1b, b1c, w2p, b2c = prep[:4]
     n = int(u_dev.numel())
     lib = _lib.load()
     flags = _lib.FLAG_NOT_SCALE if rp.not_scale else 0
@@ -129,5 +149,5 @@ def fused_readout_mlp(rp, u_dev: torch.Tensor, v_dev: torch.Tensor) -> torch.Ten
         return y
 
     if torch.is_grad_enabled() and any(p.requires_grad for p in mlp.parameters()):
-        return _FusedReadoutMLP.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n)
+        return _FusedReadoutMLP.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n, prep)
     return launch(None)
