@@ -10,6 +10,10 @@
 //   with zero rows to 32*HT (tpnet_amd/fused_decoder.py::pack_weights); b1p / w2p: f32 [32*HT], zero beyond the hidden dim.
 //   src_emb == dst_emb == NULL is the reference's not_encode mode (embeddings replaced by zeros, modules.py:106-108):
 //   their k-steps are skipped.
+// (Measured and not kept, round 2: the opposite arrangement -- a wave keeps the 2 x 26 A fragments of two hidden tiles in
+// registers for every pair tile and the 32 x 416 input tile is staged through LDS once for all waves: at 350+ registers per
+// wave a CU holds one 3-wave workgroup, whose staging and MFMA phases then run back to back: 518 us against 255 us at
+// n = 200 000.)
 #include "tpnet_common.h"
 
 namespace tpnet {
