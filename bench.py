@@ -160,6 +160,22 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if world > 1:
+        # a collective that never returns (a rank lost, a communicator that cannot form) must not hang the run: after
+        # TPNET_BENCH_WATCHDOG seconds (default 420) rank 0 reports the failure as its JSON line and every rank exits
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "temporal edges/sec (proj-update + pairwise readout)", "value": None,
+                                  "unit": "edges/s", "n_gpus": world, "error": "multi-GPU run did not finish in time "
+                                  "(watchdog); set TPNET_ROWS_C_LOOP=0 to route the exchange through torch.distributed"}),
+                      flush=True)
+            os._exit(3)
+        _wd = threading.Timer(float(os.environ.get("TPNET_BENCH_WATCHDOG", "420")), _give_up)
+        _wd.daemon = True
+        _wd.start()
+
     import tpnet_amd
     from tpnet_amd import _lib
     from tpnet_amd.stream import CONFIGS, bytes_per_edge
