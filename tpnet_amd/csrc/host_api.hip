@@ -4,6 +4,9 @@
 // checked and copied into a slot of a pinned, device-mapped ring on the host, and the kernels read the slot directly: the
 // per-batch call is host-bound (a batch is microseconds of GPU work), so what counts is the number of runtime calls per
 // API call -- one kernel launch + one event record for a readout, two launches + one event record for an update.
+// (Measured and not kept: the update's plan kernel on a helper stream beside the batch's two readouts -- the GPU side would
+// allow it, but two cross-stream event waits and two more event records cost the call 11 us of host time, and the per-batch
+// loop is host-bound: C2 59-69 us per batch against 60.)
 #include "tpnet_common.h"
 
 #include <cstring>
