@@ -154,7 +154,8 @@ int tpnet_pair_feature(const tpnet_state* st, const int64_t* u, const int64_t* v
  * (TPNET_ERR_INDEX for an id outside [-N, N); negative ids wrap like ATen indexing), copy them into a slot of a pinned,
  * device-mapped staging ring and launch kernels that read the slot directly -- no separate host->device copy is enqueued,
  * and a call costs one FFI crossing.  A tpnet_stage is the ONLY object this library allocates (pinned host memory + one
- * event per slot); a slot is reused only after the launch that read it has finished (the call waits if the ring wrapped). */
+ * event per slot); a slot is reused only after the launch that read it has finished (the call waits if the ring wrapped).
+ * A stage serves ONE calling thread and one device (the reference's loop is single-threaded under the GIL). */
 typedef struct tpnet_stage tpnet_stage;
 int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out);
 int tpnet_stage_destroy(tpnet_stage* stage);
