@@ -610,6 +610,7 @@ static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int
     tot += align_up(3 * (size_t)Ec * 4, 256) * 2;               // e_ref, e_g
     tot += align_up(nc * (size_t)L * (size_t)d * 4, 256);       // version log
     tot += align_up((size_t)N * 4, 256) * 2;                    // node_lo, node_hi
+    tot += align_up(nc * 4, 256) * 2;                           // inv, rhead
     return tot + 256;
 }
 
@@ -649,6 +650,8 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
     out->log = (float*)take(nc * (size_t)L * (size_t)d * 4);
     out->node_lo = (uint32_t*)take((size_t)N * 4);
     out->node_hi = (uint32_t*)take((size_t)N * 4);
+    out->inv = (uint32_t*)take(nc * 4);
+    out->rhead = (uint32_t*)take(nc * 4);
     out->chains = reinterpret_cast<Chain*>(out->base.light);
     out->chains_sparse = reinterpret_cast<Chain*>(out->base.heavy);
     // the second sort's keys live where the first sort's unsorted keys were (8 bytes per contribution, dead by then), its
@@ -730,6 +733,65 @@ __device__ __forceinline__ void resolve_version(const K* __restrict__ keys, int6
     g = decay_f32(lambda, t_to - m.tref[c]);
 }
 
+// One pass over the sorted keys: [node_lo[n], node_hi[n]) = the sorted positions of node n's contributions in the chunk (both
+// 0 for a node without any: the arrays are zeroed first); inv[v] = the sorted position of the contribution whose pre-sort
+// index is v; rhead[j] = the first position of j's (node, batch) run.  With these, "the version of node p before batch b"
+// needs NO search whenever p is itself a target in batch b -- which every partner of a contribution and both endpoints of
+// an edge are (an edge contributes to both of its endpoints): it is the run that precedes p's run of batch b.
+template <typename K>
+__global__ void k_node_ranges(const K* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t nc, int batch_bits,
+                              uint32_t* __restrict__ node_lo, uint32_t* __restrict__ node_hi, uint32_t* __restrict__ inv,
+                              uint32_t* __restrict__ rhead) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
+        const K key = keys[j];
+        const K node = key >> batch_bits;
+        if (j == 0 || (keys[j - 1] >> batch_bits) != node) node_lo[node] = (uint32_t)j;
+        if (j == nc - 1 || (keys[j + 1] >> batch_bits) != node) node_hi[node] = (uint32_t)(j + 1);
+        inv[vals[j]] = (uint32_t)j;
+        // head of the run (backward gallop + binary search)
+        int64_t h = j;
+        if (j > 0 && keys[j - 1] == key) {
+            int64_t hi = j, step = 1, lo;            // keys[hi] == key; find lo with keys[lo] != key (or -1)
+            for (;;) {
+                lo = hi - step;
+                if (lo < 0) { lo = -1; break; }
+                if (keys[lo] != key) break;
+                hi = lo;
+                step <<= 1;
+            }
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (keys[mid] == key) hi = mid; else lo = mid;
+            }
+            h = hi;
+        }
+        rhead[j] = (uint32_t)h;
+    }
+}
+
+// version of `node` before batch b when the node is a target IN batch b and `pos` is one of its contributions of that batch:
+// the run before the one `pos` is in, or the table.  false = `pos` is not such a position (bad ids): take the search.
+template <typename K>
+__device__ __forceinline__ bool version_before_own_run(const WPlan& p, const K* __restrict__ keys, int batch_bits, int64_t node,
+                                                       int64_t b, uint32_t pos, const BatchDesc* __restrict__ desc,
+                                                       const NodeMeta* __restrict__ meta, double lambda, double t_to,
+                                                       uint32_t& ref, float& g) {
+    const K bmask = ((K)1 << batch_bits) - 1;
+    const K want = (K)(((uint64_t)node << batch_bits) | (uint64_t)b);
+    if (keys[pos] != want) return false;
+    const uint32_t h = p.rhead[pos];
+    if (h > p.node_lo[node]) {                                 // an earlier run of the same node: its tail is its log slot
+        ref = h - 1;
+        g = decay_f32(lambda, t_to - desc[(int64_t)(keys[h - 1] & bmask)].t_last);
+    } else {
+        const NodeMeta m = meta[node];
+        const uint32_t c = m.ver & 1u;
+        ref = WREF_TABLE | c;
+        g = decay_f32(lambda, t_to - m.tref[c]);
+    }
+    return true;
+}
+
 template <typename K>
 __device__ __forceinline__ void finish_w(uint32_t bx, uint32_t nbx, WPlan p, const K* __restrict__ keys, const int64_t* __restrict__ src,
                            const int64_t* __restrict__ dst, const double* __restrict__ t, int64_t Ec, int64_t B, int64_t N,
@@ -771,27 +833,21 @@ __device__ __forceinline__ void finish_w(uint32_t bx, uint32_t nbx, WPlan p, con
             const bool same_node_next = has_next && (kn >> batch_bits) == (key >> batch_bits);
             chain_head = !same_node_prev || (int64_t)(kp & bmask) / KW != w;
             last_run = run_tail && !same_node_next;
-            // position inside the run (backward gallop + binary search to the run's head)
-            int64_t h = j;
-            if (!run_head) {
-                int64_t hi = j, step = 1, lo;            // keys[hi] == key; find lo with keys[lo] != key (or -1)
-                for (;;) {
-                    lo = hi - step;
-                    if (lo < 0) { lo = -1; break; }
-                    if (keys[lo] != key) break;
-                    hi = lo;
-                    step <<= 1;
-                }
-                while (hi - lo > 1) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (keys[mid] == key) hi = mid; else lo = mid;
-                }
-                h = hi;
-            }
+            const int64_t h = p.rhead[j];                // head of the run (k_node_ranges)
             const int64_t ri = j - h;
             uint32_t ref;
             float g;
-            resolve_version(keys, nc, batch_bits, (int64_t)partner, b, desc, meta, lambda, Tb, ref, g, p.node_lo, p.node_hi);
+            {
+                // the partner is a target in this batch too (the other side of the same edge): its contribution's position
+                int64_t cb, ce;
+                int cside;
+                decode((int64_t)val, B, Ec, cb, cside, ce);
+                const int64_t e0b = cb * B;
+                const int64_t neb = (Ec - e0b < B) ? (Ec - e0b) : B;
+                const uint32_t sym = (uint32_t)(2 * e0b + (cside ? 0 : neb) + (ce - e0b));
+                if (!version_before_own_run<K>(p, keys, batch_bits, (int64_t)partner, b, p.inv[sym], desc, meta, lambda, Tb, ref, g))
+                    resolve_version(keys, nc, batch_bits, (int64_t)partner, b, desc, meta, lambda, Tb, ref, g, p.node_lo, p.node_hi);
+            }
             uint32_t fl = 0;
             if (run_head) fl |= WREF_RUN_HEAD;
             if (run_tail) fl |= WREF_RUN_TAIL;
@@ -896,21 +952,18 @@ __device__ __forceinline__ void edge_refs(uint32_t bx, uint32_t nbx, WPlan p, co
         const int64_t b = e / B;
         uint32_t ref;
         float g;
-        resolve_version(keys, nc, batch_bits, node, b, p.base.desc, meta, lambda, p.base.desc[b].now, ref, g, p.node_lo, p.node_hi);
+        bool done = false;
+        if (which < 2) {                                           // src / dst of the edge are targets in its batch
+            const int64_t e0b = b * B;
+            const int64_t neb = (Ec - e0b < B) ? (Ec - e0b) : B;
+            const uint32_t orig = (uint32_t)(2 * e0b + (which ? neb : 0) + (e - e0b));
+            done = version_before_own_run<K>(p, keys, batch_bits, node, b, p.inv[orig], p.base.desc, meta, lambda,
+                                             p.base.desc[b].now, ref, g);
+        }
+        if (!done)
+            resolve_version(keys, nc, batch_bits, node, b, p.base.desc, meta, lambda, p.base.desc[b].now, ref, g, p.node_lo, p.node_hi);
         p.e_ref[x] = ref;
         p.e_g[x] = g;
-    }
-}
-
-// [node_lo[n], node_hi[n]) = the sorted positions of node n's contributions in the chunk (both 0 for a node without any:
-// the arrays are zeroed first)
-template <typename K>
-__global__ void k_node_ranges(const K* __restrict__ keys, int64_t nc, int batch_bits, uint32_t* __restrict__ node_lo,
-                              uint32_t* __restrict__ node_hi) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += (int64_t)gridDim.x * blockDim.x) {
-        const K node = keys[j] >> batch_bits;
-        if (j == 0 || (keys[j - 1] >> batch_bits) != node) node_lo[node] = (uint32_t)j;
-        if (j == nc - 1 || (keys[j + 1] >> batch_bits) != node) node_hi[node] = (uint32_t)(j + 1);
     }
 }
 
@@ -970,10 +1023,11 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
     TPNET_HIP_TRY(hipMemsetAsync(p.node_lo, 0, (size_t)st.N * 4, s));
     TPNET_HIP_TRY(hipMemsetAsync(p.node_hi, 0, (size_t)st.N * 4, s));
     if (narrow)
-        hipLaunchKernelGGL(k_node_ranges<uint32_t>, dim3(grid), dim3(256), 0, s, k32_out, nc, batch_bits, p.node_lo, p.node_hi);
+        hipLaunchKernelGGL(k_node_ranges<uint32_t>, dim3(grid), dim3(256), 0, s, k32_out, p.base.vals_out, nc, batch_bits, p.node_lo,
+                           p.node_hi, p.inv, p.rhead);
     else
-        hipLaunchKernelGGL(k_node_ranges<uint64_t>, dim3(grid), dim3(256), 0, s, p.base.keys_out, nc, batch_bits, p.node_lo,
-                           p.node_hi);
+        hipLaunchKernelGGL(k_node_ranges<uint64_t>, dim3(grid), dim3(256), 0, s, p.base.keys_out, p.base.vals_out, nc, batch_bits,
+                           p.node_lo, p.node_hi, p.inv, p.rhead);
     if (narrow)
         hipLaunchKernelGGL(k_plan_w<uint32_t>, dim3(grid + (want_readout ? egrid : 0)), dim3(256), 0, s, p, k32_out, src, dst,
                            neg, t, Ec, batch, st.N, batch_bits, lambda, p.lk_in, p.lv_in, lk_none, meta, st.err, (uint32_t)grid);

@@ -229,6 +229,8 @@ struct WPlan {
     float* log;           // [2*Ec][L][d] version log of the chunk (only the slots of run tails are ever touched)
     uint32_t* node_lo;    // [N] first / one-past-last sorted position of every node's contributions in the chunk (0, 0: none)
     uint32_t* node_hi;
+    uint32_t* inv;        // [2*Ec] pre-sort index of a contribution -> its sorted position
+    uint32_t* rhead;      // [2*Ec] sorted position -> first position of its (node, batch) run
     int32_t K;            // batches per window
     int64_t Ew;           // edges per full window = K * batch
 };
