@@ -158,3 +158,32 @@ def test_layer_list_is_lazy_about_layers_1_to_L():
     rp2.random_projections[3]
     assert rp._params_exposed is False                       # the copy's list belongs to the copy
     assert sorted(rp2.state_dict().keys()) == sorted(rp.state_dict().keys())
+
+
+def test_encoder_pattern_detection_host_logic():
+    """`_anchor_runs`: np.repeat(anchors, K) is recognised with any K whose blocks are constant (runs of equal anchors merge
+    whole blocks only), anything else is refused."""
+    from tpnet_amd import RandomProjectionModule as R
+    a = np.array([5, 9, 9, 2, 7], dtype=np.int64)
+    anchors, K = R._anchor_runs(np.repeat(a, 20))
+    assert K == 20 and np.array_equal(anchors, a)
+    anchors, K = R._anchor_runs(np.repeat(np.array([3, 3, 3], dtype=np.int64), 4))      # one long run: K = the whole length
+    assert K == 12 and np.array_equal(np.repeat(anchors, K), np.repeat(3, 12))
+    bad = np.repeat(a, 20).copy(); bad[21] = 4
+    r = R._anchor_runs(bad)
+    assert r is None or r[1] < 4                                                         # blocks of 1: not the encoder's call
+    assert R._anchor_runs(np.arange(10, dtype=np.int64)) is None
+    assert R._anchor_runs(np.array([1], dtype=np.int64)) is None
+
+
+def test_fused_feature_applies_only_to_the_reference_mlp():
+    """The one-launch readout + mlp serves exactly Linear(F, 4F) -> ReLU -> Linear(4F, F) with biases, fp32, on a GPU; anything
+    else (the goldens' Identity, a wider layer, a CPU module) keeps the torch layers."""
+    from tpnet_amd import fused_feature as ff
+    mk = lambda a, b, c: torch.nn.Sequential(torch.nn.Linear(a, b), torch.nn.ReLU(), torch.nn.Linear(b, c))
+    assert not ff.supported(mk(64, 256, 64), 64)                      # CPU weights
+    assert not ff.supported(torch.nn.Identity(), 64)
+    assert not ff.supported(mk(64, 128, 64), 64)
+    assert ff.prepared(torch.nn.Identity(), 64) is None
+    assert ff.prepared(mk(64, 256, 64), 64) is None                   # (CPU: not supported, no cache entry)
+    assert ff.needs_grad(list(mk(4, 16, 4).parameters())) and not ff.needs_grad([torch.zeros(1)])
