@@ -170,7 +170,9 @@ int tpnet_host_pair_feature(const tpnet_state* st, tpnet_stage* stage, const int
                             float* out, void* stream);
 
 /* update (models/TPNet.py:67-99) from host arrays, B <= tpnet_stage_max_batch: ONE plan kernel (a single workgroup sorts
- * the batch's 2B contributions in LDS and writes the item lists) + the step kernel.  workspace: tpnet_workspace_bytes(B, B). */
+ * the batch's 2B contributions in LDS and writes the item lists) + the step kernel.  workspace: tpnet_workspace_bytes(B, B).
+ * Larger batches (up to slot_bytes / 24 edges): the staged arrays are copied to the tail of the workspace (which must then hold
+ * tpnet_workspace_bytes(B, B) rounded up to 256 + 24 B bytes) and tpnet_update plans and steps from there. */
 int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst,
                       const double* h_t, int64_t B, double now_time, double lambda, uint32_t launch_id, uint32_t flags,
                       void* workspace, size_t ws_bytes, void* stream);

@@ -148,9 +148,28 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
     if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
         return TPNET_ERR_BAD_ARG;
     if (B < 1 || !h_src || !h_dst || !h_t || !stage) return TPNET_ERR_BAD_ARG;
-    if (B > tpnet_stage_max_batch(stage)) return TPNET_ERR_BAD_ARG;
     if (launch_id == 0 || launch_id >= 0x7FFFFFFFu) return TPNET_ERR_BAD_ARG;
     if (flags & TPNET_FLAG_EAGER_DECAY) return TPNET_ERR_BAD_ARG;     // (the exact mode's dense decay is tpnet_decay, before this call)
+    if (B > tpnet_stage_max_batch(stage)) {
+        // a batch too large for the single-workgroup plan: the staged arrays are copied to the tail of the workspace (the
+        // chunk planner gathers from them at random: not something to do over PCIe) and the per-batch path plans + steps
+        if ((size_t)B * 24 > stage->slot_bytes) return TPNET_ERR_BAD_ARG;
+        const size_t pb = (plan_bytes(B, B) + 255) / 256 * 256;
+        if (!workspace || pb + (size_t)B * 24 > ws_bytes) return TPNET_ERR_WORKSPACE;
+        char *host = nullptr, *dev = nullptr;
+        int rc = stage_acquire(stage, (size_t)B * 24, &host, &dev);
+        if (rc) return rc;
+        int64_t* hs = reinterpret_cast<int64_t*>(host);
+        if (!copy_ids(hs, h_src, B, st->N) || !copy_ids(hs + B, h_dst, B, st->N)) return TPNET_ERR_INDEX;
+        memcpy(hs + 2 * B, h_t, (size_t)B * 8);
+        hipStream_t s = (hipStream_t)stream;
+        int64_t* d = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(workspace) + pb);
+        TPNET_HIP_TRY(hipMemcpyAsync(d, host, (size_t)B * 24, hipMemcpyHostToDevice, s));
+        rc = stage_release(stage, s);
+        if (rc) return rc;
+        return tpnet_update(st, d, d + B, reinterpret_cast<const double*>(d + 2 * B), B, now_time, lambda, launch_id, flags,
+                            workspace, pb, stream);
+    }
     Plan p{};
     int rc = plan_carve(workspace, ws_bytes, B, B, &p);
     if (rc) return rc;

@@ -6,6 +6,7 @@ being recorded, the kernel also writes the pre-mlp features and the backward pas
 layers' gradients (the projections carry no gradient: requires_grad=False in the reference, models/TPNet.py:49-62).
 Differs from the torch layers in f32 summation order only, so it is the DEFAULT for the decoder's short pair lists."""
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -13,7 +14,8 @@ import torch
 from . import _lib
 
 _PREPARED = weakref.WeakKeyDictionary()     # mlp module -> cache entry (kept off the module: ctypes objects do not deepcopy)
-MAX_PAIRS = 8192      # longer lists: the readout kernels + the dense layers as GEMMs (torch, or the bf16 kernel if opted in)
+# longer lists: the readout kernels + the dense layers as GEMMs (torch, or the bf16 kernel if opted in)
+MAX_PAIRS = int(os.environ.get("TPNET_DEV_FUSED_MAX_PAIRS", "8192"))
 
 
 def supported(mlp: torch.nn.Module, F: int) -> bool:

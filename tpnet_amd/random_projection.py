@@ -72,7 +72,8 @@ class _Stage:
             _lib.check(lib.tpnet_stage_create(slots, slot_bytes, C.byref(h)), "stage_create")
         self.handle = h
         self.max_pairs = int(lib.tpnet_stage_max_pairs(h))
-        self.max_batch = int(lib.tpnet_stage_max_batch(h))
+        self.max_batch = int(lib.tpnet_stage_max_batch(h))      # batches planned by one workgroup, read straight from the slot
+        self.max_host_batch = slot_bytes // 24                  # larger ones: staged, copied to the workspace, chunk planner
 
     def __del__(self):
         try:
@@ -261,20 +262,21 @@ class RandomProjectionModule(nn.Module):
         return _lib.State(p0=p0.data_ptr(), q=eng["q"].data_ptr(), meta=eng["meta"].data_ptr(), N=self.node_num,
                           d=self.dim, L=self.num_layer, err=eng["err"].data_ptr())
 
-    def _workspace(self, max_edges: int, batch: int, stream: bool = False):
+    def _workspace(self, max_edges: int, batch: int, stream: bool = False, tail: int = 0):
         """Plan workspace.  `stream`: sized for tpnet_run_stream (the windowed schedule's plan + version log where it applies),
         capped at one chunk of the stream -- the C side walks longer streams chunk by chunk."""
         eng = self._engine()
         cache = self.__dict__.setdefault("_ws_need", {})
-        need = cache.get((max_edges, batch, stream))
+        need = cache.get((max_edges, batch, stream, tail))
         if need is None:
             if stream:
                 need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer, max_edges, batch)
             else:
                 need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
+            need = (need + 255) // 256 * 256 + tail
             if len(cache) > 64:
                 cache.clear()
-            cache[(max_edges, batch, stream)] = need
+            cache[(max_edges, batch, stream, tail)] = need
         if eng["ws"] is None or eng["ws"].numel() < need:
             eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
         return eng["ws"]
@@ -439,7 +441,8 @@ class RandomProjectionModule(nn.Module):
         lam = float(self.time_decay_weight)
         flags = 0
         src_h, dst_h = self._host_ids(src_node_ids, "src_node_ids"), self._host_ids(dst_node_ids, "dst_node_ids")
-        host = src_h is not None and dst_h is not None and B <= self._eng["stage"].max_batch
+        stage = self._eng["stage"]
+        host = src_h is not None and dst_h is not None and B <= stage.max_host_batch
         if host and self.exact:
             # range check BEFORE anything is enqueued (the exact mode's decay below is a state change; otherwise the C call
             # checks the ids on the host before it launches anything)
@@ -455,7 +458,7 @@ class RandomProjectionModule(nn.Module):
             fac = (C.c_float * self.num_layer)(*[np.float32(np.power(g, i)) for i in range(1, self.num_layer + 1)])
             _lib.check(lib.tpnet_decay(self._st_ref(), fac, next_time, self._stream()), "decay")
             flags |= _lib.FLAG_SEQUENTIAL
-        ws = self._workspace(B, B)
+        ws = self._workspace(B, B, tail=24 * B + 512 if (host and B > stage.max_batch) else 0)
         lid = self._next_launch_ids(1)
         if host:
             # host arrays (what the reference's loop passes, train_link_prediction.py:372): one FFI call = staging + one
