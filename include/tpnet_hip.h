@@ -140,14 +140,25 @@ typedef struct tpnet_mlp {
     const float* b2;  /* [F] */
     int32_t F;        /* (2L+2)^2 */
     int32_t H;        /* 4 F */
+    /* optional (NULL: never the matrix-core kernel), L = 3 only: the layouts the fp32 matrix-core kernel reads --
+     * w1 = mlp[0].weight as is ([256][64]); w2f[((w * 2 + t) * 64 + lane) * 16 + s] = mlp[2].weight[32 t + (lane & 31)]
+     * [32 w + (s & 3) + 8 (s >> 2) + 4 (lane >> 5)]  (w = 0..7 hidden tile, t = 0..1 output tile, s = 0..15 k-step) */
+    const float* w1;
+    const float* w2f;
 } tpnet_mlp;
 
 /* get_pair_wise_feature INCLUDING self.mlp (models/TPNet.py:112-129) in one launch: the features of tpnet_pair_gram stay
- * in LDS and go through both dense layers in fp32 (vector ALUs; differs from the torch layers in summation order only).
+ * in LDS and go through both dense layers in fp32 (differs from the torch layers in summation order only): on the fp32
+ * matrix cores (v_mfma_f32_32x32x2_f32; L = 3, rows of >= 36 floats in 16-byte vectors, mlp->w1 / w2f given) for lists of any
+ * length, else on the vector ALUs (any L; meant for short lists).
  * out: device float[n][F]; out_gram (optional, may be NULL): the pre-mlp features [n][F], what a backward pass needs.
  * Meant for the decoder's short pair lists (models/modules.py:112: n = batch size); any L in 1..4. */
 int tpnet_pair_feature(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
                        double lambda, uint32_t flags, const tpnet_mlp* mlp, float* out_gram, float* out, void* stream);
+
+/* self.mlp alone on the fp32 matrix cores (L = 3: 64 -> 256 -> 64; mlp->w1 / w2f required): y[n][64] = mlp(x[n][64]), for
+ * features that a separate readout produced (the anchored / shared-first-node kernels of the encoder's call). */
+int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, float* y, void* stream);
 
 /* ---- host-array entry points: what the reference's per-batch calls hand over are HOST numpy arrays (models/TPNet.py:
  * 74-77, 107, 117; train_link_prediction.py:359-373).  These variants take host pointers, check the ids on the host

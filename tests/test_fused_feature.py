@@ -242,3 +242,54 @@ def test_encoder_pattern_takes_the_anchored_kernel_and_matches():
         got2 = rp.get_pair_wise_feature(u, v2)
         want2 = rp.mlp(rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v2).cuda()))
     np.testing.assert_allclose(got2.cpu().numpy(), want2.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [64, 128, 256, 512, 120, 36])
+def test_feature_on_the_fp32_matrix_cores(d):
+    """From 2 048 pairs get_pair_wise_feature is ONE launch with self.mlp on the fp32 matrix cores (v_mfma_f32_32x32x2_f32:
+    fp32 products and sums, so it stays in the fp32 parity class): against the readout + torch layers on host ids (staged),
+    on a list longer than the staging slot (device copy of the ids), exact on integer data, gradients, and the dense layers
+    alone (tpnet_mlp64_f32) behind a separate readout."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import fused_feature as ff
+    rng = np.random.RandomState(d + 1)
+    N = 300
+    rp = _module(N, d, 3)
+    for src, dst, t in _stream(rng, N, 150, 3):
+        rp.update(src, dst, t)
+    for n in (2048, 3001, 16384, 20011):
+        u, v = rng.randint(0, N, n).astype(np.int64), rng.randint(0, N, n).astype(np.int64)
+        with torch.no_grad():
+            gram = rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda())
+            want = rp.mlp(gram)
+            got = rp.get_pair_wise_feature(u, v)
+            alone = ff.mlp_f32(rp.mlp, gram)
+        assert got.shape == want.shape and alone is not None
+        for x in (got, alone):
+            err = (x - want).abs().max().item()
+            assert err <= 2e-5 * max(1.0, want.abs().max().item()), (n, err)
+    # gradients through the one-launch forward (the kernel also writes the pre-mlp features)
+    u, v = rng.randint(0, N, 2500).astype(np.int64), rng.randint(0, N, 2500).astype(np.int64)
+    got = rp.get_pair_wise_feature(u, v)
+    want = rp.mlp(rp.pair_gram(u, v))
+    gy = torch.randn_like(want)
+    for a, b in zip(torch.autograd.grad(got, list(rp.mlp.parameters()), gy), torch.autograd.grad(want, list(rp.mlp.parameters()), gy)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # integer data: fp32 products and sums are exact whatever their order
+    rq = _module(N, d, 3, not_scale=True)
+    g = torch.Generator().manual_seed(d)
+    P0 = torch.zeros(N, d)
+    for i in range(N):
+        idx = torch.randperm(d, generator=g)[:4]
+        P0[i, idx] = torch.randint(0, 2, (4,), generator=g).float() * 2 - 1
+    rq.random_projections[0].data.copy_(P0.cuda())
+    with torch.no_grad():
+        rq.mlp[0].weight.copy_(torch.randint(-3, 4, (256, 64), generator=g).float())
+        rq.mlp[0].bias.copy_(torch.randint(-8, 9, (256,), generator=g).float())
+        rq.mlp[2].weight.copy_(torch.randint(-2, 3, (64, 256), generator=g).float())
+        rq.mlp[2].bias.copy_(torch.randint(-8, 9, (64,), generator=g).float())
+        u, v = rng.randint(0, N, 4099).astype(np.int64), rng.randint(0, N, 4099).astype(np.int64)
+        assert torch.equal(rq.get_pair_wise_feature(u, v), rq.mlp(rq.pair_gram(u, v)))
+    rp.check_device_errors()

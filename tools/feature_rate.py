@@ -37,10 +37,11 @@ for cfg, ns in (("C2", (1000, 80000)), ("C3", (10000, 800000)), ("C5", (10000, 2
             t_gram = timeit(lambda: rp.pair_gram(u, v))
             line = (f"{cfg} d={c['d']} n={n}: readout alone {t_gram:.1f} us; + torch fp32 mlp {t_torch:.1f}; + bf16 mlp kernel {t_two:.1f}; "
                     f"ONE kernel, mlp on the matrix cores {t_one:.1f}")
-            if n <= ff.MAX_PAIRS:
-                prep = ff.prepared(rp.mlp, 64)
-                out = torch.empty((n, 64), device=dev)
-                t_f32 = timeit(lambda: lib.tpnet_pair_feature(rp._st_ref(), u.data_ptr(), v.data_ptr(), n, rp._now_host, float(c["lam"]),
-                                                              0, prep[2], None, out.data_ptr(), rp._stream()))
-                line += f"; ONE kernel fp32 {t_f32:.1f}"
+            prep = ff.prepared(rp.mlp, 64)
+            out = torch.empty((n, 64), device=dev)
+            t_f32 = timeit(lambda: lib.tpnet_pair_feature(rp._st_ref(), u.data_ptr(), v.data_ptr(), n, rp._now_host, float(c["lam"]),
+                                                          0, prep[2], None, out.data_ptr(), rp._stream()))
+            gram = rp.pair_gram(u, v)
+            t_mlp = timeit(lambda: ff.mlp_f32(rp.mlp, gram))
+            line += f"; ONE kernel fp32 ({'matrix cores' if n >= 2048 else 'vector ALUs'}) {t_f32:.1f}; dense layers alone on the fp32 matrix cores {t_mlp:.1f}"
         print(line, flush=True)

@@ -32,7 +32,7 @@ class State(C.Structure):
 class Mlp(C.Structure):
     """tpnet_mlp: device arrays of self.mlp in the fused kernel's layout (include/tpnet_hip.h)."""
     _fields_ = [("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2t", C.c_void_p), ("b2", C.c_void_p), ("F", C.c_int32),
-                ("H", C.c_int32)]
+                ("H", C.c_int32), ("w1", C.c_void_p), ("w2f", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/tpnet_hip.h declares (tests check this)
@@ -90,6 +90,7 @@ SIGNATURES = {
     "tpnet_gram_unpack": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_uint32, _P, _P]),
     "tpnet_check_errors": (C.c_int, [_SP, _P]),
     "tpnet_pair_feature": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp), _P, _P, _P]),
+    "tpnet_mlp64_f32": (C.c_int, [_P, C.c_int64, C.POINTER(Mlp), _P, _P]),
     "tpnet_stage_create": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(_P)]),
     "tpnet_stage_destroy": (C.c_int, [_P]),
     "tpnet_stage_max_pairs": (C.c_int64, [_P]),

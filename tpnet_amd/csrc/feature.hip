@@ -7,6 +7,8 @@
 // is the right trade for <= ~10^4 pairs; long lists take the readout kernels + the bf16 matrix-core mlp, mlp.hip).
 #include "readout.hpp"
 
+#include <cstdlib>
+
 namespace tpnet {
 
 static constexpr int FB = 256;        // threads per workgroup
@@ -176,6 +178,12 @@ int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* 
     const int NN = 2 * st.L + 2;
     if (m.F != NN * NN || m.H != 4 * NN * NN || !m.w1t || !m.b1 || !m.w2t || !m.b2) return TPNET_ERR_BAD_ARG;
     if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
+    // L = 3 on rows of whole 16-byte vectors: the fp32 matrix-core kernel (feature_mfma.hip) from `mfma_from` pairs on -- its
+    // weights live in registers for the whole launch, so lists of any length are one launch; below that the vector-ALU
+    // kernel's 8-pair workgroups spread a short list over more CUs
+    static const int64_t mfma_from = getenv("TPNET_DEV_FEATURE_MFMA_FROM") ? atoll(getenv("TPNET_DEV_FEATURE_MFMA_FROM")) : 2048;
+    if (m.w1 && m.w2f && n >= mfma_from && pair_feature_mfma_supported(st) && !(reinterpret_cast<uintptr_t>(out) & 15))
+        return launch_pair_feature_bf16(st, u, v, n, now, lambda, flags, m.w1, m.b1, m.w2f, m.b2, out_gram, out, s, true);
     TPNET_DISPATCH(({
         constexpr int GPB = FB / LPP;
         const int ppb = (GPB > FSUB && n <= 256 * FSUB) ? FSUB : GPB;

@@ -6,6 +6,10 @@
 // pre-permuted as in mlp.hip).  The eight partial Y tiles are added in a FIXED order through LDS (run-to-run identical
 // bits).  The features never leave the chip; the weights of a wave (its 32 rows of W1, its 32 columns of W2: 48 VGPRs)
 // are loaded once per workgroup.  bf16 operands, fp32 accumulation: 2e-2 class like tpnet_mlp64_bf16 -- opt-in.  L = 3.
+// F32 = true: the same kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation -- differs from
+// the torch layers in summation order only), which makes ONE launch the default get_pair_wise_feature for lists of any length:
+// k-step s of layer 1 takes features (s, s + 32) (lane half h reads 32 consecutive floats of its pair's LDS row and of its W1
+// row), k-step s of layer 2 takes the hidden units that register s of the two lane halves holds (W2 gathered to match).
 #include "readout.hpp"
 
 namespace tpnet {
@@ -17,13 +21,20 @@ static constexpr int MB = 512;            // threads per workgroup: 8 waves = th
 static constexpr int MF = 64, MH = 256;
 static constexpr int TS = 68;             // floats per LDS row of the feature / partial tiles (64 + 4: bank spread)
 
-template <int LPP, int VPL, int W, bool FULL>
+template <int LPP, int VPL, int W, bool FULL, bool F32>
 __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const int64_t* __restrict__ u,
                                                           const int64_t* __restrict__ v, int64_t n, double now,
-                                                          double lambda, uint32_t flags, const __bf16* __restrict__ w1,
-                                                          const float* __restrict__ b1, const __bf16* __restrict__ w2p,
+                                                          double lambda, uint32_t flags, const void* __restrict__ w1v,
+                                                          const float* __restrict__ b1, const void* __restrict__ w2v,
                                                           const float* __restrict__ b2, float* __restrict__ out_gram,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const float* __restrict__ feat_in) {
+    // feat_in != NULL: the dense layers alone on features that already exist ([n][64] f32): the tile is loaded, not formed
+    // bf16: w1 = bf16 [256][64], w2p = bf16 [64][256] (hidden axis permuted per 32-tile, fused_mlp.permute_w2)
+    // f32:  w1 = f32 [256][64] (mlp[0].weight as is), w2f = f32 [8 waves][2 output tiles][64 lanes][16 k-steps]
+    const __bf16* __restrict__ w1 = reinterpret_cast<const __bf16*>(w1v);
+    const __bf16* __restrict__ w2p = reinterpret_cast<const __bf16*>(w2v);
+    const float* __restrict__ w1f = reinterpret_cast<const float*>(w1v);
+    const float* __restrict__ w2f = reinterpret_cast<const float*>(w2v);
     constexpr int L = 3;
     constexpr int GPB = MB / LPP;             // pairs per readout pass
     constexpr int PT = 32 / GPB;              // passes per 32-pair tile
@@ -38,13 +49,31 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
     // ---- this wave's weights: rows [32 wave, 32 wave + 32) of W1 as A operand, the matching columns of (permuted) W2
     bf16x8 a1[4], a2[2][2];
+    float f1[F32 ? 32 : 1], f2[2][F32 ? 16 : 1];
+    if constexpr (F32) {
+        // layer 1: A[m = hidden 32 wave + r][k] with k-step s <-> features (s, s + 32): lane half h holds W1[..][32 h + s]
 #pragma unroll
-    for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const bf16x8*>(w1 + (wave * 32 + r) * MF + 16 * s + 8 * h);
+        for (int q4 = 0; q4 < 8; ++q4) {
+            const float4 x = *reinterpret_cast<const float4*>(w1f + (wave * 32 + r) * MF + 32 * h + 4 * q4);
+            f1[4 * q4] = x.x; f1[4 * q4 + 1] = x.y; f1[4 * q4 + 2] = x.z; f1[4 * q4 + 3] = x.w;
+        }
+        // layer 2: A[m = output 32 t2 + r][k] with k-step s <-> hidden 32 wave + (s&3) + 8 (s>>2) + 4 h (gathered on the host)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const int off = wave * 32 + 16 * s2 + 8 * h;          // position inside the PERMUTED hidden axis
-        a2[s2][0] = *reinterpret_cast<const bf16x8*>(w2p + r * MH + off);
-        a2[s2][1] = *reinterpret_cast<const bf16x8*>(w2p + (32 + r) * MH + off);
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 x = *reinterpret_cast<const float4*>(w2f + (((wave * 2 + t2) * 64 + lane) * 16) + 4 * q4);
+                f2[t2][4 * q4] = x.x; f2[t2][4 * q4 + 1] = x.y; f2[t2][4 * q4 + 2] = x.z; f2[t2][4 * q4 + 3] = x.w;
+            }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const bf16x8*>(w1 + (wave * 32 + r) * MF + 16 * s + 8 * h);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int off = wave * 32 + 16 * s2 + 8 * h;          // position inside the PERMUTED hidden axis
+            a2[s2][0] = *reinterpret_cast<const bf16x8*>(w2p + r * MH + off);
+            a2[s2][1] = *reinterpret_cast<const bf16x8*>(w2p + (32 + r) * MH + off);
+        }
     }
     float bias1[16];
 #pragma unroll
@@ -53,6 +82,14 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     const int64_t ntiles = (n + 31) / 32;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- the features of the tile's 32 pairs -> LDS
+        if (feat_in) {
+            for (int i = tid; i < 32 * (MF / 4); i += MB) {
+                const int row = i / (MF / 4), c = i % (MF / 4);
+                const int64_t p = tile * 32 + row;
+                const float4 x = p < n ? *reinterpret_cast<const float4*>(feat_in + p * MF + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(feat + row * TS + 4 * c) = x;
+            }
+        } else
 #pragma unroll 1
         for (int pass = 0; pass < PT; ++pass) {
             const int pidx = pass * GPB + g;
@@ -68,34 +105,50 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
             for (int i = tid; i < npair * MF; i += MB) out_gram[tile * 32 * MF + i] = feat[(i / MF) * TS + (i % MF)];
         }
         // ---- layer 1, hidden tile `wave`: H^T = W1 . X^T; lane (r, h) holds X[pair r][16 s + 8 h + j] as B operand
-        f32x16 acc;
+        f32x16 acc, y0, y1;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+        for (int q = 0; q < 16; ++q) { acc[q] = 0.0f; y0[q] = 0.0f; y1[q] = 0.0f; }
+        if constexpr (F32) {
+            float xs[32];                         // X[pair r][32 h + s], s = 0..31
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float* xr = feat + r * TS + 16 * s + 8 * h;
-            const float4 lo = *reinterpret_cast<const float4*>(xr);
-            const float4 hi = *reinterpret_cast<const float4*>(xr + 4);
-            bf16x8 bx;
-            bx[0] = (__bf16)lo.x; bx[1] = (__bf16)lo.y; bx[2] = (__bf16)lo.z; bx[3] = (__bf16)lo.w;
-            bx[4] = (__bf16)hi.x; bx[5] = (__bf16)hi.y; bx[6] = (__bf16)hi.z; bx[7] = (__bf16)hi.w;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bx, acc, 0, 0, 0);
-        }
-        // register q = hidden row 32 wave + (q&3) + 8 (q>>2) + 4 h, column = pair r  ->  bias, ReLU, B operand of layer 2
-        bf16x8 bh[2];
+            for (int q4 = 0; q4 < 8; ++q4) {
+                const float4 x = *reinterpret_cast<const float4*>(feat + r * TS + 32 * h + 4 * q4);
+                xs[4 * q4] = x.x; xs[4 * q4 + 1] = x.y; xs[4 * q4 + 2] = x.z; xs[4 * q4 + 3] = x.w;
+            }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float x = acc[q] + bias1[q];
-            x = x > 0.0f ? x : 0.0f;
-            bh[q >> 3][q & 7] = (__bf16)x;
-        }
-        f32x16 y0, y1;
+            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f1[s], xs[s], acc, 0, 0, 0);
+            // register q = hidden row 32 wave + (q&3) + 8 (q>>2) + 4 h of pair r: bias, ReLU; it IS the B operand of k-step q
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { y0[q] = 0.0f; y1[q] = 0.0f; }
+            for (int q = 0; q < 16; ++q) {
+                float x = acc[q] + bias1[q];
+                x = x > 0.0f ? x : 0.0f;
+                y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[0][q], x, y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[1][q], x, y1, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][0], bh[s2], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][1], bh[s2], y1, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                const float* xr = feat + r * TS + 16 * s + 8 * h;
+                const float4 lo = *reinterpret_cast<const float4*>(xr);
+                const float4 hi = *reinterpret_cast<const float4*>(xr + 4);
+                bf16x8 bx;
+                bx[0] = (__bf16)lo.x; bx[1] = (__bf16)lo.y; bx[2] = (__bf16)lo.z; bx[3] = (__bf16)lo.w;
+                bx[4] = (__bf16)hi.x; bx[5] = (__bf16)hi.y; bx[6] = (__bf16)hi.z; bx[7] = (__bf16)hi.w;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bx, acc, 0, 0, 0);
+            }
+            // register q = hidden row 32 wave + (q&3) + 8 (q>>2) + 4 h, column = pair r  ->  bias, ReLU, B operand of layer 2
+            bf16x8 bh[2];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float x = acc[q] + bias1[q];
+                x = x > 0.0f ? x : 0.0f;
+                bh[q >> 3][q & 7] = (__bf16)x;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][0], bh[s2], y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][1], bh[s2], y1, 0, 0, 0);
+            }
         }
         // ---- the eight partial tiles, added in a fixed order: waves 0..3 park theirs, waves 4..7 add theirs on top, then
         // every thread sums the four slabs for its outputs.  y0[4i..4i+3] = outputs 8i + 4h + (0..3) of pair r, y1: + 32
@@ -141,9 +194,14 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     }
 }
 
+bool pair_feature_mfma_supported(const tpnet_state& st) {
+    const Geom gm = pick_geom(st.d);
+    return st.L == 3 && gm.w == 4 && gm.lpp >= 16;
+}
+
 int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                              uint32_t flags, const void* w1, const float* b1, const void* w2p, const float* b2,
-                             float* out_gram, float* out, hipStream_t s) {
+                             float* out_gram, float* out, hipStream_t s, bool f32, const float* feat_in) {
     if (n == 0) return TPNET_OK;
     if (st.L != 3 || (flags & TPNET_FLAG_PACKED)) return TPNET_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(b2)) & 15) return TPNET_ERR_BAD_ARG;
@@ -153,8 +211,14 @@ int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int6
     const int64_t tiles = (n + 31) / 32;
     const int grid = (int)(tiles < 2048 ? tiles : 2048);
 #define TPNET_PF(LPP_, VPL_, FULL_)                                                                                          \
-    hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now, lambda, flags, \
-                       (const __bf16*)w1, b1, (const __bf16*)w2p, b2, out_gram, out)
+    do {                                                                                                                     \
+        if (f32)                                                                                                             \
+            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, true>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now, \
+                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, false>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now, \
+                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
+    } while (0)
     if (gm.lpp == 16 && gm.vpl == 1) { if (full) TPNET_PF(16, 1, true); else TPNET_PF(16, 1, false); }
     else if (gm.lpp == 16) { if (full) TPNET_PF(16, 2, true); else TPNET_PF(16, 2, false); }
     else if (gm.lpp == 32 && gm.vpl == 1) { if (full) TPNET_PF(32, 1, true); else TPNET_PF(32, 1, false); }
@@ -176,5 +240,16 @@ extern "C" int tpnet_pair_feature_bf16(const tpnet_state* st, const int64_t* u, 
     if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1) return TPNET_ERR_BAD_ARG;
     if (n < 0 || (n > 0 && (!u || !v || !out || !w1_bf16 || !b1 || !w2p_bf16 || !b2))) return TPNET_ERR_BAD_ARG;
     return launch_pair_feature_bf16(*st, u, v, n, now_time, lambda, flags, w1_bf16, b1, w2p_bf16, b2, out_gram, out,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, false, nullptr);
+}
+
+extern "C" int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, float* y, void* stream) {
+    if (n < 0 || !mlp || (n > 0 && (!x || !y))) return TPNET_ERR_BAD_ARG;
+    if (n == 0) return TPNET_OK;
+    if (mlp->F != 64 || mlp->H != 256 || !mlp->w1 || !mlp->w2f || !mlp->b1 || !mlp->b2) return TPNET_ERR_BAD_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TPNET_ERR_BAD_ARG;
+    tpnet_state st{};                      // (not dereferenced when the tile comes from `x`; geometry of d = 128 picks the 32-lane kernel)
+    st.N = 1; st.d = 128; st.L = 3;
+    return launch_pair_feature_bf16(st, nullptr, nullptr, n, 0.0, 0.0, 0, mlp->w1, mlp->b1, mlp->w2f, mlp->b2, nullptr, y,
+                                    (hipStream_t)stream, true, x);
 }

@@ -149,6 +149,13 @@ int launch_unpack_bundles(const tpnet_state& st, const int64_t* local_ids, int64
 int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                         uint32_t flags, const tpnet_mlp& m, float* out_gram, float* out, hipStream_t s);
 
+// readout + mlp on the matrix cores (feature_mfma.hip): bf16 (opt-in class) or fp32 (f32 = true: w1 = f32 [256][64], w2 = the
+// gathered f32 layout of tpnet_mlp::w2f)
+bool pair_feature_mfma_supported(const tpnet_state& st);
+int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
+                             uint32_t flags, const void* w1, const float* b1, const void* w2p, const float* b2,
+                             float* out_gram, float* out, hipStream_t s, bool f32, const float* feat_in = nullptr);
+
 // the plan of ONE batch by one workgroup (plan.hip, k_plan_one): same Plan contents as plan_build for batch 0 of a chunk
 static constexpr int64_t PLAN_ONE_MAX = 2048;
 int64_t plan_one_max_batch();      // PLAN_ONE_MAX (0 with the developer override TPNET_DEV_NO_PLAN_ONE)

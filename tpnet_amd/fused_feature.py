@@ -26,6 +26,73 @@ def supported(mlp: torch.nn.Module, F: int) -> bool:
             and mlp[0].weight.dtype == torch.float32 and mlp[0].weight.is_cuda)
 
 
+_W2F_IDX = {}
+
+
+def _w2f_index(dev):
+    """Index tensors of the gather w2f[((w*2 + t)*64 + lane)*16 + s] = W2[32 t + (lane & 31)][32 w + (s & 3) + 8 (s >> 2) +
+    4 (lane >> 5)] (w = 0..7, t = 0..1, lane = 0..63, s = 0..15), cached per device."""
+    key = str(dev)
+    if key not in _W2F_IDX:
+        w = torch.arange(8).view(8, 1, 1, 1)
+        t = torch.arange(2).view(1, 2, 1, 1)
+        lane = torch.arange(64).view(1, 1, 64, 1)
+        s_ = torch.arange(16).view(1, 1, 1, 16)
+        rows = (32 * t + (lane & 31)).expand(8, 2, 64, 16).reshape(-1)
+        cols = (32 * w + (s_ & 3) + 8 * (s_ >> 2) + 4 * (lane >> 5)).expand(8, 2, 64, 16).reshape(-1)
+        _W2F_IDX[key] = (rows.to(dev), cols.to(dev))
+    return _W2F_IDX[key]
+
+
+def _w2f_rows(dev):
+    return _w2f_index(dev)[0]
+
+
+def _w2f_cols(dev):
+    return _w2f_index(dev)[1]
+
+
+class _MlpF32(torch.autograd.Function):
+    """self.mlp alone on the fp32 matrix cores (tpnet_mlp64_f32); backward = the fp32 torch expressions."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, mlp_ref):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        if x.shape[0]:
+            rc = _lib.load().tpnet_mlp64_f32(x.data_ptr(), x.shape[0], mlp_ref, y.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc:
+                _lib.check(rc, "mlp64_f32")
+        ctx.save_for_backward(x, w1, b1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        pre = torch.addmm(b1, x, w1.t())
+        hid = torch.relu(pre)
+        gh = (gy @ w2) * (pre > 0)
+        return None, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None
+
+
+def mlp_f32(mlp, x):
+    """mlp(x) through tpnet_mlp64_f32 if `mlp` is the reference's 64-256-64 on this GPU (else None)."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2 or x.shape[1] != 64:
+        return None
+    prep = prepared(mlp, 64)
+    if prep is None or not prep[1].w1:
+        return None
+    if needs_grad(prep[4]):
+        return _MlpF32.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, prep[2])
+    return _MlpF32.forward(_NoCtx(), x, None, None, None, None, prep[2])
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
 def prepared(mlp, F):
     """(key, tpnet_mlp struct, its byref, keep-alive tensors) or None if `mlp` is not the reference's Linear-ReLU-Linear on
     a GPU: transposed f32 copies of the weights, rebuilt only when a parameter changed (optimizer step, load_state_dict,
@@ -41,11 +108,16 @@ def prepared(mlp, F):
         if not supported(mlp, F):
             return None
         with torch.no_grad():
-            keep = (w1.detach().t().contiguous(), b1.detach().contiguous(), w2.detach().t().contiguous(),
-                    b2.detach().contiguous())
+            keep = [w1.detach().t().contiguous(), b1.detach().contiguous(), w2.detach().t().contiguous(),
+                    b2.detach().contiguous()]
+            p_w1 = p_w2f = None
+            if F == 64:                           # L = 3: the layouts of the fp32 matrix-core kernel (include/tpnet_hip.h, tpnet_mlp)
+                keep.append(w1.detach().contiguous())
+                keep.append(w2.detach()[_w2f_rows(w2.device), _w2f_cols(w2.device)].contiguous())
+                p_w1, p_w2f = keep[4].data_ptr(), keep[5].data_ptr()
         st = _lib.Mlp(w1t=keep[0].data_ptr(), b1=keep[1].data_ptr(), w2t=keep[2].data_ptr(), b2=keep[3].data_ptr(),
-                      F=w1.shape[1], H=w1.shape[0])
-        cache = (key, st, C.byref(st), keep, (w1, b1, w2, b2))
+                      F=w1.shape[1], H=w1.shape[0], w1=p_w1, w2f=p_w2f)
+        cache = (key, st, C.byref(st), tuple(keep), (w1, b1, w2, b2))
         _PREPARED[mlp] = cache
     return cache
 

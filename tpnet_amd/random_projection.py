@@ -562,13 +562,14 @@ class RandomProjectionModule(nn.Module):
             return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
         src = np.asarray(src_node_ids)
         n = len(src)
-        if n <= _ff.MAX_PAIRS and not self.fused_mlp and not isinstance(dst_node_ids, torch.Tensor):
-            # the decoder's call (models/modules.py:112: n = batch size): readout AND self.mlp in one launch, fp32
+        if not self.fused_mlp and not isinstance(dst_node_ids, torch.Tensor):
+            # readout AND self.mlp in one launch, fp32: the decoder's call (models/modules.py:112: n = batch size) and, where the
+            # fp32 matrix-core kernel serves the shape (L = 3, rows of >= 36 floats in 16-byte vectors), lists of any length
             fused = self._fused_feature(src, dst_node_ids, n)
             if fused is not None:
                 return fused
         # (rows of <= 128 floats: the generic kernel's 16-lane geometry is as fast on long lists; measured)
-        if self.dim > 128 and n >= 4 and n % 2 == 0 and n > _ff.MAX_PAIRS and np.array_equal(src[: n // 2], src[n // 2:]):
+        if self.dim > 128 and n >= 4 and n % 2 == 0 and n > 8192 and np.array_equal(src[: n // 2], src[n // 2:]):
             # the encoder's pattern: neighbours tiled twice, each half of dst a np.repeat of the row's anchor
             # (models/TPNet.py:313-316): one lane group per row with the anchors in registers (rows of <= 128 floats: the
             # generic kernel is as fast on long lists -- measured, tools/encoder_readout.py)
@@ -660,8 +661,23 @@ class RandomProjectionModule(nn.Module):
         if prep is None:
             return None
         self._ensure_engine()
-        if n > self._eng["stage"].max_pairs:
-            return None
+        mfma = bool(prep[1].w1) and self.dim % 4 == 0 and self.dim >= 36 and not self.use_matrix
+        if n > (self._eng["stage"].max_pairs if mfma else _ff.MAX_PAIRS):
+            # a long list: with the matrix-core kernel still one launch, from a device copy of the ids -- except the encoder's
+            # pattern on wide rows, which the caller below serves with the anchored readout + the matrix-core mlp
+            if not mfma or (self.dim > 128 and n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:])):
+                return None
+            u, v = self._to_device(self._check_ids(src, "src_node_ids"), self._check_ids(dst, "dst_node_ids"))
+            flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+
+            def launch(gram):
+                out = torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"])
+                _lib.check(_lib.load().tpnet_pair_feature(self._st_ref(), u.data_ptr(), v.data_ptr(), n, self._now_host,
+                                                          float(self.time_decay_weight), flags, prep[2],
+                                                          gram.data_ptr() if gram is not None else None, out.data_ptr(),
+                                                          self._stream()), "pair_feature")
+                return out
+            return _ff.apply_with_grad(mlp, launch, n, NG) if _ff.needs_grad(prep[4]) else launch(None)
         uh, vh = self._host_ids(src, "src_node_ids"), self._host_ids(dst, "dst_node_ids")
         flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
         if _ff.needs_grad(prep[4]):
@@ -673,7 +689,8 @@ class RandomProjectionModule(nn.Module):
             from . import fused_mlp as fm
             if fm.supported(self.mlp):
                 return fm.fused_mlp(self.mlp, feats)
-        return self.mlp(feats)
+        y = _ff.mlp_f32(self.mlp, feats) if self.num_layer == 3 else None      # the fp32 matrix-core kernel where it applies
+        return y if y is not None else self.mlp(feats)
 
     def reset_random_projections(self):
         """models/TPNet.py:131-139."""
