@@ -109,8 +109,43 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
             rp.update(src[s], dst[s], t[s])
         torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    return {"value": nb * B / el, "unit": "edges/s", "us_per_batch": el / nb * 1e6,
-            "what": "module API per batch from host arrays: 2 x get_pair_wise_feature (with rp.mlp) + update"}
+    res = {"value": nb * B / el, "unit": "edges/s", "us_per_batch": el / nb * 1e6,
+           "what": "module API per batch from host arrays: 2 x get_pair_wise_feature (with rp.mlp) + update"}
+    # encoder-level unit (secondary): the encoder's two calls per batch on top -- 4*B*K pairs each in the
+    # reference's tile / repeat pattern (models/TPNet.py:311-316), K = 20 synthetic neighbours per node
+    K = 20
+    nbe = max(1, min(8, nb))
+    rng = np.random.RandomState(7)
+    N = rp.node_num
+    calls = []                                   # the index arrays of every call, built before the clock starts (that part is the
+    for b in range(nbe + 2):                     # reference encoder's own host work, not the module API)
+        s = slice(b * B, (b + 1) * B)
+        nodes = np.concatenate([src[s], dst[s]])
+        per = []
+        for anchors in ((src[s], dst[s]), (src[s], neg[s])):
+            neigh = rng.randint(1, N, (len(nodes), K)).astype(np.int64)
+            per.append((np.tile(neigh.reshape(-1), 2),
+                        np.concatenate([np.repeat(np.tile(anchors[0], 2), K), np.repeat(np.tile(anchors[1], 2), K)])))
+        calls.append(per)
+    rp.reset_random_projections()
+    with torch.no_grad():
+        for b in range(nbe + 2):
+            if b == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            s = slice(b * B, (b + 1) * B)
+            for u_, v_ in calls[b]:
+                rp.get_pair_wise_feature(u_, v_)
+            rp.get_pair_wise_feature(src[s], dst[s])
+            rp.get_pair_wise_feature(src[s], neg[s])
+            rp.update(src[s], dst[s], t[s])
+        torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res["encoder_level"] = {"value": nbe * B / el, "unit": "edges/s", "us_per_batch": el / nbe * 1e6,
+                            "what": f"+ 2 x get_pair_wise_feature on 4*B*K = {4 * B * K} pairs (K = {K}) per batch, host index arrays in the "
+                                    "reference's tile / repeat layout (built before the clock starts)"} pairs (K = {K}) per batch, index arrays "
+                                    "built on the host as the reference builds them"}
+    return res
 
 
 def copy_bandwidth_gbs(dev):
