@@ -143,8 +143,7 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
     el = time.perf_counter() - t0
     res["encoder_level"] = {"value": nbe * B / el, "unit": "edges/s", "us_per_batch": el / nbe * 1e6,
                             "what": f"+ 2 x get_pair_wise_feature on 4*B*K = {4 * B * K} pairs (K = {K}) per batch, host index arrays in the "
-                                    "reference's tile / repeat layout (built before the clock starts)"} pairs (K = {K}) per batch, index arrays "
-                                    "built on the host as the reference builds them"}
+                                    "reference's tile / repeat layout (built before the clock starts)"}
     return res
 
 
