@@ -310,7 +310,7 @@ def main():
     rp = None
     out_pos = out_neg = None
     process_warmup = None
-    if shard == "single" and os.environ.get("TPNET_BENCH_PROCESS_WARMUP", "1") != "0":
+    if shard == "single" and os.environ.get("TPNET_BENCH_PROCESS_WARMUP", "1") != "0" and 28.0 * N * d < 20e9:
         # First-use costs of the HIP runtime in a fresh process (measured with tools/bench_flow.py on fresh boxes: the FIRST
         # K-step call of a process takes 90-150 us longer than every later identical one -- 276 / 338 us against 189 us for
         # K = 20 -- whatever module it runs on, with or without a GPU pre-heat): one untimed pass of the same call shapes on a
