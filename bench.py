@@ -460,7 +460,7 @@ def main():
         timed = roof_pass(K, out_pos, out_neg)
         if Kr > K:
             # the dominant kernel of the path is the one long streams run on (tpnet_run_stream picks the windowed schedule
-            # from 48 batches): it is timed over ROOF_STEPS batches of the same stream; the figure for the K timed steps
+            # from 56 batches): it is timed over ROOF_STEPS batches of the same stream; the figure for the K timed steps
             # themselves (the per-batch kernel, launch-bound) is kept next to it
             o_pos = torch.empty((Kr * Bg, out_pos.shape[1]), dtype=torch.float32, device=dev)
             o_neg = torch.empty_like(o_pos)

@@ -79,7 +79,7 @@ typedef struct tpnet_state {
                                        across GPUs before tpnet_gram_unpack finishes them */
 
 #define TPNET_FLAG_SCHED_WINDOWED 16u /* tpnet_run_stream: take the windowed schedule whenever it applies (>= 4 batches), not
-                                       only for streams long enough for it to pay (>= 48 batches) */
+                                       only for streams long enough for it to pay (>= 56 batches) */
 #define TPNET_FLAG_SCHED_BATCH 32u    /* tpnet_run_stream: one launch per batch, always */
 
 const char* tpnet_strerror(int status);

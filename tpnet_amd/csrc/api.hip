@@ -55,9 +55,10 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL | TPNET_FLAG_SCHED_BATCH)) return 0;
     const int K = wplan_window_batches(batch, st.d, st.L);
     const int64_t nb = (E + batch - 1) / batch;
-    // short streams: the windowed schedule pays ~280 us up front (two sorts, pipeline fill) and ~4 us per batch at C2, the
-    // per-batch one ~160 us and ~7 us: the crossover is near 40 batches
-    static const int min_nb = env_int("TPNET_DEV_WIN_MIN_BATCHES", 48);
+    // short streams: the windowed schedule pays ~250 us up front (two sorts, L + 1 dependent launches of >= 35 us to fill the
+    // pipeline) and ~3.3 us per batch at C2, the per-batch one ~50 us and ~6.7 us: measured crossover between 40 batches
+    // (309 against 380 us) and 60 (438 against 430 us)
+    static const int min_nb = env_int("TPNET_DEV_WIN_MIN_BATCHES", 56);
     if (K == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
     *K_out = K;
     const int64_t Ew = (int64_t)K * batch;
