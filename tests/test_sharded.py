@@ -129,6 +129,96 @@ def _relabel_worker(rank, world, port, N, E, B, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_targeted_exchange_plan_is_complete_and_consistent(G):
+    """plan_targeted (a row travels only to the ranks that read it), computed for EVERY rank: rank r receives
+    exactly the remote nodes its own pairs and targets read (dst / neg of the edges whose src it owns, src of those whose dst
+    it owns), ordered by (owner, node); and what owner s says it sends to r is, element for element, what r expects from s."""
+    from tpnet_amd.sharded import plan_targeted
+    rng = np.random.RandomState(G)
+    N, E, B = 200, 530, 64
+    src, dst, neg = (rng.randint(1, N, E).astype(np.int64) for _ in range(3))
+    ts = torch.from_numpy
+    plans = [plan_targeted(ts(src), ts(dst), ts(neg), B, N, G, me) for me in range(G)]
+    for b in range((E + B - 1) // B):
+        s = slice(b * B, min((b + 1) * B, E))
+        for r in range(G):
+            need = set()
+            for e in range(s.start, s.stop):
+                if src[e] % G == r:
+                    need.update([int(dst[e]), int(neg[e])])
+                if dst[e] % G == r:
+                    need.add(int(src[e]))
+            need = {x for x in need if x % G != r}
+            P = plans[r]
+            lo = int(P["recv_cnt"][:b].sum())
+            got = P["recv_nodes"][lo:lo + int(P["recv_cnt"][b].sum())].tolist()
+            assert set(got) == need and len(got) == len(need)
+            o = 0
+            for own in range(G):
+                c = int(P["recv_cnt"][b][own])
+                seg = got[o:o + c]
+                o += c
+                assert all(x % G == own for x in seg) and seg == sorted(seg)
+                Ps = plans[own]
+                assert int(Ps["send_cnt"][b][r]) == c
+                slo = int(Ps["send_cnt"][:b].sum()) + int(Ps["send_cnt"][b][:r].sum())
+                assert Ps["send_nodes"][slo:slo + c].tolist() == seg
+
+
+def _targeted_relabel_worker(rank, world, port, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from tpnet_amd.sharded import ShardedStreamRunner
+        N, E, B = 97, 300, 40
+
+        class _Stub:                                   # stands in for the local module (no GPU in this tier)
+            node_num = (N + world - 1) // world + 3 * B
+        src, dst, neg, t = _stream(2, N, E)
+        run = ShardedStreamRunner(_Stub(), N, 3 * B)
+        ts = lambda x: torch.from_numpy(x)
+        R = run.relabel_targeted(ts(src), ts(dst), ts(neg), B)
+        n_cap, H = run.n_cap, run.H
+        ok = True
+        for b in range((E + B - 1) // B):
+            s = slice(b * B, min((b + 1) * B, E))
+            k0, k1 = int(R["rstart"][b]), int(R["rstart"][b] + R["rtot"][b])
+            slot_of = {int(n): int(l) for n, l in zip(R["recv_nodes"][k0:k1], R["unpack_ids"][k0:k1])}
+            ok &= sorted(slot_of.values()) == list(range(n_cap, n_cap + len(slot_of)))          # one halo row per received node
+            for which, g in (("src", src[s]), ("dst", dst[s]), ("neg", neg[s])):
+                l = R[which][s].numpy()
+                for x, lx in zip(g.tolist(), l.tolist()):
+                    if x % world == rank:
+                        ok &= lx == x // world                                                   # owned rows: n // G
+                    elif x in slot_of:
+                        ok &= lx == slot_of[x]                                                   # received this batch: its halo row
+                    else:
+                        ok &= lx == n_cap                                                        # never read by this rank
+            # everything this rank's units read is owned or received
+            for e in range(s.start, s.stop):
+                if src[e] % world == rank:
+                    ok &= all(x % world == rank or int(x) in slot_of for x in (dst[e], neg[e]))
+                if dst[e] % world == rank:
+                    ok &= src[e] % world == rank or int(src[e]) in slot_of
+        q.put((rank, ok, n_cap + H))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_targeted_relabelling_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_targeted_relabel_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_shard_relabelling_gloo(world):
     ctx = mp.get_context("spawn")
@@ -145,7 +235,7 @@ def test_row_shard_relabelling_gloo(world):
     assert all(rows == (N + world - 1) // world + 3 * B for _, _, rows in res)     # rows per rank: N/G + halo, not N
 
 
-def _gpu_worker(rank, world, port, cfg, q):
+def _gpu_worker(rank, world, port, cfg, q, exchange="allgather"):
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -158,6 +248,7 @@ def _gpu_worker(rank, world, port, cfg, q):
         runner = ShardedStreamRunner.create(node_num=N, edge_num=E, dim=d, num_layer=L, time_decay_weight=lam, device=dev,
                                             beginning_time=np.float64(t[0]), halo_rows=3 * B, seed=rank)
         runner.set_full_p0(P0)
+        runner.exchange = exchange
         # the shard holds N/G + halo rows, not N
         n_cap = (N + world - 1) // world
         assert runner.rp.node_num == n_cap + 3 * B
@@ -185,8 +276,9 @@ def _gpu_worker(rank, world, port, cfg, q):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["allgather", "targeted"])
 @pytest.mark.parametrize("cfg", [(211, 128, 3, 700, 100, 2e-6), (150, 64, 2, 333, 50, 1e-6), (3000, 128, 3, 900, 60, 2e-6)])
-def test_sharded_stream_equals_single_gpu(cfg):
+def test_sharded_stream_equals_single_gpu(cfg, exchange):
     """Two ranks (gloo) sharing cuda:0, each holding ONLY its rows (+ halo): features and the re-assembled table equal the
     single-GPU run; the per-rank table is N/G + halo rows."""
     if not torch.cuda.is_available():
@@ -194,7 +286,7 @@ def test_sharded_stream_equals_single_gpu(cfg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, cfg, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     msgs = [q.get(timeout=300) for _ in range(3)]

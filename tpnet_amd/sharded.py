@@ -62,6 +62,50 @@ def plan_touched(src: torch.Tensor, dst: torch.Tensor, neg, batch: int, N: int, 
     return un.contiguous(), counts, offsets
 
 
+def plan_targeted(src: torch.Tensor, dst: torch.Tensor, neg, batch: int, N: int, G: int, me: int):
+    """TARGETED exchange plan of rank `me` (every row travels only to the ranks that read it).
+    Rank r reads, in batch b: dst and neg of the edges whose src it owns (their readouts are its, and dst is the partner of its
+    target src), and src of the edges whose dst it owns (the partner of its target dst).  Every rank derives the same lists
+    from the stream (no request round).  Pure torch on any device.  Returns a dict:
+      recv_nodes   int64 [R]      the remote nodes this rank receives, ordered by (batch, owner, node)
+      recv_cnt     int64 [nb, G]  how many of them per batch come from each owner (host)
+      send_nodes   int64 [S]      the owned nodes this rank sends, ordered by (batch, reader, node) (a node repeats per reader)
+      send_cnt     int64 [nb, G]  how many go to each reader per batch (host)
+      recv_keys    int64 [R]      (batch * N + node), ascending inside a batch's owner runs: for the endpoint lookup
+    """
+    E = int(src.numel())
+    nb = (E + batch - 1) // batch
+    dev = src.device
+    bidx = torch.arange(E, device=dev, dtype=torch.int64) // batch
+    s64, d64 = src.to(torch.int64), dst.to(torch.int64)
+    readers = [s64 % G, d64 % G]
+    nodes = [d64, s64]
+    bs = [bidx, bidx]
+    if neg is not None:
+        readers.append(s64 % G)
+        nodes.append(neg.to(torch.int64))
+        bs.append(bidx)
+    rd, nd, bb = torch.cat(readers), torch.cat(nodes), torch.cat(bs)
+    keep = (nd % G) != rd                                        # a rank does not send to itself
+    rd, nd, bb = rd[keep], nd[keep], bb[keep]
+    # distinct (batch, reader, owner, node), sorted in that order
+    key = ((bb * G + rd) * G + (nd % G)) * N + nd
+    key = torch.unique(key)
+    k_node = key % N
+    k_own = (key // N) % G
+    k_rd = (key // (N * G)) % G
+    k_b = key // (N * G * G)
+    mine_r = k_rd == me
+    recv_nodes = k_node[mine_r]
+    recv_b, recv_o = k_b[mine_r], k_own[mine_r]
+    recv_cnt = torch.bincount(recv_b * G + recv_o, minlength=nb * G).view(nb, G).cpu().numpy().astype(np.int64)
+    mine_s = k_own == me
+    send_nodes, send_b, send_r = k_node[mine_s], k_b[mine_s], k_rd[mine_s]          # already ordered by (batch, reader, node)
+    send_cnt = torch.bincount(send_b * G + send_r, minlength=nb * G).view(nb, G).cpu().numpy().astype(np.int64)
+    return dict(recv_nodes=recv_nodes.contiguous(), recv_cnt=recv_cnt, send_nodes=send_nodes.contiguous(), send_cnt=send_cnt,
+                recv_keys=(recv_b * N + recv_nodes).contiguous(), recv_b=recv_b)
+
+
 def exchange_rows(send: torch.Tensor, maxc: int, group=None):
     """All-gather of one padded [maxc, row] buffer per rank -> [G, maxc, row]."""
     G = dist.get_world_size(group)
@@ -81,6 +125,9 @@ class ShardedStreamRunner:
     table with relabelled node ids (owned: n // G, remote: n_cap + its slot in the batch's halo), restricted to the
     targets / pair sources the rank owns (tpnet_step_batch, own_mod = 0).  Memory per rank: (n_cap + H) rows instead of N.
     """
+
+    exchange = "allgather"     # "allgather" (v1: every touched row to every rank, RCCL from C) | "targeted" (v2: each row only to
+                               # the ranks that read it, all_to_all through torch.distributed; see run_stream_targeted)
 
     def __init__(self, rp_local, node_num: int, halo_rows: int, group=None):
         self.rp = rp_local
@@ -210,6 +257,8 @@ class ShardedStreamRunner:
         """Same contract as RandomProjectionModule.run_stream (global node ids in, per-edge features out), over all ranks.
         Returns (feat_pos, feat_neg): complete on every rank if merge_outputs (one all-reduce of disjoint rows at the end),
         otherwise each rank holds the rows of the pairs whose src node it owns and zeros elsewhere."""
+        if self.exchange == "targeted":
+            return self.run_stream_targeted(src, dst, neg, t, batch_size, t_host_last, merge_outputs)
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
@@ -298,6 +347,124 @@ class ShardedStreamRunner:
         rp._now_dirty = True
         if G > 1 and merge_outputs:
             dist.all_reduce(out_pos, group=self.group)          # disjoint rows: the sum is a merge
+            if out_neg is not None:
+                dist.all_reduce(out_neg, group=self.group)
+        return out_pos, out_neg
+
+    # ---- targeted exchange (v2) ------------------------------------------------------------------------------------
+    def relabel_targeted(self, src, dst, neg, batch_size: int):
+        """plan_targeted + the local id of every edge endpoint: owned -> n // G; a remote node this rank receives in the
+        edge's batch -> its halo row (n_cap + position in the batch's receive list); any other remote node -> the first halo
+        row (never dereferenced by a unit this rank computes: it is neither a partner of one of its targets nor an endpoint of
+        one of its pairs)."""
+        G, me, N, n_cap = self.G, self.me, self.N, self.n_cap
+        E, B = int(src.numel()), int(batch_size)
+        nb = (E + B - 1) // B
+        dev = src.device
+        P = plan_targeted(src, dst, neg, B, N, G, me)
+        rtot = P["recv_cnt"].sum(axis=1)
+        if nb and int(rtot.max()) > self.H:
+            raise ValueError(f"a batch reads {int(rtot.max())} rows of other ranks but the shard has {self.H} halo rows")
+        rstart = np.concatenate([[0], np.cumsum(rtot)[:-1]]).astype(np.int64)
+        slot = torch.arange(P["recv_nodes"].numel(), device=dev) - torch.from_numpy(rstart).to(dev)[P["recv_b"]]
+        bidx = torch.arange(E, device=dev, dtype=torch.int64) // B
+        keys = P["recv_keys"]
+        # (recv_keys are ascending per batch only inside an owner's run: sort once for the lookup)
+        order = torch.argsort(keys)
+        skeys, sslot = keys[order], slot[order]
+
+        def local(x):
+            x = x.to(torch.int64)
+            k = bidx * N + x
+            pos = torch.clamp(torch.searchsorted(skeys, k), max=max(int(skeys.numel()) - 1, 0))
+            hit = (skeys[pos] == k) if skeys.numel() else torch.zeros_like(k, dtype=torch.bool)
+            halo = n_cap + (sslot[pos] if skeys.numel() else torch.zeros_like(k))
+            return torch.where(x % G == me, x // G, torch.where(hit, halo, torch.full_like(k, n_cap))).contiguous()
+
+        P.update(src=local(src), dst=local(dst), neg=local(neg) if neg is not None else None,
+                 unpack_ids=(n_cap + slot).contiguous(), pack_ids=(P["send_nodes"] // G).contiguous(), rtot=rtot, rstart=rstart)
+        return P
+
+    def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
+        """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
+        all-to-all with per-peer counts (RCCL: ncclSend / ncclRecv pairs under torch.distributed.all_to_all_single; gloo in
+        the tests: an all-gather of the send buffers from which every rank takes its parts), unpack into the halo, step.
+        Same results as the all-gather variant; each rank receives only what its own pairs and targets read."""
+        rp, G, me = self.rp, self.G, self.me
+        rp._ensure_engine()
+        lib = _lib.load()
+        dev = rp._dev()
+        E, B = int(src.numel()), int(batch_size)
+        nb = (E + B - 1) // B
+        L, d = rp.num_layer, rp.dim
+        bundle = (L + 1) * d
+        NG = rp.pair_wise_feature_dim
+        lam = float(rp.time_decay_weight)
+        out_pos = torch.zeros((E, NG), dtype=torch.float32, device=dev)
+        out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
+        if E == 0:
+            return out_pos, out_neg
+        if int(torch.stack([src.min(), dst.min()]).min()) < 0 or int(torch.stack([src.max(), dst.max()]).max()) >= self.N:
+            raise IndexError(f"node id out of range for {self.N} nodes")
+        R = self.relabel_targeted(src, dst, neg, B)
+        last_idx = torch.clamp(torch.arange(1, nb + 1, device=dev) * B, max=E) - 1
+        t_last = t[last_idx].cpu().numpy() if t_host_last is None else np.asarray(t_host_last, dtype=np.float64)
+        ws = rp._workspace(E, B)
+        st = rp._state()
+        stream = rp._stream()
+        flags = _lib.FLAG_NOT_SCALE if rp.not_scale else 0
+        ls, ld, ln = R["src"], R["dst"], R["neg"]
+        _lib.check(lib.tpnet_plan_stream(C.byref(st), ls.data_ptr(), ld.data_ptr(), t.data_ptr(), E, B, rp._now_host,
+                                         lam, flags, ws.data_ptr(), ws.numel(), stream), "plan_stream")
+        lid0 = rp._next_launch_ids(nb)
+        scnt, rcnt = R["send_cnt"], R["recv_cnt"]
+        stot, rtot = scnt.sum(axis=1), R["rtot"]
+        sstart = np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
+        send = torch.zeros((max(int(stot.max()), 1), bundle), dtype=torch.float32, device=dev)
+        recv = torch.empty((max(int(rtot.max()), 1), bundle), dtype=torch.float32, device=dev)
+        zero_off = torch.zeros(1, dtype=torch.int64, device=dev)
+        nccl = G > 1 and dist.get_backend(self.group) == "nccl"
+        if G > 1 and not nccl:
+            # gloo (tests): every rank needs everybody's per-reader counts to cut the gathered send buffers
+            all_scnt = [None] * G
+            dist.all_gather_object(all_scnt, scnt, group=self.group)
+            smax = max(int(a.sum(axis=1).max()) for a in all_scnt)
+            gathered = [torch.empty((max(smax, 1), bundle), dtype=torch.float32, device=dev) for _ in range(G)]
+            padded = torch.zeros((max(smax, 1), bundle), dtype=torch.float32, device=dev)
+        now = rp._now_host
+        stp = C.byref(st)
+        for b in range(nb):
+            ns, nr = int(stot[b]), int(rtot[b])
+            if G > 1 and (ns or nr or not nccl):
+                if ns:
+                    _lib.check(lib.tpnet_pack_bundles(stp, R["pack_ids"].data_ptr() + 8 * int(sstart[b]), ns, now, lam,
+                                                      send.data_ptr(), stream), "pack_bundles")
+                if nccl:
+                    dist.all_to_all_single(recv[:nr], send[:ns], output_split_sizes=rcnt[b].tolist(),
+                                           input_split_sizes=scnt[b].tolist(), group=self.group)
+                else:
+                    padded[:ns].copy_(send[:ns])
+                    dist.all_gather(gathered, padded, group=self.group)
+                    o = 0
+                    for s_ in range(G):                  # rows owner s_ packed for me: after what it packed for readers < me
+                        c = int(rcnt[b][s_])
+                        if c:
+                            a0 = int(all_scnt[s_][b][:me].sum())
+                            recv[o:o + c].copy_(gathered[s_][a0:a0 + c])
+                            o += c
+                if nr:
+                    _lib.check(lib.tpnet_unpack_bundles(stp, R["unpack_ids"].data_ptr() + 8 * int(R["rstart"][b]), nr, now,
+                                                        recv.data_ptr(), nr, zero_off.data_ptr(), 1, stream), "unpack_bundles")
+            _lib.check(lib.tpnet_step_batch(stp, ls.data_ptr(), ld.data_ptr(), ln.data_ptr() if ln is not None else None,
+                                            t.data_ptr(), E, B, b, lam, lid0 + b, flags, 0, self.n_cap, out_pos.data_ptr(),
+                                            out_neg.data_ptr() if out_neg is not None else None, ws.data_ptr(), ws.numel(),
+                                            stream), "step_batch")
+            now = float(t_last[b])
+        rp._now_host = now
+        rp._params_valid = False
+        rp._now_dirty = True
+        if G > 1 and merge_outputs:
+            dist.all_reduce(out_pos, group=self.group)
             if out_neg is not None:
                 dist.all_reduce(out_neg, group=self.group)
         return out_pos, out_neg
