@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: in-kernel phase stamps of ONE k_wupdate launch of the windowed schedule (diagnostic build:
+"""Developer tool (written for the first version of the windowed schedule; the slot layout it decodes has not been re-checked
+against k_wpipe): in-kernel phase stamps of ONE launch of the windowed schedule (diagnostic build:
 make -C tpnet_amd/csrc STAMPS=1).   TPNET_DEV_STAMP_LAYER=2 python tools/wstamps.py [C2]"""
 import os, sys
 import numpy as np, torch
