@@ -229,7 +229,7 @@ def main():
     cfg_run = dict(cfg, B=Bg)
     # the roofline pass (rank 0, N = 1) times the dominant kernel over at least ROOF_STEPS batches: a K = 20 timed region is
     # too short for the schedule long streams run on (see `roofline` below), so the stream is generated that long
-    ROOF_STEPS = 512
+    ROOF_STEPS = 2048
     Kr = max(K, ROOF_STEPS) if world == 1 else K
     src, dst, neg, t, N = make_workload(cfg_run, W + Kr, 0)
     shard = os.environ.get("TPNET_BENCH_SHARD", "rows") if (world > 1 or force_dist) else "single"
