@@ -479,8 +479,9 @@ def main():
                                  "kernel duration + inter-kernel boundary (rocprofv3 per-kernel average: profiles/); measured "
                                  f"over {roof['steps']} steps of the bench stream starting at the timed region"
                                  + (f" (the {K} timed steps alone run the per-batch kernel: timed_region)" if "timed_region" in roof else "")
-                                 + "; the state is cache-resident at this config, so the algorithmic rate can exceed what HBM "
-                                   "itself delivers: see traffic")
+                                 + ("; the state is cache-resident at this config, so the algorithmic rate can exceed what "
+                                    "HBM itself delivers: see traffic / memory_side_frac" if 28.0 * N * d < 256e6 else
+                                    "; the state is far larger than the 256 MB Infinity Cache: row accesses are HBM misses"))
         try:
             cbw = copy_bandwidth_gbs(dev)
             roof["copy_bandwidth_gbs_measured"] = cbw
