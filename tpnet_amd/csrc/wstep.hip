@@ -668,7 +668,9 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     const Geom geo = pick_geom(st.d, geo_env == 1);           // (TPNET_DISPATCH_G declares its own `gm`)
     const int lph = heavy_lph(geo.lpp, geo.vpl);
     const int GPB = WB / geo.lpp;
-    static const int rs_env = getenv("TPNET_DEV_WIN_RSPLIT") ? atoi(getenv("TPNET_DEV_WIN_RSPLIT")) : 0;   // (measured: no gain at C2)
+    // (the readout of rows of 17..32 vectors on 16 lanes x 2 vectors: four pairs per wave, a reduction over 16 lanes.  No gain
+    // with 16 K-edge windows; with 24 K-edge windows and 256 hub workgroups C2 goes 3.40 -> 3.18 us per batch: default on)
+    static const int rs_env = getenv("TPNET_DEV_WIN_RSPLIT") ? atoi(getenv("TPNET_DEV_WIN_RSPLIT")) : 1;
     const bool rsplit = rs_env == 1 && geo.lpp == 32 && geo.vpl == 1 && st.d / 4 > 16;   // rows of 17..32 vectors
     WStep ws;
     ws.CP = (st.d / 4 + lph - 1) / lph;
@@ -686,7 +688,7 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
         ws.seg[i] = nb;
         if (w >= 0 && w < nw) {
             ws.w_upd[i] = w;
-            nb += (uint32_t)(hb_env > 0 ? hb_env : 256);   // (128 -> 256: -7 % on streams with very heavy hubs, nothing lost elsewhere: tools/degree_sensitivity.py)
+            nb += (uint32_t)(hb_env > 0 ? hb_env : 384);   // (four-law sweeps, tools/degree_sensitivity.py: 128 -> 256 -> 384, each step -5..-7 % on streams with heavy hubs, nothing lost elsewhere)
         }
     }
     ws.seg[L] = nb;
