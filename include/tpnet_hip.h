@@ -31,10 +31,11 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 4 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
+#define TPNET_ABI_VERSION 5 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
                                3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream);
                                4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
-                                    (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored */
+                                    (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored;
+                               5: + tpnet_run_stream_tagged / tpnet_plan_tag (a stream's plan replayed across epochs) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -79,8 +80,12 @@ typedef struct tpnet_state {
                                        across GPUs before tpnet_gram_unpack finishes them */
 
 #define TPNET_FLAG_SCHED_WINDOWED 16u /* tpnet_run_stream: take the windowed schedule whenever it applies (>= 4 batches), not
-                                       only for streams long enough for it to pay (>= 56 batches) */
+                                       only for streams long enough for it to pay (>= 28 batches of <= 2048 edges, >= 56 larger
+                                       ones) */
 #define TPNET_FLAG_SCHED_BATCH 32u    /* tpnet_run_stream: one launch per batch, always */
+#define TPNET_FLAG_PLAN_SORTED 64u    /* tpnet_run_stream, windowed schedule: plan every chunk with the chunk planner (two device-wide
+                                       radix sorts) even where the three-launch planner applies (batches of <= 2048 edges, <= 64
+                                       windows per chunk).  Both give the same bits; this one is the slower start-up */
 
 const char* tpnet_strerror(int status);
 int tpnet_abi_version(void);
@@ -231,6 +236,27 @@ int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* d
                      const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                      uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
                      void* workspace, size_t ws_bytes, double* t_end_out, void* stream);
+
+/* The same loop for a stream that is run AGAIN: train_link_prediction.py:234-253 replays the same chronological stream every
+ * epoch (reset_random_projections at the epoch's start, then the same batches), so the plan of the update -- sorted
+ * contributions, chains, version references of src / dst -- is the same every epoch; only the negatives are drawn anew.  A call
+ * that runs the windowed schedule on the whole stream as ONE chunk leaves its plan in the workspace and describes it in
+ * tag->built; a later call with equal arguments, the same workspace and the same two signatures skips the planning and only
+ * resolves the negatives' readout references again (tag->replayed = 1).  The CALLER vouches with the signatures:
+ *   stream_sig: identifies the CONTENTS of src / dst / t (equal value = unchanged arrays; 0 = never replay);
+ *   table_sig:  identifies the table's per-node (current copy, reference time) state before the call -- e.g. one constant
+ *               for "just after tpnet_state_init(t0)" per t0, a fresh value after anything else wrote the state (0 = never).
+ * A caller that lets anything else use the workspace in between clears the tag (memset 0).  tag == NULL: tpnet_run_stream. */
+typedef struct tpnet_plan_tag {
+    uint64_t table_sig;   /* in */
+    uint64_t stream_sig;  /* in */
+    uint64_t replayed;    /* out: 1 = this call reused the plan in the workspace */
+    uint64_t built[20];   /* library-owned description of the plan the workspace holds (zero = none) */
+} tpnet_plan_tag;
+int tpnet_run_stream_tagged(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                            const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                            uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg,
+                            void* workspace, size_t ws_bytes, double* t_end_out, void* stream, tpnet_plan_tag* tag);
 
 /* ---- row-sharded multi-GPU building blocks (one process per GPU; the exchange itself is the caller's RCCL call) ----
  * Rows are owned cyclically: owner(n) = n % G.  Every rank holds the full stream; per batch it (1) packs the

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(hip_lib):
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/tpnet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES.keys()) == syms
-    assert hip_lib.tpnet_abi_version() == 4
+    assert hip_lib.tpnet_abi_version() == 5
     assert hip_lib.tpnet_strerror(-4) == b"node id out of range"
 
 
@@ -187,3 +187,20 @@ def test_fused_feature_applies_only_to_the_reference_mlp():
     assert ff.prepared(torch.nn.Identity(), 64) is None
     assert ff.prepared(mk(64, 256, 64), 64) is None                   # (CPU: not supported, no cache entry)
     assert ff.needs_grad(list(mk(4, 16, 4).parameters())) and not ff.needs_grad([torch.zeros(1)])
+
+
+def test_product_library_has_no_developer_knobs(hip_lib):
+    """Timing / tuning knobs (window length, thresholds, roles switched off ...) exist only in -DTPNET_DEV builds
+    (libtpnet_hip_dev.so): the product library reads no environment variable of its own, and none of the knob names is
+    compiled into it."""
+    from tpnet_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"TPNET_DEV_" not in blob
+    assert b"WIN_SKIP" not in blob and b"ROLE_MASK" not in blob
+
+
+def test_plan_tag_layout(hip_lib):
+    """tpnet_plan_tag as the header declares it: 3 words + 20 library-owned words."""
+    from tpnet_amd import _lib
+    assert ctypes.sizeof(_lib.PlanTag) == 23 * 8
+    assert _lib.PlanTag.built.offset == 24

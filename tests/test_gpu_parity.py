@@ -924,3 +924,87 @@ def test_version_protocol_under_multi_pass_grids(d, B, N):
         _assert_features(outs[0][1][sub].cpu().numpy(), st, src[sub], neg[sub], f"batch {b} neg")
         O.update(st, src[s], dst[s], t[s])
     _assert_state(outs[0][2], np.stack(st.P[1:]), 2e-4, "state")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the three-launch planner (wplan3.hip) and plan replay across epochs
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 400, 64, 50), (64, 2, 3000, 200, 90), (128, 3, 9000, 1000, 20),
+                                        (256, 3, 500, 500, 13), (16, 4, 300, 100, 70), (512, 1, 200, 2048, 5),
+                                        (120, 3, 260, 40, 200), (128, 3, 50, 1000, 12)])
+def test_three_launch_planner_equals_chunk_planner(d, L, N, B, nb):
+    """Both planners of the windowed schedule describe the same runs (blocks of 8 contributions in index order, the same
+    versions read): features and state are equal bit for bit, whatever the window length each picks."""
+    _need_gpu()
+    rng = np.random.RandomState(d + B + nb)
+    E = nb * B - B // 3
+    lam = 2e-6
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    src[5] = N + 3                                               # a bad edge and a bad negative: skipped and counted
+    neg[7] = -2
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    a = _module(N, d, L, lam, t[0], P0=P0)
+    fa, na = a.run_stream(ds, dd, dn, dt, B, schedule="windowed")
+    b = _module(N, d, L, lam, t[0], P0=P0)
+    fb, nb_ = b.run_stream(ds, dd, dn, dt, B, schedule="windowed-sorted")
+    ok = torch.ones(E, dtype=torch.bool, device=DEV)
+    ok[5] = False                                                # (rows of a bad id are not defined)
+    assert torch.equal(fa[ok], fb[ok])
+    ok[7] = False
+    assert torch.equal(na[ok], nb_[ok])
+    np.testing.assert_array_equal(_layers(a), _layers(b))
+    for m in (a, b):
+        with pytest.raises(IndexError):
+            m.check_device_errors()
+
+
+@pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 400, 64, 50), (64, 2, 3000, 200, 30), (128, 3, 9000, 1000, 20)])
+def test_plan_replay_across_epochs(d, L, N, B, nb):
+    """train_link_prediction.py:234-253: every epoch resets the projections and runs the SAME stream with new negatives.
+    The second epoch replays the first one's plan (only the negatives' readout references are formed again) and gives the
+    bits a cold plan gives; anything that invalidates the plan (an in-place write to the stream, another use of the
+    workspace, a different table state) is noticed."""
+    _need_gpu()
+    rng = np.random.RandomState(d + B + nb)
+    E = nb * B - B // 3
+    lam = 2e-6
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    neg2 = rng.randint(0, N, E).astype(np.int64)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dn2, dt = dev(src), dev(dst), dev(neg), dev(neg2), dev(t)
+
+    def epoch(rp, negs, **kw):
+        rp.reset_random_projections()
+        rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+        fp, fn = rp.run_stream(ds, dd, negs, dt, B, schedule="windowed", **kw)
+        return fp.clone(), fn.clone(), _layers(rp), rp.last_stream_replayed
+
+    cold = _module(N, d, L, lam, t[0], P0=P0)
+    c1 = epoch(cold, dn, replay=False)
+    c2_ = epoch(cold, dn2, replay=False)
+    assert not c1[3] and not c2_[3]
+    rp = _module(N, d, L, lam, t[0], P0=P0)
+    e1 = epoch(rp, dn)
+    e2 = epoch(rp, dn2)
+    e3 = epoch(rp, dn)
+    assert not e1[3] and e2[3] and e3[3]
+    for got, want in ((e1, c1), (e2, c2_), (e3, c1)):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        np.testing.assert_array_equal(got[2], want[2])
+    # an in-place write to the stream is seen (torch bumps _version) ...
+    dd[3] = dd[3]
+    assert not epoch(rp, dn)[3]
+    assert epoch(rp, dn)[3]
+    # ... so is another user of the workspace (update() plans in it) ...
+    rp.reset_random_projections()
+    rp.update(src[:B], dst[:B], t[:B])
+    assert not epoch(rp, dn)[3]
+    # ... and a table that is not in the state the plan was built for (no reset: the second call continues the first)
+    rp.run_stream(ds, dd, dn, dt + (t[-1] - t[0] + 1.0), B, schedule="windowed")
+    assert not rp.last_stream_replayed
+    e4 = epoch(rp, dn)
+    assert torch.equal(e4[0], c1[0]) and torch.equal(e4[1], c1[1])
+    np.testing.assert_array_equal(e4[2], c1[2])

@@ -16,6 +16,7 @@ FLAG_SEQUENTIAL = 4
 FLAG_PACKED = 8
 FLAG_SCHED_WINDOWED = 16
 FLAG_SCHED_BATCH = 32
+FLAG_PLAN_SORTED = 64
 
 ERR_INDEX = -4
 
@@ -27,6 +28,11 @@ class NodeMeta(C.Structure):
 class State(C.Structure):
     _fields_ = [("p0", C.c_void_p), ("q", C.c_void_p), ("meta", C.c_void_p), ("N", C.c_int64), ("d", C.c_int32),
                 ("L", C.c_int32), ("err", C.c_void_p)]
+
+
+class PlanTag(C.Structure):
+    """tpnet_plan_tag: what lets tpnet_run_stream_tagged replay the plan a stream left in the workspace (include/tpnet_hip.h)."""
+    _fields_ = [("table_sig", C.c_uint64), ("stream_sig", C.c_uint64), ("replayed", C.c_uint64), ("built", C.c_uint64 * 20)]
 
 
 class Mlp(C.Structure):
@@ -61,6 +67,8 @@ SIGNATURES = {
                                C.c_size_t, _P]),
     "tpnet_run_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                    C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(C.c_double), _P]),
+    "tpnet_run_stream_tagged": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
+                                          C.c_uint32, _P, _P, _P, C.c_size_t, C.POINTER(C.c_double), _P, C.POINTER(PlanTag)]),
     "tpnet_plan_stream": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P,
                                     C.c_size_t, _P]),
     "tpnet_step_batch": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_uint32,

@@ -3,6 +3,7 @@
 #include "tpnet_common.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace tpnet {
@@ -29,12 +30,6 @@ static int64_t max_chunk(size_t ws_bytes, int64_t E, int64_t batch) {
     return lo * batch;
 }
 
-// developer knobs for kernel experiments (never set in tests or bench.py)
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 struct StepTimer {
     hipEvent_t* ev = nullptr;  // one pair per chunk, around its loop of step launches (plan kernels excluded)
     int64_t n = 0, cap = 0;    // pairs recorded / available
@@ -50,18 +45,22 @@ struct StepTimer {
 // The windowed path (wstep.hip) serves a stream when its arithmetic contract allows it (no eager decay / strictly
 // sequential sums: those are the per-batch kernels' exact mode), the rows take 16-byte vectors, there are enough batches
 // for a window to pay, and the caller's workspace holds the plan of at least one window.  Returns the chunk (edges per
-// plan: whole windows of K batches, or all of E) and K; 0 = use the per-batch path.
+// plan: whole windows of Kmax batches, or all of E) and Kmax; 0 = use the per-batch path.
 static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, int64_t batch, uint32_t flags, int* K_out) {
     if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL | TPNET_FLAG_SCHED_BATCH)) return 0;
     const int K = wplan_window_batches(batch, st.d, st.L);
     const int64_t nb = (E + batch - 1) / batch;
-    // short streams: the windowed schedule pays ~250 us up front (two sorts, L + 1 dependent launches of >= 35 us to fill the
-    // pipeline) and ~3.3 us per batch at C2, the per-batch one ~50 us and ~6.7 us: measured crossover between 40 batches
-    // (309 against 380 us) and 60 (438 against 430 us)
-    static const int min_nb = env_int("TPNET_DEV_WIN_MIN_BATCHES", 56);
+    // short streams: with the three-launch planner (wplan3.hip; batches of <= 2 048 edges) the pipeline pays ~70 us of planning
+    // and L + 1 dependent launches up front, the per-batch schedule ~20 us and ~6.6 us per batch (C2): the pipeline wins from
+    // about 28 batches (tools/short_sweep.py: 20 batches 210 against 180 us, 40 batches 277 against 312 us).  Larger batches keep the chunk planner's crossover (two device-wide sorts).
+    static const int min_nb3 = TPNET_DEV_INT(WIN_MIN_BATCHES, 28);
+    const int min_nb = batch <= PLAN_ONE_MAX ? min_nb3 : 56;
     if (K == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
     *K_out = K;
-    const int64_t Ew = (int64_t)K * batch;
+    int64_t Ew = (int64_t)K * batch;
+    // packed rows of (2L+2)(2L+3)/2 floats: every chunk's output must start on a 16-byte boundary (launch_wstep)
+    const int NN = 2 * st.L + 2;
+    if ((flags & TPNET_FLAG_PACKED) && ((NN * (NN + 1) / 2) % 4) != 0 && Ew % 4 != 0) Ew *= (Ew % 2 == 0) ? 2 : 4;
     const int64_t cap = wplan_max_chunk_edges(batch, st.d, st.L);          // the version log of a chunk is bounded
     const int64_t hard = cap / Ew * Ew;
     const int64_t lim = (E <= cap) ? E : hard;
@@ -75,26 +74,76 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     return lo * Ew;
 }
 
+// Batches per window of a chunk of nb batches.  A pipeline of nw windows is nw + L dependent launches, each a fixed floor
+// (~10 us: kernel boundary + the dependent loads of its longest unit) plus its share of the bandwidth work (~2.5 us per batch
+// at C2): few long windows for short streams.  Measured (tools/short_trace.sh, sum of the pipeline launches): 20 batches as
+// 1 / 2 / 4 windows 127 / 85 / 110 us; 158 batches at 12 / 16 / 24 per window 493 / 472 / 450 us; long streams: the cap of 24
+// (tools/degree_sensitivity.py).
+static int window_batches_for(int64_t nb, int Kmax) {
+    static const int fixed = TPNET_DEV_INT(WINDOW_FIXED, 0);
+    if (fixed > 0) return fixed < Kmax ? fixed : Kmax;
+    static const int num = TPNET_DEV_INT(WINDOW_SQ, 5);
+    int K = 2;
+    while (K < Kmax && (int64_t)K * K < (int64_t)num * nb) ++K;         // K = ceil(sqrt(5 nb))
+    const int64_t nw0 = (nb + K - 1) / K;                              // equal windows: ceil(nb / nw0) batches each
+    return (int)((nb + nw0 - 1) / nw0);
+}
+
+// what a plan left in the workspace was built for (tpnet_plan_tag::built, opaque to the caller)
+struct PlanBuilt {
+    uint64_t valid;
+    const void *src, *dst, *t, *ws;
+    int64_t E, batch, N;
+    uint64_t ws_bytes;
+    double now_time, lambda;
+    int32_t d, L, K;
+    uint32_t flags;
+    uint64_t table_sig, stream_sig;
+    uint64_t have_readout;
+};
+static_assert(sizeof(PlanBuilt) <= sizeof(((tpnet_plan_tag*)nullptr)->built), "tpnet_plan_tag::built too small");
+
 static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                                const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                                uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* ws,
-                               size_t ws_bytes, int64_t chunk, int Kmax, hipStream_t s, StepTimer* timer) {
+                               size_t ws_bytes, int64_t chunk, int Kmax, hipStream_t s, StepTimer* timer,
+                               tpnet_plan_tag* tag) {
     const int NN = 2 * st.L + 2;
     const int NG = (flags & TPNET_FLAG_PACKED) ? NN * (NN + 1) / 2 : NN * NN;
     uint32_t lid = launch_id_base;
     for (int64_t c0 = 0; c0 < E; c0 += chunk, ++lid) {
         const int64_t Ec = (E - c0 < chunk) ? (E - c0) : chunk;
-        // windows of equal length: a chunk of nb batches is cut into ceil(nb / Kmax) windows of ceil(nb / that) batches
         const int64_t nb = (Ec + batch - 1) / batch;
-        const int64_t nw0 = (nb + Kmax - 1) / Kmax;
-        const int K = (int)((nb + nw0 - 1) / nw0);
+        const int K = window_batches_for(nb, Kmax);
         WPlan p{};
         int rc = wplan_carve(ws, ws_bytes, Ec, batch, st.N, st.d, st.L, K, &p);
         if (rc) return rc;
         const bool have_readout = out_pos || out_neg;
-        rc = wplan_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
-                         c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, s);
+        static const int no3 = TPNET_DEV_INT(NO_PLAN3, 0);
+        const bool plan3 = !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && wplan3_applies(st, Ec, batch, K);
+        // a plan may be replayed when the whole stream is ONE chunk and the caller vouches (tag) that the stream arrays and
+        // the table's per-node state are what the plan in this workspace was built for
+        PlanBuilt now{};
+        bool replay = false;
+        if (tag && plan3 && Ec == E && tag->table_sig && tag->stream_sig) {
+            now.valid = 1; now.src = src; now.dst = dst; now.t = t; now.ws = ws; now.E = E; now.batch = batch; now.N = st.N;
+            now.ws_bytes = ws_bytes; now.now_time = now_time; now.lambda = lambda; now.d = st.d; now.L = st.L; now.K = K;
+            now.flags = flags & ~(uint32_t)TPNET_FLAG_SCHED_WINDOWED;
+            now.table_sig = tag->table_sig; now.stream_sig = tag->stream_sig; now.have_readout = have_readout ? 1 : 0;
+            replay = memcmp(&now, tag->built, sizeof(PlanBuilt)) == 0;
+        }
+        if (tag) {
+            memset(tag->built, 0, sizeof(tag->built));                  // (invalid unless this call completes its plan)
+            tag->replayed = replay ? 1 : 0;
+        }
+        if (plan3)
+            rc = wplan3_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
+                              c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, replay, s);
+        else
+            rc = wplan_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
+                             c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, s);
         if (rc) return rc;
+        if (now.valid) memcpy(tag->built, &now, sizeof(PlanBuilt));
         StreamArgs a;
         a.src = src + c0;
         a.dst = dst + c0;
@@ -128,15 +177,16 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
 static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int64_t* dst, const int64_t* neg,
                            const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                            uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* ws,
-                           size_t ws_bytes, hipStream_t s, StepTimer* timer) {
+                           size_t ws_bytes, hipStream_t s, StepTimer* timer, tpnet_plan_tag* tag = nullptr) {
     if (E == 0) return TPNET_OK;
     {
         int Kw = 0;
         const int64_t wchunk = window_chunk(st, ws_bytes, E, batch, flags, &Kw);
         if (wchunk > 0)
             return run_stream_windowed(st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos,
-                                       out_neg, ws, ws_bytes, wchunk, Kw, s, timer);
+                                       out_neg, ws, ws_bytes, wchunk, Kw, s, timer, tag);
     }
+    if (tag) { memset(tag->built, 0, sizeof(tag->built)); tag->replayed = 0; }   // (the per-batch planner overwrites the workspace)
     const int64_t chunk = max_chunk(ws_bytes, E, batch);
     if (chunk < 1) return TPNET_ERR_WORKSPACE;
     const int NN = 2 * st.L + 2;
@@ -149,8 +199,8 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
         if (rc) return rc;
         // edge-fused updates: every launch of this chunk must run BOTH roles with the (src,dst) readout on, and the sums
         // must not be order-sensitive by contract; worth it where the batch is bound by bytes, not by its longest chain
-        static const int fuse_env = env_int("TPNET_DEV_FUSE", -1);       // developer override: 0 / 1
-        static const int role_mask0 = env_int("TPNET_DEV_ROLE_MASK", 3);
+        static const int fuse_env = TPNET_DEV_INT(FUSE, -1);       // developer override: 0 / 1
+        static const int role_mask0 = TPNET_DEV_INT(ROLE_MASK, 3);
         const bool fuse = out_pos && p.fuse_src && role_mask0 == 3 &&
                           !(flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL)) &&
                           (fuse_env >= 0 ? fuse_env == 1 : batch > 1024);
@@ -184,7 +234,7 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
                 rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | ROLE_UPDATE, s);
                 if (rc) return rc;
             } else {
-                static const int role_mask = env_int("TPNET_DEV_ROLE_MASK", 3);
+                static const int role_mask = TPNET_DEV_INT(ROLE_MASK, 3);
                 const uint32_t roles = ((role_mask & 2) ? ROLE_UPDATE : 0u) |
                                        ((have_readout && (role_mask & 1)) ? ROLE_READOUT : 0u);
                 rc = launch_step(st, a, p, b, batch, ne, lambda, lid, flags | roles | (fuse ? STEP_FUSE : 0u), s);
@@ -373,6 +423,26 @@ int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* d
     if (launch_id_base == 0 || (uint64_t)launch_id_base + (uint64_t)nb >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
     rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos, out_neg,
                          workspace, ws_bytes, (hipStream_t)stream, nullptr);
+    if (rc) return rc;
+    if (t_end_out && E > 0) {
+        TPNET_HIP_TRY(hipMemcpyAsync(t_end_out, t + E - 1, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));
+        TPNET_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return TPNET_OK;
+}
+
+int tpnet_run_stream_tagged(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                            const double* t, int64_t E, int64_t batch, double now_time, double lambda,
+                            uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* workspace,
+                            size_t ws_bytes, double* t_end_out, void* stream, tpnet_plan_tag* tag) {
+    int rc = check_state(st);
+    if (rc) return rc;
+    if (E < 0 || batch < 1 || (E > 0 && (!src || !dst || !t))) return TPNET_ERR_BAD_ARG;
+    if (out_neg && !neg) return TPNET_ERR_BAD_ARG;
+    const int64_t nb = (E + batch - 1) / batch;
+    if (launch_id_base == 0 || (uint64_t)launch_id_base + (uint64_t)nb >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
+    rc = run_stream_impl(*st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos, out_neg,
+                         workspace, ws_bytes, (hipStream_t)stream, nullptr, tag);
     if (rc) return rc;
     if (t_end_out && E > 0) {
         TPNET_HIP_TRY(hipMemcpyAsync(t_end_out, t + E - 1, sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream));

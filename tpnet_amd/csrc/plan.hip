@@ -37,7 +37,7 @@ struct SegOffset {   // offset of segment boundary (i + shift): begin iterator =
     }
 };
 static bool use_segmented_sort(int64_t batch, size_t nc) {
-    static const char* env = getenv("TPNET_DEV_SEGSORT");       // developer override: "0" / "1"
+    static const char* env = TPNET_DEV_STR(SEGSORT);       // developer override: "0" / "1"
     if (nc >= (1ull << 32)) return false;
     if (env) return env[0] == '1';
     return 2 * batch <= SEGSORT_MAX_KEYS;
@@ -303,7 +303,7 @@ __global__ void k_finish(Plan p, const K* __restrict__ keys_out, const int64_t* 
 }
 
 static uint32_t heavy_threshold_for(int64_t batch, uint32_t flags) {
-    static const char* thr_env = getenv("TPNET_DEV_HEAVY_THRESHOLD");
+    static const char* thr_env = TPNET_DEV_STR(HEAVY_THRESHOLD);
     uint32_t thr = (uint32_t)(batch / 300);
     thr = thr < HEAVY_THRESHOLD ? HEAVY_THRESHOLD : (thr > 128u ? 128u : thr);
     if (thr_env) thr = (uint32_t)atoi(thr_env);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
 }
 
 int64_t plan_one_max_batch() {
-    static const int off = getenv("TPNET_DEV_NO_PLAN_ONE") ? 1 : 0;     // developer override: always the chunk planner
+    static const int off = TPNET_DEV_STR(NO_PLAN_ONE) ? 1 : 0;     // developer override: always the chunk planner
     return off ? 0 : PLAN_ONE_MAX;
 }
 
@@ -484,7 +484,7 @@ int plan_blocks(const tpnet_state& st, const Plan& p, const int64_t* src, const 
     const int node_bits = ceil_log2_u64((uint64_t)st.N) < 1 ? 1 : ceil_log2_u64((uint64_t)st.N);
     if (node_bits > 31) return TPNET_ERR_BAD_ARG;
     const uint32_t thr = heavy_threshold_for(B, flags);
-    static const int bs_env = getenv("TPNET_DEV_PLAN_ONE_BS") ? atoi(getenv("TPNET_DEV_PLAN_ONE_BS")) : 0;   // developer override
+    static const int bs_env = TPNET_DEV_INT(PLAN_ONE_BS, 0);   // developer override
 #define TPNET_PLAN_ONE(BS_, IPT_)                                                                                         \
     hipLaunchKernelGGL((k_plan_one<BS_, IPT_>), dim3((unsigned)nbl), dim3(BS_), 0, s, p, src, dst, t, Ec, (int32_t)B, st.N,   \
                        node_bits, now_time, t_prev_dev, lambda, (int)st.L, thr, st.err)
@@ -578,7 +578,7 @@ int plan_build(const tpnet_state& st, const Plan& p, const int64_t* src, const i
 //   * the list of every node's last run in the chunk (what the write-back copies to the table).
 // =====================================================================================================================
 int wplan_window_batches(int64_t batch, int d, int L) {
-    static const char* env = getenv("TPNET_DEV_WINDOW");       // developer override: 0 = off, n = batches per window
+    static const char* env = TPNET_DEV_STR(WINDOW);       // developer override: 0 = off, n = batches per window
     (void)L;
     if (d % 4 != 0 || d < 4 || batch < 1) return 0;             // scalar-load rows (use_matrix, odd d) keep the per-batch path
     if (batch > 4096) return 0;                                 // such batches are bandwidth-bound one launch at a time already
@@ -588,8 +588,19 @@ int wplan_window_batches(int64_t batch, int d, int L) {
     return K >= 2 ? (int)K : 0;
 }
 
+// Contributions per (node, window) above which a workgroup per column part walks the chain instead of one lane group: a lane
+// group keeps 8 rows in flight, so a chain of n contributions is n / 8 dependent memory round trips -- the latency floor of a
+// launch, which has to stay below the launch's bandwidth time, i.e. scale with the window (measured, tools/short_trace.sh:
+// 20 batches in 2 windows of 10 -> pipeline 127 us at 96, 85 us at 32; 24-batch windows of long streams: 96 as before).
+uint32_t wplan_heavy_threshold(int K) {
+    static const int env = TPNET_DEV_INT(WIN_HEAVY, 0);
+    if (env > 0) return (uint32_t)env;
+    const int t = 4 * K;
+    return (uint32_t)(t < 16 ? 16 : (t > 96 ? 96 : t));
+}
+
 int64_t wplan_max_chunk_edges(int64_t batch, int d, int L) {
-    static const char* env = getenv("TPNET_DEV_WIN_CHUNK_MB");
+    static const char* env = TPNET_DEV_STR(WIN_CHUNK_MB);
     const int64_t log_cap = (env ? (int64_t)atoi(env) : 4096) << 20;         // bytes of version log per chunk (C2: 1 GiB 4.6 us per batch, 4 GiB 4.1: fewer pipeline drains)
     int64_t e = log_cap / (2 * (int64_t)L * d * 4);
     const int64_t hard = (int64_t)(WREF_SLOT_MASK >> 1);                     // slots are 26-bit sorted positions
@@ -601,8 +612,8 @@ int64_t wplan_max_chunk_edges(int64_t batch, int d, int L) {
 
 static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int L, int K) {
     const size_t nc = 2 * (size_t)Ec;
-    const int64_t Ew = (int64_t)K * batch;
-    const size_t nw = (size_t)((Ec + Ew - 1) / Ew);
+    (void)K;
+    const size_t nw = (size_t)((Ec + batch - 1) / batch);       // (room for windows of ONE batch: the window length is chosen per chunk)
     size_t tot = 0;
     tot += align_up(nc * 4, 256) * 3;                           // s_ref, s_g, s_dec
     tot += align_up(nc * 2, 256);                               // s_bc
@@ -611,6 +622,8 @@ static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int
     tot += align_up(nc * (size_t)L * (size_t)d * 4, 256);       // version log
     tot += align_up((size_t)N * 4, 256) * 2;                    // node_lo, node_hi
     tot += align_up(nc * 4, 256) * 2;                           // inv, rhead
+    tot += align_up((size_t)N * 8, 256) + align_up((2 * WIN_MAX_WINDOWS * 8 + WIN_MAX_WINDOWS) * 4, 256) +
+           align_up(wplan3_table_bytes(Ec), 256) + align_up(wplan3_blk_bytes(Ec, batch), 256);   // wmask, wcls, wtab, wblk (hashed planner, wplan3.hip)
     return tot + 256;
 }
 
@@ -638,7 +651,7 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
     };
     const size_t nc = 2 * (size_t)Ec;
     const int64_t Ew = (int64_t)K * batch;
-    const size_t nw = (size_t)((Ec + Ew - 1) / Ew);
+    const size_t nw = (size_t)((Ec + batch - 1) / batch);
     out->s_ref = (uint32_t*)take(nc * 4);
     out->s_g = (float*)take(nc * 4);
     out->s_dec = (float*)take(nc * 4);
@@ -652,6 +665,12 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
     out->node_hi = (uint32_t*)take((size_t)N * 4);
     out->inv = (uint32_t*)take(nc * 4);
     out->rhead = (uint32_t*)take(nc * 4);
+    out->wmask = (unsigned long long*)take((size_t)N * 8);
+    out->wcls = (uint32_t*)take((2 * WIN_MAX_WINDOWS * 8 + WIN_MAX_WINDOWS) * 4);
+    out->wtab = take(wplan3_table_bytes(Ec));
+    out->wzero_bytes = (size_t)(p - reinterpret_cast<char*>(out->wmask));
+    out->wblk = (uint32_t*)take(wplan3_blk_bytes(Ec, batch));
+    out->heavy_thr = wplan_heavy_threshold(K);
     out->chains = reinterpret_cast<Chain*>(out->base.light);
     out->chains_sparse = reinterpret_cast<Chain*>(out->base.heavy);
     // the second sort's keys live where the first sort's unsorted keys were (8 bytes per contribution, dead by then), its
@@ -1011,8 +1030,7 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
                                                 p.base.vals_out, (size_t)nc, 0u, (unsigned)key_bits, s, false));
     }
     TPNET_HIP_TRY(hipGetLastError());
-    static const char* thr_env = getenv("TPNET_DEV_WIN_HEAVY");
-    const uint32_t thr = thr_env ? (uint32_t)atoi(thr_env) : 96u;   // contributions per (node, window) above which a workgroup per column part walks the chain
+    const uint32_t thr = p.heavy_thr;   // contributions per (node, window) above which a workgroup per column part walks the chain
     const int egrid = (int)(((want_readout ? 3 : 0) * Ec + 255) / 256) > 4096 ? 4096 : (int)(((want_readout ? 3 : 0) * Ec + 255) / 256);
     const int win_bits = ceil_log2_u64((uint64_t)nw + 1) < 1 ? 1 : ceil_log2_u64((uint64_t)nw + 1);
     if (win_bits + 9 > 31) return TPNET_ERR_BAD_ARG;

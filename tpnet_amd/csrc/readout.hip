@@ -123,7 +123,7 @@ int launch_pair_gram_anchored(const tpnet_state& st, const int64_t* neigh, const
     if (!pair_gram_anchored_supported(st)) return TPNET_ERR_BAD_ARG;
     TPNET_DISPATCH(({
         if constexpr (FULL && LPP >= 16) {
-            static const int kc_env = getenv("TPNET_DEV_ANCHOR_KC") ? atoi(getenv("TPNET_DEV_ANCHOR_KC")) : 0;
+            static const int kc_env = TPNET_DEV_INT(ANCHOR_KC, 0);
             int64_t kc = ((int64_t)K * n_rows + 8191) / 8192;            // >= ~8192 units in the launch
             kc = kc < 4 ? 4 : (kc > K ? K : kc);
             if (kc_env > 0) kc = kc_env > K ? K : kc_env;

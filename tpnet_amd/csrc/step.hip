@@ -19,7 +19,7 @@ int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64
     // 40 hub-layer units of up to ~1000 edges (see BLOCK_SMALL in device_common.hpp for the measurements; just above
     // that the 512-thread kernel falls off a cliff: d=128, B=1100 takes 9.3 us against 7.5 us) -- and 256-thread ones
     // for everything larger and for tiny batches
-    static const char* env = getenv("TPNET_DEV_BLOCK");                  // developer override: "256" / "512"
+    static const char* env = TPNET_DEV_STR(BLOCK);                  // developer override: "256" / "512"
     const bool small_wg = env ? env[0] == '2' : (ne > 1024 || ne < 400);
     return small_wg ? launch_step_bs<BLOCK_SMALL, false>(st, a, p, b, batch, ne, lambda, launch_id, flags, s)
                     : launch_step_bs<BLOCK, false>(st, a, p, b, batch, ne, lambda, launch_id, flags, s);

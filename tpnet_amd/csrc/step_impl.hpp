@@ -238,7 +238,7 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         constexpr int GPB = BS / LPP;
         constexpr int ISL = (LPP < 16 && W == 4) ? 16 / LPP : 1;
         static const int resident = resident_blocks(k_step<LPP, VPL, W, L, FULL, false, BS, FUSE>, BS);
-        static const int hb_env = getenv("TPNET_DEV_HEAVY_BLOCKS") ? atoi(getenv("TPNET_DEV_HEAVY_BLOCKS")) : 0;
+        static const int hb_env = TPNET_DEV_INT(HEAVY_BLOCKS, 0);
         const int HEAVY_BLOCKS = hb_env > 0 ? hb_env : (ne <= 1024 ? HEAVY_BLOCKS_SMALL : HEAVY_BLOCKS_LARGE);
         // One pass when it fits: 2*ne readout pairs + up to 2*ne distinct targets.  A small batch is bound by its
         // chain of dependent memory round trips, so every workgroup should be resident at once (a workgroup that
@@ -250,14 +250,14 @@ int launch_step_bs(const tpnet_state& st, const StreamArgs& a, const Plan& p, in
         const int item_min = grid_for((((int64_t)ne * 3) / 4 + 1) * ISL, GPB, 1 << 20);
         if (item_blocks > room) item_blocks = room > item_min ? room : item_min;
         int grid = HEAVY_BLOCKS + pair_blocks + item_blocks;
-        static const int cap_env = getenv("TPNET_DEV_GRID_CAP") ? atoi(getenv("TPNET_DEV_GRID_CAP")) : 0;
+        static const int cap_env = TPNET_DEV_INT(GRID_CAP, 0);
         const int GRID_CAP = cap_env > 0 ? cap_env : 256 * 8;
         if (grid > HEAVY_BLOCKS + GRID_CAP) grid = HEAVY_BLOCKS + GRID_CAP;
         // streamed state stores for mid-size batches on the two geometries that serve them (see stv)
-        static const char* nt_env = getenv("TPNET_DEV_NT_STATE");          // developer override: "0" / "1"
+        static const char* nt_env = TPNET_DEV_STR(NT_STATE);          // developer override: "0" / "1"
         constexpr bool NT_GEOM = BS == BLOCK && W == 4 && VPL == 1 && (LPP == 16 || LPP == 32);
         const bool nt_state = NT_GEOM && (nt_env ? nt_env[0] == '1' : (ne >= 512 && ne <= 2048));
-        static const char* if_env = getenv("TPNET_DEV_ITEMS_FIRST");        // developer override: "0" / "1"
+        static const char* if_env = TPNET_DEV_STR(ITEMS_FIRST);        // developer override: "0" / "1"
         const bool items_first = FUSE && (flags & ROLE_UPDATE) && (flags & ROLE_READOUT) && (if_env ? if_env[0] == '1' : ne > 1024);
         const uint32_t kflags = flags | (items_first ? STEP_ITEMS_FIRST : 0u) | (a.out_pos ? STEP_HAS_POS : 0u) |
                                 (a.out_neg ? STEP_HAS_NEG : 0u);

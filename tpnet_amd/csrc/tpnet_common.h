@@ -6,6 +6,18 @@
 #include "../../include/tpnet_hip.h"
 #include "tpnet_dev.h"
 
+// Developer knobs (window length, thresholds, roles switched off for timing experiments ...) exist only in builds made with
+// -DTPNET_DEV (make VARIANT=dev VARFLAGS=-DTPNET_DEV -> libtpnet_hip_dev.so, loaded through TPNET_DEV_LIB by tools/): the product
+// library never reads the environment, and none of the knob names is compiled into it (tests/test_abi.py checks).
+#ifdef TPNET_DEV
+static inline int tpnet_dev_env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#define TPNET_DEV_INT(NAME, DFLT) tpnet_dev_env_int("TPNET_DEV_" #NAME, (DFLT))
+#define TPNET_DEV_STR(NAME) getenv("TPNET_DEV_" #NAME)
+#else
+#define TPNET_DEV_INT(NAME, DFLT) (DFLT)
+#define TPNET_DEV_STR(NAME) ((const char*)nullptr)
+#endif
+
 namespace tpnet {
 
 // ---- per-node record, 32 bytes: {ver, pad, tref[2], pad} ---------------------------------------------------
@@ -93,7 +105,7 @@ struct Geom {
 inline Geom pick_geom(int d, bool many = false) {
     if (d % 4 != 0) return {64, 1, 1};
     const int nvec = d / 4;
-    static const char* g0 = getenv("TPNET_DEV_GEOM");
+    static const char* g0 = TPNET_DEV_STR(GEOM);
     if (g0 && g0[0] == '1' && g0[3] == '2' && nvec <= 32) return {16, 2, 4};   // developer override "16x2"
     if (many && nvec > 16 && nvec <= 32) return {16, 2, 4};
     // narrow rows (the column slices of a dim-sharded table, tpnet_amd/sharded.py): 4 / 8 lanes per row, so that a wave
@@ -102,7 +114,7 @@ inline Geom pick_geom(int d, bool many = false) {
     if (nvec <= 8) return {8, 1, 4};
     if (nvec <= 16) return {16, 1, 4};
     if (nvec <= 32) return {32, 1, 4};
-    static const char* g = getenv("TPNET_DEV_GEOM");          // developer override: "64x1", "64x2", "32x2"
+    static const char* g = TPNET_DEV_STR(GEOM);          // developer override: "64x1", "64x2", "32x2"
     if (g && g[0] == '6' && g[3] == '1' && nvec <= 64) return {64, 1, 4};
     if (g && g[0] == '6') return {64, nvec <= 64 ? 1 : 2, 4};
     if (g && g[0] == '3') return {32, 2, 4};
@@ -198,8 +210,17 @@ static constexpr uint32_t WREF_BLK_HEAD = 1u << 28; // first / last contribution
 static constexpr uint32_t WREF_BLK_TAIL = 1u << 27;
 static constexpr uint32_t WREF_LAST_RUN = 1u << 26; // the run is its node's last one in the chunk: the write-back copies it to the table
 static constexpr uint32_t WREF_SLOT_MASK = (1u << 26) - 1;   // bits 25..0: log slot (= chunk-relative sorted position of a run's tail)
+static constexpr int WIN_MAX_WINDOWS = 64;          // windows per chunk of the three-launch planner (wplan3.hip: a 64-bit mask per node)
 static constexpr int WIN_BLOCK = 8;                 // contributions summed on their own before they join the row (fixed
                                                     // association: the result of a run does not depend on who sums it)
+
+// length class of a chain inside its window's list (wplan3.hip): 0 = walked by a workgroup per column part (more than
+// `thr` contributions), then classes of halving length -- a block's chains are alike, the long ones lead
+__host__ __device__ inline int wchain_class(uint32_t cnt, uint32_t thr) {
+    if (cnt > thr) return 0;
+    const int dl = (32 - __builtin_clz(thr | 1u)) - (32 - __builtin_clz(cnt | 1u));
+    return 1 + (dl > 6 ? 6 : (dl < 0 ? 0 : dl));
+}
 
 struct WinDesc {          // per window: its slice of the chain list (sorted by decreasing length: the plan's second sort)
     uint32_t start;       // first chain of the window in WPlan::chains
@@ -238,6 +259,12 @@ struct WPlan {
     uint32_t* node_hi;
     uint32_t* inv;        // [2*Ec] pre-sort index of a contribution -> its sorted position
     uint32_t* rhead;      // [2*Ec] sorted position -> first position of its (node, batch) run
+    unsigned long long* wmask;   // [N] hashed planner (wplan3.hip): bit w = the node is a target in window w of the chunk
+    uint32_t* wcls;       // [2][WIN_MAX_WINDOWS][8] chains per (window, length class); placement cursors; then [WIN_MAX_WINDOWS] position cursors
+    void* wtab;           // two open-addressing tables of wplan3_table_bytes(Ec) bytes in all
+    size_t wzero_bytes;   // wmask, wcls and wtab are contiguous: what one fill has to zero before a plan
+    uint32_t* wblk;       // per-workgroup counts / bases of the hashed planner (wplan3_blk_bytes)
+    uint32_t heavy_thr;   // contributions per (node, window) above which a workgroup per column part walks the chain
     int32_t K;            // batches per window
     int64_t Ew;           // edges per full window = K * batch
 };
@@ -249,6 +276,16 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
 int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                 const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
                 bool want_readout, hipStream_t s);
+// the same plan without a device-wide sort (wplan3.hip: one fill + three kernels) for batches that fit one workgroup's LDS and chunks of <= 64 windows;
+// replay = the workspace still holds this plan of the SAME stream on the SAME table state: only the negatives' readout
+// references are formed again
+bool wplan3_applies(const tpnet_state& st, int64_t Ec, int64_t batch, int K);
+size_t wplan3_table_bytes(int64_t Ec);
+size_t wplan3_blk_bytes(int64_t Ec, int64_t batch);
+int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                 const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
+                 bool want_readout, bool replay, hipStream_t s);
+uint32_t wplan_heavy_threshold(int K);
 // pipeline step j of a chunk of nw windows: layer i of window j-i+1 (i = 1..L) and the readout of window j-L, whichever
 // exist, in ONE launch; j = 0 .. nw+L-1.
 int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t j, int64_t Ec, int64_t batch,

@@ -517,7 +517,9 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
 #endif
 
     if (sidx == L + 1) {
+#ifdef TPNET_DEV
         if (st.dbg_skip & 4) return;
+#endif
         // ---- readouts of window w_read: (src,dst) and (src,neg) of every edge on the state BEFORE the edge's batch
         constexpr int NR = C::NR, NN = C::NN;
         constexpr int RGPB = WB / RLPP;
@@ -577,7 +579,9 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
     unsigned long long* dbg = (st.dbg_layer == layer) ? P.base.dbg : nullptr;   // stamps of diagnostic builds (-DTPNET_STAMPS)
     (void)dbg;
     if (sidx < L) {
+#ifdef TPNET_DEV
         if (st.dbg_skip & 1) return;
+#endif
         const Chain* __restrict__ heavy = P.chains + wd.start;         // the window's longest chains
         const uint32_t units = wd.n_heavy * (uint32_t)st.CP;
         for (uint32_t h = rb; h < units; h += nblk)
@@ -586,7 +590,9 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
         BEND();
         return;
     }
+#ifdef TPNET_DEV
     if (st.dbg_skip & 2) return;
+#endif
     const Chain* __restrict__ small = P.chains + wd.start + wd.n_heavy;   // the others, longest first: a block's chains are alike
     const int64_t n_small = (int64_t)wd.n_chains - (int64_t)wd.n_heavy;
     for (int64_t base = (int64_t)rb * GPB; base < n_small; base += (int64_t)nblk * GPB) {
@@ -601,21 +607,22 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
 // ---------------------------------------------------------------------------------------------------------------
 // end of a chunk: the last version of every touched node -> the other copy of its table bundle, meta published
 // ---------------------------------------------------------------------------------------------------------------
+// (a workgroup scans WBS sorted positions, lists the last runs it finds (~WBS/6) in LDS and copies them with four loads per
+// thread in flight at once: one load per iteration was a loop of ~15 dependent round trips)
+static constexpr int WBS = 256;
 __global__ __launch_bounds__(WB) void k_wwriteback(tpnet_state S, WPlan P, int64_t nc, uint32_t bid) {
     const int per = S.L * S.d;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
     __shared__ uint32_t n_list;
-    __shared__ uint32_t l_pos[WB];
-    __shared__ int32_t l_node[WB];
-    __shared__ int32_t l_copy[WB];
-    // a block scans WB sorted positions for runs that are their node's last in the chunk, lists them in LDS, then all its
-    // threads copy the listed bundles (every load of the copy is independent: two memory round trips per block)
-    for (int64_t j0 = (int64_t)blockIdx.x * WB; j0 < nc; j0 += (int64_t)gridDim.x * WB) {
+    __shared__ uint32_t l_pos[WBS];
+    __shared__ int32_t l_node[WBS];
+    __shared__ int32_t l_copy[WBS];
+    for (int64_t j0 = (int64_t)blockIdx.x * WBS; j0 < nc; j0 += (int64_t)gridDim.x * WBS) {
         __syncthreads();
         if (threadIdx.x == 0) n_list = 0;
         __syncthreads();
         const int64_t j = j0 + threadIdx.x;
-        if (j < nc && (P.s_ref[j] & WREF_LAST_RUN)) {
+        if (threadIdx.x < WBS && j < nc && (P.s_ref[j] & WREF_LAST_RUN)) {
             const int32_t u = P.base.s_target[j];
             const int c = (int)(meta[u].ver & 1u);
             const uint32_t k = atomicAdd(&n_list, 1u);
@@ -627,11 +634,20 @@ __global__ __launch_bounds__(WB) void k_wwriteback(tpnet_state S, WPlan P, int64
         const uint32_t n = n_list;
         if ((per & 3) == 0) {
             const uint32_t pv = (uint32_t)per / 4;
-            for (uint32_t x = threadIdx.x; x < n * pv; x += WB) {
-                const uint32_t k = x / pv, o = x - k * pv;
-                const float4* src = reinterpret_cast<const float4*>(P.log + (int64_t)l_pos[k] * per);
-                float4* dst = reinterpret_cast<float4*>(S.q + ((int64_t)(l_copy[k] ^ 1) * S.N + l_node[k]) * (int64_t)per);
-                dst[o] = src[o];
+            const uint32_t tot = n * pv;
+            for (uint32_t x0 = threadIdx.x; x0 < tot; x0 += 4 * WB) {           // four loads in flight per thread
+                const uint32_t xa = x0, xb = x0 + WB, xc = x0 + 2 * WB, xd = x0 + 3 * WB;
+                const uint32_t ka = xa / pv, kb = (xb < tot ? xb : xa) / pv, kc = (xc < tot ? xc : xa) / pv, kd = (xd < tot ? xd : xa) / pv;
+                const uint32_t oa = xa - ka * pv, ob = (xb < tot ? xb : xa) - kb * pv, oc = (xc < tot ? xc : xa) - kc * pv,
+                               od = (xd < tot ? xd : xa) - kd * pv;
+                const float4 va = reinterpret_cast<const float4*>(P.log + (int64_t)l_pos[ka] * per)[oa];
+                const float4 vb = reinterpret_cast<const float4*>(P.log + (int64_t)l_pos[kb] * per)[ob];
+                const float4 vc = reinterpret_cast<const float4*>(P.log + (int64_t)l_pos[kc] * per)[oc];
+                const float4 vd = reinterpret_cast<const float4*>(P.log + (int64_t)l_pos[kd] * per)[od];
+                reinterpret_cast<float4*>(S.q + ((int64_t)(l_copy[ka] ^ 1) * S.N + l_node[ka]) * (int64_t)per)[oa] = va;
+                if (xb < tot) reinterpret_cast<float4*>(S.q + ((int64_t)(l_copy[kb] ^ 1) * S.N + l_node[kb]) * (int64_t)per)[ob] = vb;
+                if (xc < tot) reinterpret_cast<float4*>(S.q + ((int64_t)(l_copy[kc] ^ 1) * S.N + l_node[kc]) * (int64_t)per)[oc] = vc;
+                if (xd < tot) reinterpret_cast<float4*>(S.q + ((int64_t)(l_copy[kd] ^ 1) * S.N + l_node[kd]) * (int64_t)per)[od] = vd;
             }
         } else {
             for (uint32_t x = threadIdx.x; x < n * (uint32_t)per; x += WB) {
@@ -648,10 +664,10 @@ __global__ __launch_bounds__(WB) void k_wwriteback(tpnet_state S, WPlan P, int64
 
 int launch_wwriteback(const tpnet_state& st, const WPlan& p, int64_t Ec, uint32_t launch_id, hipStream_t s) {
     const int64_t nc = 2 * Ec;
-    int grid = (int)((nc + WB - 1) / WB);
-    if (grid > 4096) grid = 4096;
+    int64_t grid = (nc + WBS - 1) / WBS;
+    if (grid > 16384) grid = 16384;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_wwriteback, dim3(grid), dim3(WB), 0, s, st, p, nc, launch_id);
+    hipLaunchKernelGGL(k_wwriteback, dim3((unsigned)grid), dim3(WB), 0, s, st, p, nc, launch_id);
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }
@@ -662,21 +678,21 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     if (st.d % 4 != 0) return TPNET_ERR_BAD_ARG;
     const int L = st.L;
     const int64_t nw = (Ec + p.Ew - 1) / p.Ew;
-    static const int hb_env = getenv("TPNET_DEV_WIN_HB") ? atoi(getenv("TPNET_DEV_WIN_HB")) : 0;
-    static const int stamp_layer = getenv("TPNET_DEV_STAMP_LAYER") ? atoi(getenv("TPNET_DEV_STAMP_LAYER")) : 0;
-    static const int geo_env = getenv("TPNET_DEV_WIN_GEOM") ? atoi(getenv("TPNET_DEV_WIN_GEOM")) : 0;
+    static const int hb_env = TPNET_DEV_INT(WIN_HB, 0);
+    static const int stamp_layer = TPNET_DEV_INT(STAMP_LAYER, 0);
+    static const int geo_env = TPNET_DEV_INT(WIN_GEOM, 0);
     const Geom geo = pick_geom(st.d, geo_env == 1);           // (TPNET_DISPATCH_G declares its own `gm`)
     const int lph = heavy_lph(geo.lpp, geo.vpl);
     const int GPB = WB / geo.lpp;
     // (the readout of rows of 17..32 vectors on 16 lanes x 2 vectors: four pairs per wave, a reduction over 16 lanes.  No gain
     // with 16 K-edge windows; with 24 K-edge windows and 256 hub workgroups C2 goes 3.40 -> 3.18 us per batch: default on)
-    static const int rs_env = getenv("TPNET_DEV_WIN_RSPLIT") ? atoi(getenv("TPNET_DEV_WIN_RSPLIT")) : 1;
+    static const int rs_env = TPNET_DEV_INT(WIN_RSPLIT, 1);
     const bool rsplit = rs_env == 1 && geo.lpp == 32 && geo.vpl == 1 && st.d / 4 > 16;   // rows of 17..32 vectors
     WStep ws;
     ws.CP = (st.d / 4 + lph - 1) / lph;
-    static const int stamp_step = getenv("TPNET_DEV_STAMP_STEP") ? atoi(getenv("TPNET_DEV_STAMP_STEP")) : -1;
+    static const int stamp_step = TPNET_DEV_INT(STAMP_STEP, -1);
     ws.dbg_layer = (stamp_layer == -1 && stamp_step >= 0 && j != stamp_step) ? 0 : stamp_layer;
-    static const int skip_env = getenv("TPNET_DEV_WIN_SKIP") ? atoi(getenv("TPNET_DEV_WIN_SKIP")) : 0;   // timing experiments only
+    static const int skip_env = TPNET_DEV_INT(WIN_SKIP, 0);   // timing experiments only
     ws.dbg_skip = skip_env;
     const bool have_readout = a.out_pos || a.out_neg;
     auto win_edges = [&](int64_t w) { const int64_t e0 = w * p.Ew; return (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew; };
@@ -699,7 +715,7 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
                 ++nact;
                 // (chains <= contributions, typically a third of them; the lists are sorted longest first, so a block that
                 // walks a second round of chains gets short ones)
-                static const int lb_env = getenv("TPNET_DEV_WIN_LB") ? atoi(getenv("TPNET_DEV_WIN_LB")) : 0;
+                static const int lb_env = TPNET_DEV_INT(WIN_LB, 0);
                 const uint32_t g_ = (uint32_t)grid_for(2 * win_edges(ws.w_upd[i]) / 3 + 1, GPB, lb_env > 0 ? lb_env : 768);
                 per = g_ > per ? g_ : per;
             }

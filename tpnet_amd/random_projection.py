@@ -144,6 +144,9 @@ class RandomProjectionModule(nn.Module):
         self._launch_id = 1
         self._now_dirty = False
         self._params_exposed = False          # the ParameterList was handed out since the last import (see __getattr__)
+        self._table_sig = 0                   # identifies the table's per-node (copy, reference time) state (plan replay)
+        self._sig_counter = 1
+        self._plan_tag = None                 # _lib.PlanTag of the plan the stream workspace holds
 
     # ------------------------------------------------------------------------------------------------------
     # plumbing
@@ -262,7 +265,7 @@ class RandomProjectionModule(nn.Module):
         return _lib.State(p0=p0.data_ptr(), q=eng["q"].data_ptr(), meta=eng["meta"].data_ptr(), N=self.node_num,
                           d=self.dim, L=self.num_layer, err=eng["err"].data_ptr())
 
-    def _workspace(self, max_edges: int, batch: int, stream: bool = False, tail: int = 0):
+    def _workspace(self, max_edges: int, batch: int, stream: bool = False, tail: int = 0, keep_plan: bool = False):
         """Plan workspace.  `stream`: sized for tpnet_run_stream (the windowed schedule's plan + version log where it applies),
         capped at one chunk of the stream -- the C side walks longer streams chunk by chunk."""
         eng = self._engine()
@@ -279,7 +282,26 @@ class RandomProjectionModule(nn.Module):
             cache[(max_edges, batch, stream, tail)] = need
         if eng["ws"] is None or eng["ws"].numel() < need:
             eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
+            self._drop_plan()
+        if not keep_plan:
+            self._drop_plan()              # (whoever asks for the workspace may write it: only run_stream keeps its plan)
         return eng["ws"]
+
+    # plan replay (tpnet_run_stream_tagged): the table signature names the per-node (current copy, reference time) state --
+    # uniform (copy 0, one reference time) right after a reset or an import, unique after anything else wrote the state
+    def _table_uniform(self, tref: float):
+        import struct
+        self._table_sig = (struct.unpack("<Q", struct.pack("<d", float(tref)))[0] ^ 0x9E3779B97F4A7C15) | 1
+
+    def _table_written(self):
+        self._sig_counter += 1
+        self._table_sig = (self._sig_counter << 1) & 0x7FFFFFFFFFFFFFFE or 2      # even: never equals a uniform signature
+
+    def _drop_plan(self):
+        """The stream workspace is about to be used by something else (or was reallocated): no plan to replay."""
+        tag = self.__dict__.get("_plan_tag")
+        if tag is not None:
+            C.memset(C.byref(tag), 0, C.sizeof(tag))
 
     def _layer_ptrs(self):
         arr = (C.c_void_p * self.num_layer)()
@@ -311,6 +333,7 @@ class RandomProjectionModule(nn.Module):
             self._param_sig = self._sig()
             self._params_exposed = False
             self._launch_id = 1
+            self._table_uniform(self._now_host)
 
     def _materialize(self):
         """Write the eager matrices P[1..L] (decay applied) into the Parameters (in place)."""
@@ -475,6 +498,7 @@ class RandomProjectionModule(nn.Module):
         self._now_host = next_time
         self._params_valid = False
         self._now_dirty = True
+        self._table_written()
 
     def get_random_projections(self, node_ids: np.ndarray):
         """models/TPNet.py:101-110: [P[i][node_ids] for i in 0..L]."""
@@ -708,6 +732,7 @@ class RandomProjectionModule(nn.Module):
             self._engine_valid = True
             self._param_sig = self._sig()
             self._launch_id = 1
+            self._table_uniform(self._now_host)
         else:
             self._engine_valid = False
 
@@ -730,10 +755,12 @@ class RandomProjectionModule(nn.Module):
     # extension: device-resident edge stream (the reference's batch loop, train_link_prediction.py:253-373)
     # ------------------------------------------------------------------------------------------------------
     default_schedule = "auto"      # run_stream: "auto" | "windowed" | "batch" (see include/tpnet_hip.h, TPNET_FLAG_SCHED_*)
+    plan_replay = True             # run_stream: replay the plan of a stream that is run again on the same table state
+    last_stream_replayed = False
 
     def run_stream(self, src: torch.Tensor, dst: torch.Tensor, neg, t: torch.Tensor, batch_size: int,
                    want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None,
-                   raw: bool = False, packed: bool = False, schedule: str = None):
+                   raw: bool = False, packed: bool = False, schedule: str = None, replay: bool = None):
         """For each chronological batch: pre-mlp pairwise features of (src,dst) and (src,neg) on the pre-batch
         state, then update().  src/dst/neg: int64 [E] on the GPU, t: float64 [E] on the GPU.  Returns
         (feat_pos, feat_neg) of shape [E, (2L+2)^2] (None where not requested).  `t_end` = t[-1] if the caller
@@ -759,7 +786,7 @@ class RandomProjectionModule(nn.Module):
             out_neg = torch.empty((E, NG), dtype=torch.float32, device=dev)
         if E == 0:
             return out_pos, out_neg
-        ws = self._workspace(E, batch_size, stream=True)
+        ws = self._workspace(E, batch_size, stream=True, keep_plan=True)
         st = self._state()
         nb = (E + batch_size - 1) // batch_size
         lid = self._next_launch_ids(nb)
@@ -769,18 +796,36 @@ class RandomProjectionModule(nn.Module):
         if self.exact:
             flags |= _lib.FLAG_EAGER_DECAY | _lib.FLAG_SEQUENTIAL
         schedule = schedule or self.default_schedule
-        if schedule not in ("auto", "windowed", "batch"):
-            raise ValueError("schedule must be 'auto', 'windowed' or 'batch'")
-        flags |= {"auto": 0, "windowed": _lib.FLAG_SCHED_WINDOWED, "batch": _lib.FLAG_SCHED_BATCH}[schedule]
+        if schedule not in ("auto", "windowed", "batch", "windowed-sorted"):
+            raise ValueError("schedule must be 'auto', 'windowed', 'windowed-sorted' or 'batch'")
+        flags |= {"auto": 0, "windowed": _lib.FLAG_SCHED_WINDOWED, "batch": _lib.FLAG_SCHED_BATCH,
+                  "windowed-sorted": _lib.FLAG_SCHED_WINDOWED | _lib.FLAG_PLAN_SORTED}[schedule]
         t_out = C.c_double(0.0)
-        _lib.check(_lib.load().tpnet_run_stream(
+        # a stream that is run again on the same table state (every epoch of train_link_prediction.py:234-253: reset, then the
+        # same chronological batches) replays its plan: the tag tells the C side that src / dst / t hold what they held when
+        # the plan in the workspace was built (torch bumps a tensor's _version on every in-place write; a write through a raw
+        # pointer or .data is not seen -- pass replay=False then) and names the table's per-node state
+        tag = None
+        if replay is not False and self.plan_replay:
+            tag = self.__dict__.get("_plan_tag")
+            if tag is None:
+                tag = self.__dict__["_plan_tag"] = _lib.PlanTag()
+            tag.table_sig = self._table_sig
+            tag.stream_sig = (hash((src.data_ptr(), src._version, dst.data_ptr(), dst._version, t.data_ptr(), t._version, E))
+                              & 0xFFFFFFFFFFFFFFFF) | 1
+        else:
+            self._drop_plan()
+        _lib.check(_lib.load().tpnet_run_stream_tagged(
             C.byref(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
             E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
             out_pos.data_ptr() if want_pos else None, out_neg.data_ptr() if want_neg else None,
-            ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream()), "run_stream")
+            ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream(),
+            C.byref(tag) if tag is not None else None), "run_stream")
+        self.last_stream_replayed = bool(tag is not None and tag.replayed)
         self._now_host = float(t_end) if t_end is not None else float(t_out.value)
         self._params_valid = False
         self._now_dirty = True
+        self._table_written()
         return (out_pos if want_pos else None), (out_neg if want_neg else None)
 
     def check_device_errors(self):
