@@ -8,7 +8,12 @@
 A "step" = one pass of the hot path over one batch: pairwise readout of (src,dst) and (src,neg) on the pre-batch
 state + update() of the batch (the decoder-level unit of SURVEY.md §8d).  Workload = BASELINE.json configs[1]
 (C2: Wikipedia-shaped stream, d=128, batch=1000, L=3, fp32); inputs are resident in HBM when the timed region
-starts.  Prints ONE JSON line (rank 0).
+starts.  Prints ONE JSON line (rank 0):
+  value / ms_per_step   the K timed steps (ONE run_stream call, planning included), max over ranks
+  roofline              the kernel those K steps ran on, timed live with HIP events over the same K batches
+  epoch                 one epoch of the config's own stream (C2: 157 474 edges): wall clock, cold and with the plan replayed
+  long_stream           2 048 batches of the same stream: the regime of streams of millions of edges
+  cpu_baseline, dropin  the torch-CPU port on the host cores; the per-batch module API from host arrays
 """
 import argparse
 import os
@@ -227,8 +232,7 @@ def main():
     #                   reduce-scattered per chunk of steps behind the next chunk's kernels (ColumnShardedRunner).
     Bg = B * world
     cfg_run = dict(cfg, B=Bg)
-    # the roofline pass (rank 0, N = 1) times the dominant kernel over at least ROOF_STEPS batches: a K = 20 timed region is
-    # too short for the schedule long streams run on (see `roofline` below), so the stream is generated that long
+    # `long_stream` (rank 0, N = 1, beside the main figures) runs ROOF_STEPS batches of the same stream, so it is generated that long
     ROOF_STEPS = 2048
     Kr = max(K, ROOF_STEPS) if world == 1 else K
     src, dst, neg, t, N = make_workload(cfg_run, W + Kr, 0)
@@ -309,24 +313,6 @@ def main():
 
     rp = None
     out_pos = out_neg = None
-    process_warmup = None
-    if shard == "single" and os.environ.get("TPNET_BENCH_PROCESS_WARMUP", "1") != "0" and 28.0 * N * d < 20e9:
-        # First-use costs of the HIP runtime in a fresh process (measured with tools/bench_flow.py on fresh boxes: the FIRST
-        # K-step call of a process takes 90-150 us longer than every later identical one -- 276 / 338 us against 189 us for
-        # K = 20 -- whatever module it runs on, with or without a GPU pre-heat): one untimed pass of the same call shapes on a
-        # SCRATCH module, before the measured module exists.  The measured module still gets exactly W warm-up steps and K
-        # timed steps; TPNET_BENCH_PROCESS_WARMUP=0 switches this off.
-        scratch = make_full_module()
-        so_p = torch.empty((K * Bg, scratch.pair_wise_feature_dim), dtype=torch.float32, device=dev)
-        so_n = torch.empty_like(so_p)
-        for a_, b_ in ((0, max(1, W // 2)), (max(1, W // 2), max(2, W)), (W, W + K)):
-            sl_ = slice(a_ * Bg, b_ * Bg)
-            scratch.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, out_pos=so_p[:(b_ - a_) * Bg],
-                               out_neg=so_n[:(b_ - a_) * Bg], t_end=float(t[b_ * Bg - 1]))
-        torch.cuda.synchronize()
-        del scratch, so_p, so_n
-        process_warmup = ("one untimed pass of the same call shapes on a scratch module before the measured module is built "
-                          "(first-use costs of the HIP runtime in a fresh process: +90..150 us on the first K-step call)")
     if shard == "single":
         rp = make_full_module()
         NG = rp.pair_wise_feature_dim
@@ -361,7 +347,7 @@ def main():
                    f"rows of all {L + 1} layers + {3 * Bg} halo rows), global batch {Bg} = {B} per GPU, one RCCL "
                    f"all-gather of the touched rows' bundles per step"}[shard]
 
-    def emit(row_info=None, roof=None, cpu=None, dropin=None):
+    def emit(row_info=None, roof=None, cpu=None, dropin=None, extra=None):
         line = {
             "metric": "temporal edges/sec (proj-update + pairwise readout)",
             "value": K * Bg / elapsed, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -372,14 +358,14 @@ def main():
                        "batch": Bg, "dim": d, "num_layer": L, "nodes": N, "parallelism": par},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if process_warmup:
-            line["config"]["process_warmup"] = process_warmup
         if row_info is not None:
             line["col_sharded"] = row_info
         if shard == "rows":
             line["config"]["table_bytes_per_gpu"] = row_bytes
         if dropin is not None:
             line["dropin"] = dropin
+        if extra:
+            line.update(extra)
         print(json.dumps(line), flush=True)
 
     # second leg at N > 1: the column-sharded layout (ablation) on the same workload, behind a watchdog (a collective that
@@ -407,80 +393,76 @@ def main():
         state["done"] = True
         wd.cancel()
 
-    # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side), extra passes over
-    # batches [W, W + K) -- the timed region -- and, when that region is shorter than ROOF_STEPS, over [W, W + ROOF_STEPS) of
-    # the same stream (state keeps advancing; throughput above is not affected)
+    # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side, tpnet_time_stream)
+    # around the loop of launches of the dominant kernel, in an extra pass over the SAME batches [W, W + K) as the timed
+    # region -- so `roofline` describes the kernel `value` was produced by (k_step below ~28 batches, k_wpipe from there).
     roof = None
+    extra = {}
 
-    def roof_pass(k_steps, o_pos, o_neg):
-        sl = slice(W * Bg, (W + k_steps) * Bg)
-        a_src, a_dst, a_neg, a_t = d_src[sl], d_dst[sl], d_neg[sl], d_t[sl]
+    def pmc_traffic(kernel_short, edges_per_launch):
+        """Memory-side bytes per launch of this kernel from this round's committed rocprofv3 PMC passes (tools/pmc.sh ->
+        profiles/r03_<config>_pmc.json), accepted only for the same kernel at the same work per launch (+-10 %)."""
+        path = os.path.join(ROOT, "profiles", f"r03_{args.config}_pmc.json")
+        try:
+            for ent in json.load(open(path)).get("kernels", []):
+                if ent.get("kernel") == kernel_short and ent.get("traffic_bytes_per_launch") and \
+                        abs(ent.get("edges_per_launch", 0) - edges_per_launch) <= 0.1 * edges_per_launch:
+                    return ent["traffic_bytes_per_launch"], {"file": os.path.relpath(path, ROOT), "commit": ent.get("commit"),
+                                                             "command": ent.get("command"), "edges_per_launch": ent.get("edges_per_launch")}
+        except Exception:
+            pass
+        return None, None
+
+    def roof_pass(a_src, a_dst, a_neg, a_t, n_edges_in, t_now, t_last, o_pos, o_neg, flags=0):
         lib = _lib.load()
         st = rp._state()
-        ws = rp._workspace(k_steps * B, B, stream=True)
+        ws = rp._workspace(n_edges_in, B, stream=True)
         total_ms, kern_ms = C.c_float(0), C.c_float(0)
         n_launch, n_edges = C.c_int64(0), C.c_int64(0)
-        lid = rp._next_launch_ids(3 * k_steps + 8)
+        nbat = (n_edges_in + B - 1) // B
+        lid = rp._next_launch_ids(3 * nbat + 8)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.tpnet_time_stream(C.byref(st), a_src.data_ptr(), a_dst.data_ptr(), a_neg.data_ptr(),
-                                         a_t.data_ptr(), k_steps * B, B, float(t[(W + k_steps) * B - 1]), cfg["lam"], lid, 0,
+                                         a_t.data_ptr(), n_edges_in, B, t_now, cfg["lam"], lid, flags,
                                          o_pos.data_ptr(), o_neg.data_ptr(), ws.data_ptr(), ws.numel(), 1,
                                          C.byref(total_ms), C.byref(kern_ms), C.byref(n_launch), C.byref(n_edges), stream),
                    "time_stream")
+        rp._now_host = t_last
+        rp._params_valid = False
+        rp._now_dirty = True
+        rp._table_written()
         bpe = bytes_per_edge(d, L)
-        windowed = n_launch.value > 0 and n_launch.value * B < n_edges.value      # fewer launches than batches
+        windowed = n_launch.value > 0 and n_launch.value < nbat                     # fewer launches than batches
         bytes_per_launch = bpe * n_edges.value / max(1, n_launch.value)
         achieved = bytes_per_launch / (kern_ms.value * 1e-3) / 1e9 if kern_ms.value > 0 else 0.0
-        # HBM-side traffic of the same kernel from the committed rocprofv3 PMC passes (tools/pmc.sh -> profiles/)
-        traffic, traffic_src = None, None
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r02_{args.config}_pmc.json"))):
-            try:
-                pj = json.load(open(f))
-                if pj.get("traffic_bytes_per_launch") and pj.get("schedule") == ("windowed" if windowed else "batch"):
-                    traffic, traffic_src = pj["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-            except Exception:
-                pass
+        kshort = "k_wpipe" if windowed else "k_step"
+        traffic, traffic_src = pmc_traffic(kshort, n_edges.value / max(1, n_launch.value))
         kname = ("k_wpipe (windowed schedule: one launch per pipeline step = layer i of window j-i+1, i=1..L, + the readouts of "
                  "window j-L)") if windowed else "k_step (fused readout + update of one batch; one launch per step)"
         # (cache-resident configs: the algorithmic rate can exceed what the memory side delivers; the memory-side rate from the
         # committed counters -- bytes that really crossed the Infinity Cache / HBM boundary per launch -- is the one to hold
         # against the 8 TB/s peak there)
         mem_gbs = traffic / (kern_ms.value * 1e-3) / 1e9 if (traffic and kern_ms.value > 0) else None
-        return {"bound": "hbm", "kernel": kname, "windowed": windowed,
+        return {"bound": "hbm", "kernel": kname, "kernel_short": kshort, "windowed": windowed,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_src, "steps": k_steps,
+                "traffic": traffic, "traffic_source": traffic_src, "steps": nbat,
                 "memory_side_gbs": mem_gbs, "memory_side_frac": (mem_gbs / HBM_PEAK_GBS) if mem_gbs else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "launches": n_launch.value,
                 "edges_per_launch": n_edges.value / max(1, n_launch.value),
                 "avg_launch_period_us": kern_ms.value * 1e3,
-                "stream_ms_events": total_ms.value}
+                "stream_ms_events": total_ms.value,
+                "end_to_end_frac": (bpe * n_edges_in / (total_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS) if total_ms.value > 0 else None}
 
+    resident = 28.0 * N * d < 256e6
     if rank == 0 and shard == "single":
-        timed = roof_pass(K, out_pos, out_neg)
-        if Kr > K:
-            # the dominant kernel of the path is the one long streams run on (tpnet_run_stream picks the windowed schedule
-            # from 56 batches): it is timed over ROOF_STEPS batches of the same stream; the figure for the K timed steps
-            # themselves (the per-batch kernel, launch-bound) is kept next to it
-            o_pos = torch.empty((Kr * Bg, out_pos.shape[1]), dtype=torch.float32, device=dev)
-            o_neg = torch.empty_like(o_pos)
-            roof_pass(Kr, o_pos, o_neg)        # first use of this schedule's kernels in the process: untimed (code load)
-            roof = roof_pass(Kr, o_pos, o_neg)
-            del o_pos, o_neg
-            if roof["windowed"] and not timed["windowed"]:
-                roof["timed_region"] = {k: timed[k] for k in ("kernel", "achieved", "frac", "steps", "launches",
-                                                             "avg_launch_period_us", "algorithmic_bytes_per_launch")}
-            else:
-                roof = timed                   # same kernel either way (batches too large for the windowed schedule)
-                Kr = K
-        else:
-            roof = timed
-        roof["duration_note"] = ("HIP events on the launch stream around each chunk's loop of launches of this kernel / launches: "
-                                 "kernel duration + inter-kernel boundary (rocprofv3 per-kernel average: profiles/); measured "
-                                 f"over {roof['steps']} steps of the bench stream starting at the timed region"
-                                 + (f" (the {K} timed steps alone run the per-batch kernel: timed_region)" if "timed_region" in roof else "")
+        sl = slice(W * Bg, (W + K) * Bg)
+        rp.reset_random_projections()
+        roof = roof_pass(d_src[sl], d_dst[sl], d_neg[sl], d_t[sl], K * B, 0.0, float(t[(W + K) * B - 1]), out_pos, out_neg)
+        roof["duration_note"] = ("HIP events on the launch stream around the loop of launches of this kernel / launches: kernel "
+                                 "duration + inter-kernel boundary (rocprofv3 per-kernel average of the same command: profiles/); "
+                                 f"an extra pass over the {K} batches of the timed region, same schedule"
                                  + ("; the state is cache-resident at this config, so the algorithmic rate can exceed what "
-                                    "HBM itself delivers: see traffic / memory_side_frac" if 28.0 * N * d < 256e6 else
+                                    "HBM itself delivers: see traffic / memory_side_frac" if resident else
                                     "; the state is far larger than the 256 MB Infinity Cache: row accesses are HBM misses"))
         try:
             cbw = copy_bandwidth_gbs(dev)
@@ -489,13 +471,82 @@ def main():
         except Exception:
             pass
 
+        # ---- ONE epoch of the config as BASELINE states it (C2: E = 157 474 edges, batches of 1 000, the last one partial):
+        # wall clock around run_stream -- planning, pipeline fill and drain, write-back included -- after a reset, as
+        # train_link_prediction.py:246-253 starts every epoch.  `cold`: the first epoch of a process (plans the stream);
+        # `replay`: a later epoch (same stream, new negatives: the plan of the update is replayed, tpnet_run_stream_tagged).
+        def epoch_figures():
+            Ee = int(cfg["E"])
+            if Ee * (2 * 64 * 4 + 40) > 40e9:
+                return None
+            e_src, e_dst, e_t, _ = synthetic_stream(cfg["U"], cfg["I"], Ee, cfg["span"], seed=0)
+            negs = [synthetic_negatives(cfg["U"], N, Ee, B, seed=s_) for s_ in (1, 2, 3, 4)]
+            g_src, g_dst, g_t = to_dev(e_src), to_dev(e_dst), to_dev(e_t)
+            g_negs = [to_dev(x) for x in negs]
+            o_p = torch.empty((Ee, out_pos.shape[1]), dtype=torch.float32, device=dev)
+            o_n = torch.empty_like(o_p)
+            o_p.zero_(); o_n.zero_()
+            rp._workspace(Ee, B, stream=True).zero_()
+            t_end = float(e_t[-1])
+
+            def one(neg_dev, replay):
+                rp.reset_random_projections()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rp.run_stream(g_src, g_dst, neg_dev, g_t, B, out_pos=o_p, out_neg=o_n, t_end=t_end, replay=replay)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0, rp.last_stream_replayed
+            one(g_negs[0], False)                                      # first use of this shape in the process: untimed
+            cold = [one(g_negs[i % 4], False)[0] for i in range(1, 6)]
+            one(g_negs[0], None)                                       # leaves the plan behind
+            rep = [one(g_negs[i % 4], None) for i in range(1, 6)]
+            rp.check_device_errors()
+            # the dominant kernel of the epoch, timed like `roofline` (events around the loop of pipeline launches)
+            rp.reset_random_projections()
+            er = roof_pass(g_src, g_dst, g_negs[0], g_t, Ee, 0.0, t_end, o_p, o_n)
+            med = lambda xs: float(np.median(xs))
+            bpe = bytes_per_edge(d, L)
+            out = {"edges": Ee, "batch": B, "batches": (Ee + B - 1) // B,
+                   "what": "wall clock around ONE run_stream call over the config's whole stream after a reset (planning, "
+                           "pipeline fill / drain and write-back included), median of 5",
+                   "cold": {"wall_us": med(cold) * 1e6, "value": Ee / med(cold), "unit": "edges/s",
+                            "end_to_end_frac": bpe * Ee / med(cold) / 1e9 / HBM_PEAK_GBS},
+                   "replay": {"wall_us": med([r[0] for r in rep]) * 1e6, "value": Ee / med([r[0] for r in rep]), "unit": "edges/s",
+                              "end_to_end_frac": bpe * Ee / med([r[0] for r in rep]) / 1e9 / HBM_PEAK_GBS,
+                              "plan_replayed": bool(all(r[1] for r in rep)),
+                              "what": "a later epoch: same stream, new negatives, the update's plan replayed"},
+                   "kernel": {k: er[k] for k in ("kernel_short", "frac", "achieved", "launches", "edges_per_launch",
+                                                 "avg_launch_period_us", "memory_side_frac", "traffic", "stream_ms_events",
+                                                 "end_to_end_frac")}}
+            del o_p, o_n
+            return out
+        if os.environ.get("TPNET_BENCH_EPOCH", "1") != "0" and B <= 4096:
+            from tpnet_amd.stream import synthetic_stream, synthetic_negatives
+            extra["epoch"] = epoch_figures()
+
+        # ---- the long-stream regime: the same kernel schedule over ROOF_STEPS batches of the bench stream (what a stream of
+        # millions of edges runs at); reported beside, never instead of, the figures above
+        if Kr > K and B <= 4096:
+            slr = slice(W * Bg, (W + Kr) * Bg)
+            o_pos = torch.empty((Kr * Bg, out_pos.shape[1]), dtype=torch.float32, device=dev)
+            o_neg = torch.empty_like(o_pos)
+            args_r = (d_src[slr], d_dst[slr], d_neg[slr], d_t[slr], Kr * B, 0.0, float(t[(W + Kr) * B - 1]), o_pos, o_neg)
+            rp.reset_random_projections()
+            roof_pass(*args_r)                 # first use of this shape in the process: untimed
+            rp.reset_random_projections()
+            lr = roof_pass(*args_r)
+            lr["value"] = Kr * B / (lr["stream_ms_events"] * 1e-3)
+            lr["unit"] = "edges/s (HIP events around the whole call: planning and write-back included)"
+            extra["long_stream"] = lr
+            del o_pos, o_neg
+
     if rank == 0:
         cpu = dropin = None
         if shard == "single" and not args.no_dropin:
             dropin = dropin_rate(cfg, rp, src, dst, neg, t)
         if not args.no_cpu_baseline and shard == "single":
             cpu = cpu_baseline(cfg, src, dst, neg, t, N, P0.numpy())
-        emit(row_info, roof, cpu, dropin)
+        emit(row_info, roof, cpu, dropin, extra)
     if dist is not None:
         dist.destroy_process_group()
 

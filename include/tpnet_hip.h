@@ -93,6 +93,13 @@ int tpnet_last_hip_error(void);
 /* number of HIP devices visible (0 without a GPU; never initialises a context) */
 int tpnet_device_count(void);
 
+/* First-use costs of the HIP runtime, paid when the caller chooses (e.g. once per process and device, when the module's engine
+ * is created) instead of inside the first long call: measured, the first 20-launch call of a fresh process takes 60-70 us
+ * longer than every later one unless a burst of launches FOLLOWED BY A SYNCHRONISE came before it.  Enqueues one kernel that
+ * keeps the stream busy for spin_us microseconds and `launches` kernels with 512 bytes of arguments behind it; does not
+ * synchronise itself (the caller does, once).  Touches no caller memory. */
+int tpnet_runtime_warmup(int32_t launches, int32_t spin_us, void* stream);
+
 /* Bytes the caller must allocate for q and meta. */
 size_t tpnet_q_bytes(int64_t N, int32_t d, int32_t L);
 size_t tpnet_meta_bytes(int64_t N);

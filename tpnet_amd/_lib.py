@@ -49,6 +49,7 @@ SIGNATURES = {
     "tpnet_abi_version": (C.c_int, []),
     "tpnet_last_hip_error": (C.c_int, []),
     "tpnet_device_count": (C.c_int, []),
+    "tpnet_runtime_warmup": (C.c_int, [C.c_int32, C.c_int32, _P]),
     "tpnet_q_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "tpnet_meta_bytes": (C.c_size_t, [C.c_int64]),
     "tpnet_state_init": (C.c_int, [_SP, C.c_double, _P]),
@@ -144,6 +145,24 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+_fast = False
+
+
+def fast():
+    """The CPython extension in front of the per-batch entry points (tpnet_amd/_tpnet_fast.so, csrc/pyext.c), or None when
+    it was not built or a diagnostic library is loaded through TPNET_DEV_LIB (the ctypes binding above then serves every call)."""
+    global _fast
+    if _fast is False:
+        _fast = None
+        if not os.environ.get("TPNET_DEV_LIB") and os.path.exists(os.path.join(_HERE, "_tpnet_fast.so")):
+            load()
+            from . import _tpnet_fast as m          # (an import error here is a broken build: let it show)
+            if m.abi_version() != load().tpnet_abi_version():
+                raise TPNetHipError("_tpnet_fast.so and libtpnet_hip.so are different builds: run __graft_entry__.build()")
+            _fast = m
+    return _fast
 
 
 def check(rc: int, what: str = ""):

@@ -451,6 +451,24 @@ int tpnet_run_stream_tagged(const tpnet_state* st, const int64_t* src, const int
     return TPNET_OK;
 }
 
+// a kernel that keeps its queue busy for `ticks` of the 100 MHz wall clock, and one that does nothing
+__global__ void k_warm_spin(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+struct WarmArgs { uint64_t w[64]; };                        // 512 bytes of kernel arguments, like the step kernels'
+__global__ void k_warm_noop(WarmArgs a, uint64_t* sink) { if (sink && a.w[0] == 0x1234567ull) *sink = a.w[1]; }
+
+int tpnet_runtime_warmup(int32_t launches, int32_t spin_us, void* stream) {
+    if (launches < 0 || launches > 4096 || spin_us < 0 || spin_us > 5000) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (spin_us > 0) hipLaunchKernelGGL(k_warm_spin, dim3(1), dim3(64), 0, s, (uint64_t)spin_us * 100ull);
+    WarmArgs wa{};
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_warm_noop, dim3(1), dim3(64), 0, s, wa, (uint64_t*)nullptr);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 int tpnet_plan_stream(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t E,
                       int64_t batch, double now_time, double lambda, uint32_t flags, void* workspace, size_t ws_bytes,
                       void* stream) {

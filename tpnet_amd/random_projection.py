@@ -33,6 +33,7 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i:
 
 
 _OWNERS = weakref.WeakValueDictionary()      # id(module) -> module, for the lazy layer list below
+_WARMED = set()                               # devices whose HIP runtime pools were warmed (tpnet_runtime_warmup)
 
 
 class _LazyLayers(nn.ParameterList):
@@ -85,6 +86,11 @@ class _Stage:
 
 
 class RandomProjectionModule(nn.Module):
+    # plan-replay bookkeeping (class-level defaults: tpnet_amd/matrix_memory.py builds instances without this constructor)
+    _table_sig = 0
+    _sig_counter = 1
+    _plan_tag = None
+
     def __init__(self, node_num: int, edge_num: int, dim_factor: int, num_layer: int, time_decay_weight: float,
                  device: str, use_matrix: bool, beginning_time: np.float64, not_scale: bool, enforce_dim: int,
                  exact: bool = False, alloc_device=None):
@@ -216,6 +222,16 @@ class RandomProjectionModule(nn.Module):
                 err = torch.zeros(4, dtype=torch.int32, device=dev)
             self._eng = dict(dev=dev, dev_index=dev.index if dev.index is not None else torch.cuda.current_device(), q=q,
                              meta=meta, err=err, ws=None, stage=_Stage(lib, dev))
+            if dev not in _WARMED:
+                # once per process and device: the HIP runtime's first-use costs are paid here, not inside the first long
+                # call -- a burst of launches behind a busy kernel, then ONE synchronise (tools/first_call.py, first 20-batch
+                # call of a fresh process: 255..260 us without, 257 with the burst alone, 193 with burst + synchronise;
+                # every later call 185..190)
+                _WARMED.add(dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.tpnet_runtime_warmup(64, 100, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                               "runtime_warmup")
+                    torch.cuda.synchronize(dev)
             self._engine_valid = False
             self.__dict__["_st_cache"] = None
         return self._eng
@@ -226,7 +242,7 @@ class RandomProjectionModule(nn.Module):
         c = self.__dict__.get("_st_cache")
         if c is None or c[0] != ptr or c[1] is not self._eng:
             st = self._state()
-            c = (ptr, self._eng, st, C.byref(st))
+            c = (ptr, self._eng, st, C.byref(st), C.addressof(st))
             self.__dict__["_st_cache"] = c
         return c[3]
 
@@ -249,10 +265,18 @@ class RandomProjectionModule(nn.Module):
         eng = self._eng
         out = torch.empty((n, width), dtype=torch.float32, device=eng["dev"])
         if n:
-            rc = _lib.load().tpnet_host_pair_feature(
-                self._st_ref(), eng["stage"].handle, u.ctypes.data, v.ctypes.data, n, self._now_host,
-                float(self.time_decay_weight), flags, mlp_ref, out_gram.data_ptr() if out_gram is not None else None,
-                out.data_ptr(), _raw_stream(eng["dev_index"]))
+            fast = _lib.fast()
+            if fast is not None:
+                self._st_ref()
+                rc = fast.pair_feature(self.__dict__["_st_cache"][4], eng["stage"].handle.value, u, v, self._now_host,
+                                       float(self.time_decay_weight), flags, C.addressof(mlp_ref._obj) if mlp_ref is not None else 0,
+                                       out_gram.data_ptr() if out_gram is not None else 0, out.data_ptr(),
+                                       _raw_stream(eng["dev_index"]))
+            else:
+                rc = _lib.load().tpnet_host_pair_feature(
+                    self._st_ref(), eng["stage"].handle, u.ctypes.data, v.ctypes.data, n, self._now_host,
+                    float(self.time_decay_weight), flags, mlp_ref, out_gram.data_ptr() if out_gram is not None else None,
+                    out.data_ptr(), _raw_stream(eng["dev_index"]))
             if rc:
                 _lib.check(rc, "host_pair_feature")
         return out
@@ -486,9 +510,15 @@ class RandomProjectionModule(nn.Module):
         if host:
             # host arrays (what the reference's loop passes, train_link_prediction.py:372): one FFI call = staging + one
             # single-workgroup plan kernel + the step kernel
-            rc = lib.tpnet_host_update(self._st_ref(), self._eng["stage"].handle, src_h.ctypes.data, dst_h.ctypes.data,
-                                       t.ctypes.data, B, self._now_host, lam, lid, flags, ws.data_ptr(), ws.numel(),
-                                       _raw_stream(self._eng["dev_index"]))
+            fast = _lib.fast()
+            if fast is not None:
+                self._st_ref()
+                rc = fast.update(self.__dict__["_st_cache"][4], self._eng["stage"].handle.value, src_h, dst_h, t, self._now_host,
+                                 lam, lid, flags, ws.data_ptr(), ws.numel(), _raw_stream(self._eng["dev_index"]))
+            else:
+                rc = lib.tpnet_host_update(self._st_ref(), self._eng["stage"].handle, src_h.ctypes.data, dst_h.ctypes.data,
+                                           t.ctypes.data, B, self._now_host, lam, lid, flags, ws.data_ptr(), ws.numel(),
+                                           _raw_stream(self._eng["dev_index"]))
             if rc:
                 _lib.check(rc, "host_update")
         else:
@@ -815,12 +845,22 @@ class RandomProjectionModule(nn.Module):
                               & 0xFFFFFFFFFFFFFFFF) | 1
         else:
             self._drop_plan()
-        _lib.check(_lib.load().tpnet_run_stream_tagged(
-            C.byref(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
-            E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
-            out_pos.data_ptr() if want_pos else None, out_neg.data_ptr() if want_neg else None,
-            ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream(),
-            C.byref(tag) if tag is not None else None), "run_stream")
+        fast = _lib.fast()
+        if fast is not None:
+            rc, t_got = fast.run_stream(C.addressof(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else 0,
+                                        t.data_ptr(), E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
+                                        out_pos.data_ptr() if want_pos else 0, out_neg.data_ptr() if want_neg else 0,
+                                        ws.data_ptr(), ws.numel(), 0 if t_end is not None else 1,
+                                        _raw_stream(self._eng["dev_index"]), C.addressof(tag) if tag is not None else 0)
+            t_out.value = t_got
+            _lib.check(rc, "run_stream")
+        else:
+            _lib.check(_lib.load().tpnet_run_stream_tagged(
+                C.byref(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
+                E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
+                out_pos.data_ptr() if want_pos else None, out_neg.data_ptr() if want_neg else None,
+                ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream(),
+                C.byref(tag) if tag is not None else None), "run_stream")
         self.last_stream_replayed = bool(tag is not None and tag.replayed)
         self._now_host = float(t_end) if t_end is not None else float(t_out.value)
         self._params_valid = False
