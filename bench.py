@@ -149,7 +149,55 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
     res["encoder_level"] = {"value": nbe * B / el, "unit": "edges/s", "us_per_batch": el / nbe * 1e6,
                             "what": f"+ 2 x get_pair_wise_feature on 4*B*K = {4 * B * K} pairs (K = {K}) per batch, host index arrays in the "
                                     "reference's tile / repeat layout (built before the clock starts)"}
+    # the same unit with the ids resident on the device end to end (SURVEY section 8 f-3 -> f-2 -> f-1): the batch's src / dst /
+    # neg / t go up in ONE pinned copy, the device sampler draws the K most recent neighbours of the 2B nodes (the neighbour ids
+    # never visit the host), the anchored readout pairs every neighbour with the edge's two endpoints (no index arrays at
+    # all), self.mlp runs behind it; then the decoder-level calls as above.  fp32 class; `bf16_mlp`: self.mlp on the bf16 matrix
+    # cores (opt-in RandomProjectionModule.fused_mlp, 1e-2 class).
+    try:
+        from tpnet_amd.sampler import GpuRecentNeighborSampler
+        dev = rp._dev()
+        nall = (nbe + 4) * B
+        smp = GpuRecentNeighborSampler(src[:nall], dst[:nall], t[:nall], device=str(dev), num_nodes=N)
+
+        def device_loop(label):
+            rp.reset_random_projections()
+            with torch.no_grad():
+                for b in range(nbe + 4):
+                    if b == 4:
+                        torch.cuda.synchronize()
+                        t0_ = time.perf_counter()
+                    s = slice(b * B, (b + 1) * B)
+                    s_d, d_d, n_d, t_d = rp._to_device(src[s], dst[s], neg[s], t[s])
+                    t2 = t_d.repeat(2)
+                    s2 = s_d.repeat(2)
+                    for other in (d_d, n_d):
+                        neigh = smp.sample_device(torch.cat([s_d, other]), t2, K, with_edges=False)[0]
+                        rp.get_pair_wise_feature_anchored(neigh, s2, other.repeat(2))
+                    rp.get_pair_wise_feature(src[s], dst[s])
+                    rp.get_pair_wise_feature(src[s], neg[s])
+                    rp.update(src[s], dst[s], t[s])
+                torch.cuda.synchronize()
+            el_ = time.perf_counter() - t0_
+            return {"value": nbe * B / el_, "unit": "edges/s", "us_per_batch": el_ / nbe * 1e6, "what": label}
+        if _lib_anchored_ok(rp):
+            res["encoder_level_device"] = device_loop(
+                f"ids resident on the device: 1 pinned copy of the batch + 2 x (device sampler, K = {K}; anchored readout of "
+                f"4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls")
+            if rp.num_layer == 3:
+                rp.fused_mlp = True
+                try:
+                    res["encoder_level_device"]["bf16_mlp"] = device_loop("the same with self.mlp on the bf16 matrix cores (opt-in)")
+                finally:
+                    rp.fused_mlp = False
+    except Exception as ex:                       # noqa: BLE001 -- a secondary figure must not cost the main line
+        res["encoder_level_device"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     return res
+
+
+def _lib_anchored_ok(rp):
+    from tpnet_amd import _lib
+    return bool(_lib.load().tpnet_pair_gram_anchored_supported(rp._st_ref()))
 
 
 def copy_bandwidth_gbs(dev):

@@ -223,6 +223,12 @@ size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
  * plus the readouts of the window behind them -- instead of one launch per batch; with less it falls back to per-batch
  * launches.  The two schedules differ in f32 summation order only (both within 1e-4 of the reference). */
 size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch);
+/* The same with the version log of a chunk capped at log_cap_bytes (0 = the library's 4 GiB): the windowed schedule costs
+ * 2*L*d*4 bytes of log per edge of a chunk (C2: 3 KB per edge, 484 MB for one Wikipedia epoch) plus ~0.5 KB per edge of plan; a
+ * caller short of memory trades chunk length (more pipeline fills and drains) for workspace.  tpnet_run_stream takes whatever
+ * chunk the workspace it is given holds. */
+size_t tpnet_stream_workspace_bytes_capped(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch,
+                                           size_t log_cap_bytes);
 
 /* update (models/TPNet.py:67-99) for one batch: src, dst device int64[B], t device double[B] (absolute times,
  * chronological; t[B-1] is the new now_time).  now_time = the module's clock before the call; launch_id = a

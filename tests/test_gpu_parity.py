@@ -173,10 +173,13 @@ def _random_stream(rng, N, E, span, hub_frac=0.2):
                                      (128, 4, 333, 77), (64, 2, 1000, 500), (16, 3, 400, 200), (32, 3, 300, 150),
                                      (24, 2, 200, 64), (8, 4, 128, 100), (512, 4, 100, 40), (256, 4, 120, 500),
                                      (64, 4, 150, 450), (128, 1, 90, 30)])
-@pytest.mark.parametrize("exact", [True, False])
-def test_stream_matches_oracle(d, L, N, B, exact):
-    """run_stream (fused readout + update per batch, ragged last batch) == oracle loop readout, readout, update."""
+@pytest.mark.parametrize("mode", ["exact", "auto", "batch", "windowed"])
+def test_stream_matches_oracle(d, L, N, B, mode):
+    """run_stream (ragged last batch) == oracle loop readout, readout, update -- in the exact mode and on every schedule
+    of the default mode: "auto" (what the shipped default picks for a stream this short: the per-batch kernels), "batch",
+    "windowed"."""
     _need_gpu()
+    exact = mode == "exact"
     rng = np.random.RandomState(d * 7 + L)
     E = 4 * B + B // 3 + 1
     lam = 2e-6
@@ -185,7 +188,7 @@ def test_stream_matches_oracle(d, L, N, B, exact):
     rp = _module(N, d, L, lam, t[0], P0=P0, exact=exact)
     st = O.OracleState(P0, L, lam, t[0])
     dev = lambda x: torch.from_numpy(x).to(DEV)
-    fp, fn = rp.run_stream(dev(src), dev(dst), dev(neg), dev(t), B)
+    fp, fn = rp.run_stream(dev(src), dev(dst), dev(neg), dev(t), B, schedule=None if exact else mode)
     fp = fp.cpu().numpy(); fn = fn.cpu().numpy()
     for b in range(0, E, B):
         s = slice(b, min(b + B, E))
@@ -383,7 +386,7 @@ def test_shared_first_node_readout(d, L):
 # the other BASELINE.json configs: oracle on a prefix (the numpy oracle needs ~1 s per 10 000-edge batch),
 # size-independent properties on the whole stream
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg,nb_oracle", [("C1", 12), ("C3", 4), ("C5", 3)])
+@pytest.mark.parametrize("cfg,nb_oracle", [("C1", 40), ("C3", 8), ("C5", 8)])
 def test_other_configs_prefix_against_oracle(cfg, nb_oracle):
     _need_gpu()
     from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
@@ -1008,3 +1011,56 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     e4 = epoch(rp, dn)
     assert torch.equal(e4[0], c1[0]) and torch.equal(e4[1], c1[1])
     np.testing.assert_array_equal(e4[2], c1[2])
+
+
+@pytest.mark.parametrize("nb", [27, 28, 60])
+def test_auto_schedule_on_both_sides_of_its_threshold(nb):
+    """The shipped default ("auto") takes the per-batch kernels below 28 batches and the windowed pipeline from there
+    (tpnet_amd/csrc/api.hip, window_chunk): both sides against the oracle, and the choice itself (a windowed run leaves a
+    plan that the next epoch replays; a per-batch run does not)."""
+    _need_gpu()
+    d, L, N, B, lam = 64, 3, 500, 100, 2e-6
+    rng = np.random.RandomState(nb)
+    E = nb * B
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    rp = _module(N, d, L, lam, t[0], P0=P0)
+    fp, fn = rp.run_stream(ds, dd, dn, dt, B, schedule="auto")
+    st = O.OracleState(P0, L, lam, t[0])
+    fp_h, fn_h = fp.cpu().numpy(), fn.cpu().numpy()
+    for o in range(0, E, B):
+        s = slice(o, o + B)
+        _assert_features(fp_h[s], st, src[s], dst[s], f"pos batch {o // B}")
+        _assert_features(fn_h[s], st, src[s], neg[s], f"neg batch {o // B}")
+        O.update(st, src[s], dst[s], t[s])
+    _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, "final state")
+    rp.reset_random_projections()
+    rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+    rp.run_stream(ds, dd, dn, dt, B, schedule="auto")
+    assert rp.last_stream_replayed == (nb >= 28)
+
+
+def test_multi_chunk_packed_rows_with_odd_row_length():
+    """Packed rows of 21 floats (L = 2) and a workspace that holds only a few windows: every chunk's output must start on a
+    16-byte boundary, which a chunk of an odd number of edges would break: the chunk length is rounded."""
+    _need_gpu()
+    from tpnet_amd import _lib
+    lib = _lib.load()
+    d, L, N, B, nb, lam = 64, 2, 4000, 1170, 90, 2e-6            # windows of 21 batches = 24 570 edges: not a multiple of 4
+    rng = np.random.RandomState(5)
+    E = nb * B
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    a = _module(N, d, L, lam, t[0], P0=P0)
+    pa, na = a.run_stream(ds, dd, dn, dt, B, packed=True)
+    b = _module(N, d, L, lam, t[0], P0=P0)
+    small = lib.tpnet_stream_workspace_bytes_capped(N, d, L, E, B, 2 * 21 * B * 2 * L * d * 4)     # two windows per chunk
+    assert small < lib.tpnet_stream_workspace_bytes(N, d, L, E, B)
+    ws = torch.empty(small, dtype=torch.uint8, device=DEV)
+    pb, nb_ = _raw_run_stream(b, ds, dd, dn, dt, B, float(t[0]), lam, ws, flags=_lib.FLAG_PACKED | _lib.FLAG_NOT_SCALE)
+    assert torch.equal(pa, pb) and torch.equal(na, nb_)
+    np.testing.assert_array_equal(_layers(a), _layers(b))

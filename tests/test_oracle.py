@@ -204,3 +204,33 @@ def test_decoder_fixture_consistent(golden_dir):
     h = np.maximum(x @ g["dec.fc1.weight"].T + g["dec.fc1.bias"], 0)
     logits = h @ g["dec.fc2.weight"].T + g["dec.fc2.bias"]
     np.testing.assert_allclose(logits, g["logits"], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the torch-CPU port (oracle/torch_port.py: bench.py's cpu_baseline) pinned to the same golden vectors
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g1_update_d16_L3.npz", "g2_update_d120_L2.npz", "g2b_update_d64_L3_fastdecay.npz"])
+def test_torch_port_update_trajectory_matches_reference(golden_dir, name):
+    """The port issues the reference's ATen op sequence (models/TPNet.py:67-99): bit-identical to its outputs."""
+    from oracle.torch_port import TorchPort
+    g = _load(golden_dir, name)
+    L, B = int(g["L"]), int(g["B"])
+    port = TorchPort(g["P0"], L, float(g["lam"]), float(g["t0"]))
+    for b in range(len(g["src"]) // B):
+        s = slice(b * B, (b + 1) * B)
+        port.update(g["src"][s], g["dst"][s], g["t"][s])
+        mine = np.stack([p.numpy() for p in port.P[1:]])
+        np.testing.assert_array_equal(mine, g[f"P_after_{b}"])
+        assert port.now == g[f"now_after_{b}"]
+
+
+@pytest.mark.parametrize("name", ["g3g4_readout_d16_L3.npz", "g3g4_readout_d128_L3.npz", "g3g4_readout_d140_L1.npz"])
+def test_torch_port_readout_matches_reference(golden_dir, name):
+    import torch
+    from oracle.torch_port import TorchPort
+    g = _load(golden_dir, name)
+    L = int(g["L"])
+    port = TorchPort(g["P"][0], L, float(g["lam"]), 0.0)
+    port.P = [torch.from_numpy(np.array(g["P"][i])) for i in range(L + 1)]
+    np.testing.assert_array_equal(port.pair_gram(g["u"], g["v"], not_scale=True).numpy(), g["gram_raw"])
+    np.testing.assert_array_equal(port.pair_gram(g["u"], g["v"]).numpy(), g["gram_scaled"])

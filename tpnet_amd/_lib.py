@@ -64,6 +64,7 @@ SIGNATURES = {
     "tpnet_pair_gram_anchored_supported": (C.c_int, [_SP]),
     "tpnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_stream_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
+    "tpnet_stream_workspace_bytes_capped": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_size_t]),
     "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,
                                C.c_size_t, _P]),
     "tpnet_run_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,

@@ -383,6 +383,16 @@ size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max
     return a > b ? a : b;
 }
 
+size_t tpnet_stream_workspace_bytes_capped(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch,
+                                           size_t log_cap_bytes) {
+    if (log_cap_bytes == 0 || L < 1 || d < 1) return tpnet_stream_workspace_bytes(N, d, L, max_edges, batch);
+    if (batch < 1) batch = 1;
+    int64_t e = (int64_t)(log_cap_bytes / (2 * (size_t)L * (size_t)d * 4));
+    e = e / batch * batch;
+    if (e < 4 * batch) e = 4 * batch;                      // (the windowed schedule needs at least four batches per chunk)
+    return tpnet_stream_workspace_bytes(N, d, L, max_edges < e ? max_edges : e, batch);
+}
+
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
                  double now_time, double lambda, uint32_t launch_id, uint32_t flags, void* workspace, size_t ws_bytes,
                  void* stream) {

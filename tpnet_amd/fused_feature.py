@@ -73,7 +73,8 @@ class _MlpF32(torch.autograd.Function):
         pre = torch.addmm(b1, x, w1.t())
         hid = torch.relu(pre)
         gh = (gy @ w2) * (pre > 0)
-        return None, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None
+        gx = gh @ w1 if ctx.needs_input_grad[0] else None     # (the readout's features carry no gradient; a caller's own x may)
+        return gx, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None
 
 
 def mlp_f32(mlp, x):
@@ -91,6 +92,17 @@ def mlp_f32(mlp, x):
 class _NoCtx:
     def save_for_backward(self, *a):
         pass
+
+
+def invalidate(mlp=None):
+    """Forget the prepared copies of `mlp`'s weights (all modules' if None).  The cache is keyed on (data_ptr, _version) of the
+    four tensors; an in-place write THROUGH `.data` (p.data.copy_(), p.data.mul_(): some EMA / weight-averaging helpers) bumps
+    neither, so whoever writes that way calls this afterwards.  Optimizer steps, load_state_dict, .to() and plain in-place ops
+    on the Parameters are seen without it."""
+    if mlp is None:
+        _PREPARED.clear()
+    else:
+        _PREPARED.pop(mlp, None)
 
 
 def prepared(mlp, F):

@@ -219,6 +219,18 @@ class ShardedStreamRunner:
             _lib.load().tpnet_rccl_comm_destroy(self._comm)
             self._comm = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the runtime may be gone already
+            pass
+
     # ---- the stream -----------------------------------------------------------------------------------------------
     def relabel(self, src, dst, neg, batch_size: int):
         """Everything the per-batch loop needs, derived from the stream by every rank on its own (no request round):
@@ -273,7 +285,8 @@ class ShardedStreamRunner:
         out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
         if E == 0:
             return out_pos, out_neg
-        if int(torch.stack([src.min(), dst.min()]).min()) < 0 or int(torch.stack([src.max(), dst.max()]).max()) >= self.N:
+        ends = [src, dst] + ([neg] if neg is not None else [])      # (the lists key on batch * N + node: a bad id would alias)
+        if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
             raise IndexError(f"node id out of range for {self.N} nodes")
         R = self.relabel(src, dst, neg, B)
         counts, offsets, tot = R["counts"], R["offsets"], R["tot"]
@@ -404,7 +417,8 @@ class ShardedStreamRunner:
         out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
         if E == 0:
             return out_pos, out_neg
-        if int(torch.stack([src.min(), dst.min()]).min()) < 0 or int(torch.stack([src.max(), dst.max()]).max()) >= self.N:
+        ends = [src, dst] + ([neg] if neg is not None else [])      # (the lists key on batch * N + node: a bad id would alias)
+        if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
             raise IndexError(f"node id out of range for {self.N} nodes")
         R = self.relabel_targeted(src, dst, neg, B)
         last_idx = torch.clamp(torch.arange(1, nb + 1, device=dev) * B, max=E) - 1
