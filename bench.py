@@ -169,11 +169,8 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
                         t0_ = time.perf_counter()
                     s = slice(b * B, (b + 1) * B)
                     s_d, d_d, n_d, t_d = rp._to_device(src[s], dst[s], neg[s], t[s])
-                    t2 = t_d.repeat(2)
-                    s2 = s_d.repeat(2)
                     for other in (d_d, n_d):
-                        neigh = smp.sample_device(torch.cat([s_d, other]), t2, K, with_edges=False)[0]
-                        rp.get_pair_wise_feature_anchored(neigh, s2, other.repeat(2))
+                        rp.encoder_pair_features(smp, s_d, other, t_d, K)
                     rp.get_pair_wise_feature(src[s], dst[s])
                     rp.get_pair_wise_feature(src[s], neg[s])
                     rp.update(src[s], dst[s], t[s])
@@ -182,8 +179,8 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
             return {"value": nbe * B / el_, "unit": "edges/s", "us_per_batch": el_ / nbe * 1e6, "what": label}
         if _lib_anchored_ok(rp):
             res["encoder_level_device"] = device_loop(
-                f"ids resident on the device: 1 pinned copy of the batch + 2 x (device sampler, K = {K}; anchored readout of "
-                f"4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls")
+                f"ids resident on the device: 1 pinned copy of the batch + 2 x encoder_pair_features (device sampler, K = {K}; "
+                f"anchored readout of 4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls")
             if rp.num_layer == 3:
                 rp.fused_mlp = True
                 try:

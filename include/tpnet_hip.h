@@ -344,6 +344,19 @@ int tpnet_sampler_build(void* sampler, size_t sampler_bytes, const int64_t* src,
 int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const int64_t* node_ids, const double* times,
                         int64_t n, int32_t K, int64_t* out_ids, int64_t* out_eids, double* out_times, void* stream);
 
+/* The encoder's readout with the ids resident on the device end to end (models/TPNet.py:280-324, SURVEY §8 f-3 -> f-2): for one
+ * (src, other) batch of B edges -- other = dst or the negatives -- the 2B nodes [src; other] at times tile(t, 2) draw their K most
+ * recent neighbours from the device sampler, and every neighbour is paired with the edge's two endpoints: out[0][(i*K + k)] =
+ * G(neigh[i][k], src[i % B]), out[1][...] = G(neigh[i][k], other[i % B]), i in [0, 2B) -- the reference's
+ * get_pair_wise_feature(tile(neigh, 2), concat(repeat(tile(src,2),K), repeat(tile(other,2),K))) before self.mlp, without any index
+ * array and without the neighbour ids visiting the host.  One call, three launches.  scratch: tpnet_encoder_scratch_bytes(B, K)
+ * device bytes; the sampled neighbour ids [2B][K] (int64) are left at (scratch rounded up to 256) + 64 B bytes for the caller's
+ * other neighbour features.  Needs tpnet_pair_gram_anchored_supported(st).  src / other / t: device arrays of B. */
+size_t tpnet_encoder_scratch_bytes(int64_t B, int32_t K);
+int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
+                       const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
+                       uint32_t flags, void* scratch, size_t scratch_bytes, float* out, void* stream);
+
 /* ---- the step behind the path (BASELINE config 5): self.mlp = Linear(64,256)->ReLU->Linear(256,64)
  * (models/TPNet.py:64-65,129) fused in one kernel on the bf16 matrix cores, fp32 accumulate, L = 3 only.
  * x [n][64] f32 (the readout's features), y [n][64] f32.  w1_bf16: [256][64] bf16 = mlp[0].weight; w2p_bf16: [64][256]

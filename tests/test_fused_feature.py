@@ -293,3 +293,37 @@ def test_feature_on_the_fp32_matrix_cores(d):
         u, v = rng.randint(0, N, 4099).astype(np.int64), rng.randint(0, N, 4099).astype(np.int64)
         assert torch.equal(rq.get_pair_wise_feature(u, v), rq.mlp(rq.pair_gram(u, v)))
     rp.check_device_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,L,K", [(128, 3, 20), (256, 3, 7), (64, 2, 4)])
+def test_encoder_call_with_device_resident_ids(d, L, K):
+    """encoder_pair_features (row set-up + device sampler + anchored readout in one call, self.mlp behind it) against the
+    reference's own sequence on host arrays: NeighborSampler('recent').get_historical_neighbors(concat(src, other), tile(t, 2))
+    then get_pair_wise_feature(tile(neigh, 2), concat(repeat(tile(src, 2), K), repeat(tile(other, 2), K)))
+    (models/TPNet.py:280-316) -- same neighbours, same features, same row order."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd.callers import RecentNeighborSampler, encoder_pair_indices
+    from tpnet_amd.sampler import GpuRecentNeighborSampler
+    rng = np.random.RandomState(d + K)
+    N, E, B = 300, 900, 60
+    src = rng.randint(1, N, E).astype(np.int64)
+    dst = rng.randint(1, N, E).astype(np.int64)
+    t = np.sort(rng.uniform(1.0e6, 1.4e6, E))
+    rp = _module(N, d, L)
+    host = RecentNeighborSampler(src, dst, t)
+    gpu = GpuRecentNeighborSampler(src, dst, t, device="cuda:0", num_nodes=N)
+    for b0 in range(0, E - B, B):
+        s = slice(b0, b0 + B)
+        if b0 >= 5 * B:
+            other = rng.randint(1, N, B).astype(np.int64)
+            neigh_h, _, _ = host.get_historical_neighbors(np.concatenate([src[s], other]), np.tile(t[s], 2), K)
+            u, v = encoder_pair_indices(neigh_h, src[s], other)
+            want = rp.get_pair_wise_feature(u, v)
+            dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+            got, neigh_d = rp.encoder_pair_features(gpu, dev(src[s]), dev(other), dev(t[s]), K)
+            np.testing.assert_array_equal(neigh_d.cpu().numpy(), neigh_h)
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-4, atol=2e-4)
+        rp.update(src[s], dst[s], t[s])
+    rp.check_device_errors()

@@ -89,6 +89,9 @@ SIGNATURES = {
     "tpnet_sampler_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_sampler_build": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "tpnet_sample_recent": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    "tpnet_encoder_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "tpnet_encoder_gram": (C.c_int, [_SP, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                     C.c_uint32, _P, C.c_size_t, _P, _P]),
     "tpnet_mlp64_bf16": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "tpnet_mlp64_bwd_partial_floats": (C.c_int64, []),
     "tpnet_mlp64_bwd_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P]),

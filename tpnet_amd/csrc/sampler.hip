@@ -102,6 +102,21 @@ __global__ void k_sample_recent(const int64_t* __restrict__ row_start, const int
     }
 }
 
+// the encoder's rows for one (src, other) batch (models/TPNet.py:280-316): nodes = [src; other], times = tile(t, 2), and the
+// two anchors of row i = the edge's endpoints (src[i % B], other[i % B])
+__global__ void k_encoder_rows(const int64_t* __restrict__ src, const int64_t* __restrict__ other, const double* __restrict__ t,
+                               int64_t B, int64_t* __restrict__ nodes, double* __restrict__ t2, int64_t* __restrict__ a1,
+                               int64_t* __restrict__ a2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i < B ? i : i - B;
+        const int64_t s = src[e], o = other[e];
+        nodes[i] = i < B ? s : o;
+        t2[i] = t[e];
+        a1[i] = s;
+        a2[i] = o;
+    }
+}
+
 }  // namespace tpnet
 
 using namespace tpnet;
@@ -189,6 +204,37 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
                        v.nbr_t, num_nodes, node_ids, times, n, (int)K, out_ids, out_eids, out_times);
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
+}
+
+size_t tpnet_encoder_scratch_bytes(int64_t B, int32_t K) {
+    if (B < 0) B = 0;
+    if (K < 1) K = 1;
+    return (size_t)(8 * B + 2 * B * (int64_t)K) * 8 + 256;
+}
+
+int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
+                       const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
+                       uint32_t flags, void* scratch, size_t scratch_bytes, float* out, void* stream) {
+    if (!st || !sampler || B < 0 || K < 1 || num_nodes < 1 || (B > 0 && (!src || !other || !t || !scratch || !out)))
+        return TPNET_ERR_BAD_ARG;
+    if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
+    if (B == 0) return TPNET_OK;
+    if (scratch_bytes < tpnet_encoder_scratch_bytes(B, K)) return TPNET_ERR_WORKSPACE;
+    if (!tpnet_pair_gram_anchored_supported(st)) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* nodes = (int64_t*)(((size_t)scratch + 255) / 256 * 256);
+    double* t2 = (double*)(nodes + 2 * B);
+    int64_t* a1 = (int64_t*)(t2 + 2 * B);
+    int64_t* a2 = a1 + 2 * B;
+    int64_t* neigh = a2 + 2 * B;
+    int g0 = (int)((2 * B + 255) / 256);
+    if (g0 > 1024) g0 = 1024;
+    hipLaunchKernelGGL(k_encoder_rows, dim3(g0), dim3(256), 0, s, src, other, t, B, nodes, t2, a1, a2);
+    int rc = tpnet_sample_recent(sampler, E, num_nodes, nodes, t2, 2 * B, K, neigh, nullptr, nullptr, stream);
+    if (rc) return rc;
+    const int NN = 2 * st->L + 2;
+    return tpnet_pair_gram_anchored(st, neigh, a1, a2, 2 * B, K, now_time, lambda, flags, out,
+                                    out + (size_t)(2 * B) * (size_t)K * (size_t)(NN * NN), stream);
 }
 
 }  // extern "C"

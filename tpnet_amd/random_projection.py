@@ -683,6 +683,32 @@ class RandomProjectionModule(nn.Module):
         g = self.pair_gram_anchored(neighbor_ids, first_anchor_ids, second_anchor_ids)
         return self._apply_mlp(g.view(-1, self.pair_wise_feature_dim))
 
+    def encoder_pair_features(self, sampler, src_ids: torch.Tensor, other_ids: torch.Tensor, times: torch.Tensor,
+                              num_neighbors: int):
+        """Extension: the encoder's whole readout for one (src, other) batch with the ids resident on the device
+        (models/TPNet.py:280-324): `sampler` = a GpuRecentNeighborSampler, src_ids / other_ids int64 [B] and times float64 [B] on
+        the device.  Returns (features [4*B*K, (2L+2)^2] in the reference's row order with self.mlp applied, neighbour ids
+        [2B, K] on the device).  One FFI call = row set-up + neighbour sampling + anchored readout; self.mlp behind it."""
+        self._ensure_engine()
+        dev = self._dev()
+        B, K = int(src_ids.numel()), int(num_neighbors)
+        for name, x, dt in (("src_ids", src_ids, torch.int64), ("other_ids", other_ids, torch.int64), ("times", times, torch.float64)):
+            if x.device != dev or x.dtype != dt or x.dim() != 1 or x.numel() != B or not x.is_contiguous():
+                raise ValueError(f"encoder_pair_features: {name} must be a contiguous {dt} tensor of {B} elements on {dev}")
+        lib = _lib.load()
+        NG = self.pair_wise_feature_dim
+        nbytes = lib.tpnet_encoder_scratch_bytes(B, K)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((2, 2 * B * K, NG), dtype=torch.float32, device=dev)
+        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        _lib.check(lib.tpnet_encoder_gram(self._st_ref(), sampler._buf.data_ptr(), sampler.E, sampler.num_nodes, src_ids.data_ptr(),
+                                          other_ids.data_ptr(), times.data_ptr(), B, K, self._now_host,
+                                          float(self.time_decay_weight), flags, scratch.data_ptr(), nbytes, out.data_ptr(),
+                                          _raw_stream(self._eng["dev_index"])), "encoder_gram")
+        off = (-scratch.data_ptr()) % 256 + 64 * B
+        neigh = scratch[off: off + 16 * B * K].view(torch.int64).view(2 * B, K)
+        return self._apply_mlp(out.view(-1, NG)), neigh
+
     @staticmethod
     def _anchor_runs(half):
         """If `half` is repeat(anchors, K) for some K >= 2 (np.repeat of the encoder's call): (anchors, K); else None.
