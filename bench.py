@@ -253,7 +253,7 @@ def main():
             if rank == 0:
                 print(json.dumps({"metric": "temporal edges/sec (proj-update + pairwise readout)", "value": None,
                                   "unit": "edges/s", "n_gpus": world, "error": "multi-GPU run did not finish in time "
-                                  "(watchdog); set TPNET_ROWS_C_LOOP=0 to route the exchange through torch.distributed"}),
+                                  "(watchdog); set TPNET_ROWS_C_LOOP=0 to route the exchange through torch.distributed, TPNET_BENCH_EXCHANGE=allgather for the all-gather variant"}),
                       flush=True)
             os._exit(3)
         _wd = threading.Timer(float(os.environ.get("TPNET_BENCH_WATCHDOG", "420")), _give_up)
@@ -330,6 +330,9 @@ def main():
         from tpnet_amd.sharded import ShardedStreamRunner
         runner = ShardedStreamRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L, time_decay_weight=cfg["lam"],
                                             device=dev, beginning_time=np.float64(0.0), halo_rows=3 * Bg)
+        # targeted exchange (every row only to the ranks that read it, received in place, grouped ncclSend / ncclRecv from C);
+        # TPNET_BENCH_EXCHANGE=allgather: one all-gather of every touched row per step
+        runner.exchange = os.environ.get("TPNET_BENCH_EXCHANGE", "targeted")
         runner.rp._workspace(max(k_steps, W) * Bg, Bg)
 
         def run(a, b_):
@@ -389,8 +392,8 @@ def main():
                    f"per-step collective; the 36 distinct raw Gram entries per pair are reduce-scattered (RCCL) per "
                    f"chunk of ~2M edges behind the next chunk's kernels",
            "rows": f"rows sharded over {world} GPUs (owner = id % {world}; every GPU holds only its {(N + world - 1) // world} "
-                   f"rows of all {L + 1} layers + {3 * Bg} halo rows), global batch {Bg} = {B} per GPU, one RCCL "
-                   f"all-gather of the touched rows' bundles per step"}[shard]
+                   f"rows of all {L + 1} layers + {3 * Bg} halo rows), global batch {Bg} = {B} per GPU, per step one grouped RCCL "
+                   f"send / recv of the rows each peer reads, received in place ({os.environ.get('TPNET_BENCH_EXCHANGE', 'targeted')} exchange)"}[shard]
 
     def emit(row_info=None, roof=None, cpu=None, dropin=None, extra=None):
         line = {

@@ -331,6 +331,23 @@ int tpnet_rows_step(const tpnet_state* st, void* comm, const int64_t* pack_ids, 
                     int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
                     float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream);
 
+/* The same batch with the TARGETED exchange: every owned row travels only to the ranks that read it, as two
+ * messages (layer 0; layers 1..L decayed to now_time) that the reader receives STRAIGHT INTO the halo rows of its p0 and q
+ * arrays -- so a sharded batch is two launches (pack, step) around one grouped ncclSend / ncclRecv, with no unpack.
+ *   pack_ids:  device int64, the LOCAL rows to send, ordered by (reader rank, node): send_cnt[r] of them for rank r;
+ *   send_cnt / recv_cnt: HOST int64[G] (entry `me` = 0); the rows from rank r land in halo rows
+ *              [n_owned + sum(recv_cnt[:r]), ...) in the sender's order -- the local ids the caller relabelled the batch with;
+ *   send_p0 [sum(send_cnt)][d], send_q [sum(send_cnt)][L*d]: device scratch.
+ * tpnet_pack_split is the pack launch alone (a caller that moves the rows with another transport, e.g. the gloo tests): it
+ * also stamps halo rows [halo0, halo0 + n_halo) as "as of now_time". */
+int tpnet_pack_split(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out_p0,
+                     float* out_q, int64_t halo0, int64_t n_halo, void* stream);
+int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, float* send_p0, float* send_q,
+                             const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G, int32_t me, double now_time,
+                             const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
+                             int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
+                             float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
  * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,
  * per node sorted by time (stable: ties keep the reference's append order), neighbours strictly BEFORE the query

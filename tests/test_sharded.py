@@ -543,3 +543,85 @@ def test_column_runner_chunk_bounds_properties(E, B, kw):
     if "chunk_steps" not in kw:
         a, b = bounds[-1]
         assert (b - a + B - 1) // B < 2 * 64
+
+
+# =========================================================================================================
+# BASELINE config 4 at full table size: the row-sharded runner with two ranks on ONE GPU (2 x 36 GB + halos)
+# =========================================================================================================
+def _c4_worker(rank, world, port, exchange, q):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        import tpnet_amd
+        from tpnet_amd.sharded import ShardedStreamRunner
+        from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
+        c = CONFIGS["C4"]
+        N, d, lam, L = c["U"] + c["I"] + 1, c["d"], c["lam"], 3
+        B, E = 10_000, 3 * 10_000 + 2_500
+        src, dst, t, N_ = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
+        neg = synthetic_negatives(c["U"], N, E, B, 1)
+        assert N_ == N == 10_000_001
+        dev = torch.device("cuda:0")
+        runner = ShardedStreamRunner.create(node_num=N, edge_num=c["E"], dim=d, num_layer=L, time_decay_weight=lam, device=dev,
+                                            beginning_time=np.float64(0.0), halo_rows=3 * B, seed=11, draw_on_device=True)
+        runner.exchange = exchange
+        n_cap = (N + world - 1) // world
+        assert runner.rp.node_num == n_cap + 3 * B                       # the shard holds N/G + halo rows, not N
+        D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        fp, fn = runner.run_stream(D(src), D(dst), D(neg), D(t), B)
+        runner.rp.check_device_errors()
+        # a sample of the touched rows this rank owns, all layers (no 41 GB materialisation)
+        touched = np.unique(np.concatenate([src, dst]))
+        sample = touched[np.random.RandomState(3).permutation(len(touched))[:4000]]
+        mine = sample[sample % world == rank]
+        rows = torch.stack(runner.rp.get_random_projections(mine // world)).cpu().numpy()      # local row = id // G
+        shard_bytes = runner.table_bytes()
+        if rank == 0:
+            ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=c["E"], dim_factor=10, num_layer=L, time_decay_weight=lam,
+                                                   device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0),
+                                                   not_scale=False, enforce_dim=d, alloc_device=dev).to(dev)
+            for r in range(world):                                       # the full layer 0 = the ranks' rows interleaved
+                own = ref.random_projections[0].data[r::world]
+                own.copy_(ShardedStreamRunner.draw_rows(11, r, n_cap, d, dev)[:own.shape[0]])
+            rfp, rfn = ref.run_stream(D(src), D(dst), D(neg), D(t), B, schedule="batch")
+            rrows = torch.stack(ref.get_random_projections(sample)).cpu().numpy()
+            scale = float(np.abs(rrows[1:]).max())
+            q.put(("cmp", float((fp - rfp).abs().max()), float((fn - rfn).abs().max()), scale, shard_bytes,
+                   N * d * 4 * (1 + 2 * L) + 32 * N, float(runner.rp.now_time.item()) == float(t[-1])))
+            q.put(("ref", sample, rrows))
+        q.put(("rows", rank, mine, rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["targeted"])
+def test_row_sharded_c4_table_two_ranks_on_one_gpu(exchange):
+    """BASELINE config 4 ("10 M nodes ... row-sharded"): N = 10 000 001 rows of d = 256, three batches of 10 000 edges and a
+    ragged one, two gloo ranks sharing cuda:0 -- each holds 5 M rows of all layers (36 GB) + 30 000 halo rows -- against the
+    single-GPU run on the full table: features of every edge, and all layers of a sample of the touched rows."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    if torch.cuda.get_device_properties(0).total_memory < 200e9:
+        pytest.skip("needs ~150 GB of device memory (two 36 GB shards + the 72 GB control)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    msgs = [q.get(timeout=900) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=300)
+    cmp = [m for m in msgs if m[0] == "cmp"][0]
+    ref = [m for m in msgs if m[0] == "ref"][0]
+    assert cmp[1] < 2e-4 and cmp[2] < 2e-4 and cmp[6], cmp
+    assert cmp[4] < 0.52 * cmp[5], cmp                                  # half the table (+ halo) per rank
+    sample, rrows = ref[1], ref[2]
+    for m in msgs:
+        if m[0] == "rows":
+            _, rank, mine, rows = m
+            pos = {int(x): i for i, x in enumerate(sample)}
+            want = rrows[:, [pos[int(x)] for x in mine]]
+            np.testing.assert_array_equal(rows[0], want[0])            # layer 0: the same draw
+            np.testing.assert_allclose(rows[1:], want[1:], rtol=1e-4, atol=1e-5 * cmp[3])

@@ -18,6 +18,10 @@ struct RcclApi {
     int (*comm_init_rank)(void**, int, void*, int) = nullptr;                      // resolved through a by-value shim below
     int (*comm_destroy)(void*) = nullptr;
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;      // ncclSend(buf, count, type, peer, comm, stream)
+    int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;            // ncclRecv
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
     void* init_sym = nullptr;
 };
 
@@ -37,7 +41,12 @@ static int rccl_load(const char* lib_path) {
     g_rccl.init_sym = dlsym(h, "ncclCommInitRank");
     g_rccl.comm_destroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
     g_rccl.all_gather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(h, "ncclAllGather"));
-    if (!g_rccl.get_unique_id || !g_rccl.init_sym || !g_rccl.comm_destroy || !g_rccl.all_gather) {
+    g_rccl.send = reinterpret_cast<int (*)(const void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclSend"));
+    g_rccl.recv = reinterpret_cast<int (*)(void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclRecv"));
+    g_rccl.group_start = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
+    g_rccl.group_end = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
+    if (!g_rccl.get_unique_id || !g_rccl.init_sym || !g_rccl.comm_destroy || !g_rccl.all_gather || !g_rccl.send || !g_rccl.recv ||
+        !g_rccl.group_start || !g_rccl.group_end) {
         dlclose(h);
         return TPNET_ERR_NO_DEVICE;
     }
@@ -100,6 +109,62 @@ int tpnet_rows_step(const tpnet_state* st, void* comm, const int64_t* pack_ids, 
         if (g_rccl.all_gather(send, recv, (size_t)maxc * bundle, kNcclFloat32, comm, s) != 0) return TPNET_ERR_HIP;
         rc = launch_unpack_bundles(*st, unpack_ids, n_unpack, now_time, recv, maxc, offs, G, s);
         if (rc) return rc;
+    }
+    return tpnet_step_batch(st, src, dst, neg, t, E, batch, b, lambda, launch_id, flags, 0, n_owned, out_pos, out_neg,
+                            workspace, ws_bytes, stream);
+}
+
+int tpnet_pack_split(const tpnet_state* st, const int64_t* ids, int64_t n, double now_time, double lambda, float* out_p0,
+                     float* out_q, int64_t halo0, int64_t n_halo, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (n < 0 || n_halo < 0 || halo0 < 0 || halo0 + n_halo > st->N || (n > 0 && (!ids || !out_p0 || !out_q))) return TPNET_ERR_BAD_ARG;
+    return launch_pack_split(*st, ids, n, now_time, lambda, out_p0, out_q, halo0, n_halo, (hipStream_t)stream);
+}
+
+int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, float* send_p0, float* send_q,
+                             const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G, int32_t me, double now_time,
+                             const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
+                             int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
+                             float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream) {
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (G < 1 || me < 0 || me >= G || n_owned < 0 || n_owned > st->N) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (comm && G > 1) {
+        if (!g_rccl.handle || !send_cnt || !recv_cnt) return TPNET_ERR_BAD_ARG;
+        int64_t ns = 0, nr = 0;
+        for (int r = 0; r < G; ++r) {
+            if (send_cnt[r] < 0 || recv_cnt[r] < 0 || (r == me && (send_cnt[r] || recv_cnt[r]))) return TPNET_ERR_BAD_ARG;
+            ns += send_cnt[r];
+            nr += recv_cnt[r];
+        }
+        if (n_owned + nr > st->N) return TPNET_ERR_WORKSPACE;            // more rows to receive than the shard has halo rows
+        if (ns > 0 && (!pack_ids || !send_p0 || !send_q)) return TPNET_ERR_BAD_ARG;
+        int rc = launch_pack_split(*st, pack_ids, ns, now_time, lambda, send_p0, send_q, n_owned, nr, s);
+        if (rc) return rc;
+        // every row travels only to the ranks that read it, and lands where the step kernel reads it: the halo rows of p0 and
+        // of copy 0 of q (halo rows are never targets, so their current copy stays 0)
+        const size_t d = (size_t)st->d, Ld = (size_t)st->L * d;
+        float* halo_p0 = st->p0 + (size_t)n_owned * d;
+        float* halo_q = st->q + (size_t)n_owned * Ld;
+        int bad = 0;
+        bad |= g_rccl.group_start();
+        size_t so = 0, ro = 0;
+        for (int r = 0; r < G; ++r) {
+            if (send_cnt[r]) {
+                bad |= g_rccl.send(send_p0 + so * d, (size_t)send_cnt[r] * d, kNcclFloat32, r, comm, s);
+                bad |= g_rccl.send(send_q + so * Ld, (size_t)send_cnt[r] * Ld, kNcclFloat32, r, comm, s);
+                so += (size_t)send_cnt[r];
+            }
+            if (recv_cnt[r]) {
+                bad |= g_rccl.recv(halo_p0 + ro * d, (size_t)recv_cnt[r] * d, kNcclFloat32, r, comm, s);
+                bad |= g_rccl.recv(halo_q + ro * Ld, (size_t)recv_cnt[r] * Ld, kNcclFloat32, r, comm, s);
+                ro += (size_t)recv_cnt[r];
+            }
+        }
+        bad |= g_rccl.group_end();
+        if (bad) return TPNET_ERR_HIP;
     }
     return tpnet_step_batch(st, src, dst, neg, t, E, batch, b, lambda, launch_id, flags, 0, n_owned, out_pos, out_neg,
                             workspace, ws_bytes, stream);

@@ -288,6 +288,49 @@ __global__ void k_unpack_bundles(tpnet_state S, const int64_t* __restrict__ loca
     }
 }
 
+// pack for the TARGETED exchange: layer 0 and layers 1..L of row ids[k] go to two buffers (what the peers receive straight
+// into the halo rows of their p0 and q arrays: no unpack launch on the other side); the blocks behind the n rows stamp the
+// n_halo halo rows this rank is about to receive as "as of `now`" (the received layers are decayed to the batch's clock)
+__global__ void k_pack_split(tpnet_state S, const int64_t* __restrict__ ids, int64_t n, double now, double lambda,
+                             float* __restrict__ out_p0, float* __restrict__ out_q, int64_t halo0, int64_t n_halo) {
+    const int64_t d = S.d, L = S.L;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    if ((int64_t)blockIdx.x >= n) {
+        const int64_t j = ((int64_t)blockIdx.x - n) * blockDim.x + threadIdx.x;
+        if (j < n_halo && halo0 + j < S.N) {
+            NodeMeta* m = meta + halo0 + j;
+            m->tref[m->ver & 1u] = now;
+        }
+        return;
+    }
+    const int64_t k = blockIdx.x;
+    int64_t id = ids[k];
+    if ((uint64_t)id >= (uint64_t)S.N) {
+        if (threadIdx.x == 0) atomicAdd(S.err, 1u);
+        id = 0;
+    }
+    const MetaView m = read_meta(meta, id, READER_BID, now, lambda);
+    const float* qb = S.q + ((int64_t)m.copy * S.N + id) * (L * d);
+    for (int64_t r = threadIdx.x; r < d; r += blockDim.x) out_p0[k * d + r] = S.p0[id * d + r];
+    for (int64_t r = threadIdx.x; r < L * d; r += blockDim.x) {
+        const int64_t i = r / d;
+        float g = m.g;
+        for (int64_t z = 0; z < i; ++z) g *= m.g;
+        out_q[k * (L * d) + r] = qb[r] * g;
+    }
+}
+
+int launch_pack_split(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out_p0,
+                      float* out_q, int64_t halo0, int64_t n_halo, hipStream_t s) {
+    const int64_t hb = (n_halo + 255) / 256;
+    if (n + hb == 0) return TPNET_OK;
+    if (n + hb > 0x7FFFFFFF) return TPNET_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_pack_split, dim3((unsigned)(n + hb)), dim3(256), 0, s, st, ids, n, now, lambda, out_p0, out_q, halo0,
+                       n_halo);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
 int launch_pack_bundles(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
                         hipStream_t s) {
     if (n == 0) return TPNET_OK;

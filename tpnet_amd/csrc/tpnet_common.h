@@ -155,6 +155,8 @@ int launch_unpack_gathered(const tpnet_state& st, const int64_t* ids, int64_t n,
 int launch_unpack_rows(const tpnet_state& st, const int64_t* ids, int64_t n, double now, const float* in, hipStream_t s);
 int launch_pack_bundles(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out,
                         hipStream_t s);
+int launch_pack_split(const tpnet_state& st, const int64_t* ids, int64_t n, double now, double lambda, float* out_p0,
+                      float* out_q, int64_t halo0, int64_t n_halo, hipStream_t s);
 int launch_unpack_bundles(const tpnet_state& st, const int64_t* local_ids, int64_t n, double now, const float* recv,
                           int64_t maxc, const int64_t* offs, int G, hipStream_t s);
 

@@ -126,8 +126,8 @@ class ShardedStreamRunner:
     targets / pair sources the rank owns (tpnet_step_batch, own_mod = 0).  Memory per rank: (n_cap + H) rows instead of N.
     """
 
-    exchange = "allgather"     # "allgather" (v1: every touched row to every rank, RCCL from C) | "targeted" (v2: each row only to
-                               # the ranks that read it, all_to_all through torch.distributed; see run_stream_targeted)
+    exchange = "allgather"     # "allgather" (v1: every touched row to every rank) | "targeted" (v2: each row only to the ranks
+                               # that read it, received in place: run_stream_targeted); both with RCCL called from C
 
     def __init__(self, rp_local, node_num: int, halo_rows: int, group=None):
         self.rp = rp_local
@@ -143,7 +143,8 @@ class ShardedStreamRunner:
     # ---- construction -------------------------------------------------------------------------------------------
     @classmethod
     def create(cls, node_num: int, edge_num: int, dim: int, num_layer: int, time_decay_weight: float, device,
-               beginning_time, halo_rows: int, not_scale: bool = False, group=None, seed: int = 0):
+               beginning_time, halo_rows: int, not_scale: bool = False, group=None, seed: int = 0,
+               draw_on_device: bool = False):
         """Build the local shard.  `halo_rows` >= the distinct remote nodes one batch can touch (3 * batch is always enough).
         P[0] ~ N(0, 1/sqrt(dim)) (models/TPNet.py:58): each rank draws its own rows from a generator seeded with (seed,
         rank); tests inject a full matrix with set_full_p0."""
@@ -155,11 +156,21 @@ class ShardedStreamRunner:
                                     beginning_time=beginning_time, not_scale=not_scale, enforce_dim=dim,
                                     alloc_device=device)
         self = cls(rp.to(device), node_num, halo_rows, group)
-        gen = torch.Generator().manual_seed(seed * 1021 + self.me)
         p0 = self.rp._plist()[0]
-        p0.data[:self.n_cap].copy_(torch.normal(0.0, 1.0 / np.sqrt(dim), (self.n_cap, dim), generator=gen).to(p0.device))
+        if draw_on_device:         # (a 10 M-row shard: 5 GB of normals that need not pass through host memory)
+            p0.data[:self.n_cap].copy_(cls.draw_rows(seed, self.me, self.n_cap, dim, p0.device))
+        else:
+            gen = torch.Generator().manual_seed(seed * 1021 + self.me)
+            p0.data[:self.n_cap].copy_(torch.normal(0.0, 1.0 / np.sqrt(dim), (self.n_cap, dim), generator=gen).to(p0.device))
         p0.data[self.n_cap:].zero_()
         return self
+
+    @staticmethod
+    def draw_rows(seed: int, rank: int, n_rows: int, dim: int, device):
+        """The layer-0 rows rank `rank` draws with draw_on_device (same device, seed and shape -> same values: what a
+        single-GPU control run re-assembles the full matrix from)."""
+        gen = torch.Generator(device=device).manual_seed(seed * 1021 + rank)
+        return torch.normal(0.0, 1.0 / np.sqrt(dim), (n_rows, dim), generator=gen, device=device)
 
     def owned_nodes(self):
         return torch.arange(self.me, self.N, self.G, dtype=torch.int64, device=self.rp._dev())
@@ -400,9 +411,10 @@ class ShardedStreamRunner:
 
     def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
         """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
-        all-to-all with per-peer counts (RCCL: ncclSend / ncclRecv pairs under torch.distributed.all_to_all_single; gloo in
-        the tests: an all-gather of the send buffers from which every rank takes its parts), unpack into the halo, step.
-        Same results as the all-gather variant; each rank receives only what its own pairs and targets read."""
+        grouped ncclSend / ncclRecv issued from C (tpnet_rows_step_targeted) whose receives land straight in the halo rows of
+        the local table, step -- two launches and one FFI call per batch.  (Without the C communicator: the same pack launch,
+        torch.distributed.all_to_all_single into the same rows; gloo in the tests: an all-gather of the send buffers from which
+        every rank takes its parts.)  Same results as the all-gather variant; each rank receives only what it reads."""
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
@@ -431,52 +443,77 @@ class ShardedStreamRunner:
         _lib.check(lib.tpnet_plan_stream(C.byref(st), ls.data_ptr(), ld.data_ptr(), t.data_ptr(), E, B, rp._now_host,
                                          lam, flags, ws.data_ptr(), ws.numel(), stream), "plan_stream")
         lid0 = rp._next_launch_ids(nb)
-        scnt, rcnt = R["send_cnt"], R["recv_cnt"]
+        scnt, rcnt = np.ascontiguousarray(R["send_cnt"]), np.ascontiguousarray(R["recv_cnt"])
         stot, rtot = scnt.sum(axis=1), R["rtot"]
         sstart = np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
-        send = torch.zeros((max(int(stot.max()), 1), bundle), dtype=torch.float32, device=dev)
-        recv = torch.empty((max(int(rtot.max()), 1), bundle), dtype=torch.float32, device=dev)
-        zero_off = torch.zeros(1, dtype=torch.int64, device=dev)
+        n_cap = self.n_cap
+        # the rows a peer reads leave as two messages (layer 0; layers 1..L) and arrive STRAIGHT in the reader's halo rows of p0 and
+        # of copy 0 of q: pack -> grouped send / recv -> step, no unpack launch (halo rows are never targets: their copy stays 0)
+        smax = max(int(stot.max()), 1)
+        send_p0 = torch.zeros((smax, d), dtype=torch.float32, device=dev)
+        send_q = torch.zeros((smax, L * d), dtype=torch.float32, device=dev)
         nccl = G > 1 and dist.get_backend(self.group) == "nccl"
-        if G > 1 and not nccl:
-            # gloo (tests): every rank needs everybody's per-reader counts to cut the gathered send buffers
-            all_scnt = [None] * G
-            dist.all_gather_object(all_scnt, scnt, group=self.group)
-            smax = max(int(a.sum(axis=1).max()) for a in all_scnt)
-            gathered = [torch.empty((max(smax, 1), bundle), dtype=torch.float32, device=dev) for _ in range(G)]
-            padded = torch.zeros((max(smax, 1), bundle), dtype=torch.float32, device=dev)
-        now = rp._now_host
         stp = C.byref(st)
-        for b in range(nb):
-            ns, nr = int(stot[b]), int(rtot[b])
-            if G > 1 and (ns or nr or not nccl):
-                if ns:
-                    _lib.check(lib.tpnet_pack_bundles(stp, R["pack_ids"].data_ptr() + 8 * int(sstart[b]), ns, now, lam,
-                                                      send.data_ptr(), stream), "pack_bundles")
+        pack_ptr = R["pack_ids"].data_ptr()
+        ls_p, ld_p, t_p = ls.data_ptr(), ld.data_ptr(), t.data_ptr()
+        ln_p = ln.data_ptr() if ln is not None else None
+        op_p = out_pos.data_ptr(); on_p = out_neg.data_ptr() if out_neg is not None else None
+        ws_p, ws_n = ws.data_ptr(), ws.numel()
+        t_last_l = [float(x) for x in t_last]
+        now = rp._now_host
+        comm = self._c_comm() if nccl else None
+        if comm is not None or G == 1:
+            # RCCL from C: ONE call per batch = pack + grouped ncclSend / ncclRecv + step, enqueued on the current stream
+            rows_step = lib.tpnet_rows_step_targeted
+            sc_p, rc_p = scnt.ctypes.data, rcnt.ctypes.data
+            for b in range(nb):
+                rc = rows_step(stp, comm, pack_ptr + 8 * int(sstart[b]), send_p0.data_ptr(), send_q.data_ptr(), sc_p + 8 * G * b,
+                               rc_p + 8 * G * b, G, me, now, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, n_cap, op_p,
+                               on_p, ws_p, ws_n, stream)
+                if rc:
+                    _lib.check(rc, "rows_step_targeted")
+                now = t_last_l[b]
+        else:
+            # another transport (torch.distributed all_to_all on RCCL without the C communicator; gloo in the tests): the same
+            # pack launch, the rows moved into the same halo rows, the same step
+            p0_t = rp._plist()[0].data                                       # [n_cap + H, d]
+            q_t = rp._eng["q"].view(2, rp.node_num, L * d)                   # copy 0 receives
+            if not nccl:
+                all_scnt = [None] * G
+                dist.all_gather_object(all_scnt, scnt, group=self.group)
+                gmax = max(max(int(a.sum(axis=1).max()) for a in all_scnt), 1)
+                g_p0 = [torch.empty((gmax, d), dtype=torch.float32, device=dev) for _ in range(G)]
+                g_q = [torch.empty((gmax, L * d), dtype=torch.float32, device=dev) for _ in range(G)]
+                pad_p0 = torch.zeros((gmax, d), dtype=torch.float32, device=dev)
+                pad_q = torch.zeros((gmax, L * d), dtype=torch.float32, device=dev)
+            for b in range(nb):
+                ns, nr = int(stot[b]), int(rtot[b])
+                _lib.check(lib.tpnet_pack_split(stp, pack_ptr + 8 * int(sstart[b]), ns, now, lam, send_p0.data_ptr(),
+                                                send_q.data_ptr(), n_cap, nr, stream), "pack_split")
                 if nccl:
-                    dist.all_to_all_single(recv[:nr], send[:ns], output_split_sizes=rcnt[b].tolist(),
+                    dist.all_to_all_single(p0_t[n_cap:n_cap + nr], send_p0[:ns], output_split_sizes=rcnt[b].tolist(),
+                                           input_split_sizes=scnt[b].tolist(), group=self.group)
+                    dist.all_to_all_single(q_t[0, n_cap:n_cap + nr], send_q[:ns], output_split_sizes=rcnt[b].tolist(),
                                            input_split_sizes=scnt[b].tolist(), group=self.group)
                 else:
-                    padded[:ns].copy_(send[:ns])
-                    dist.all_gather(gathered, padded, group=self.group)
+                    pad_p0[:ns].copy_(send_p0[:ns]); pad_q[:ns].copy_(send_q[:ns])
+                    dist.all_gather(g_p0, pad_p0, group=self.group)
+                    dist.all_gather(g_q, pad_q, group=self.group)
                     o = 0
                     for s_ in range(G):                  # rows owner s_ packed for me: after what it packed for readers < me
                         c = int(rcnt[b][s_])
                         if c:
                             a0 = int(all_scnt[s_][b][:me].sum())
-                            recv[o:o + c].copy_(gathered[s_][a0:a0 + c])
+                            p0_t[n_cap + o:n_cap + o + c].copy_(g_p0[s_][a0:a0 + c])
+                            q_t[0, n_cap + o:n_cap + o + c].copy_(g_q[s_][a0:a0 + c])
                             o += c
-                if nr:
-                    _lib.check(lib.tpnet_unpack_bundles(stp, R["unpack_ids"].data_ptr() + 8 * int(R["rstart"][b]), nr, now,
-                                                        recv.data_ptr(), nr, zero_off.data_ptr(), 1, stream), "unpack_bundles")
-            _lib.check(lib.tpnet_step_batch(stp, ls.data_ptr(), ld.data_ptr(), ln.data_ptr() if ln is not None else None,
-                                            t.data_ptr(), E, B, b, lam, lid0 + b, flags, 0, self.n_cap, out_pos.data_ptr(),
-                                            out_neg.data_ptr() if out_neg is not None else None, ws.data_ptr(), ws.numel(),
-                                            stream), "step_batch")
-            now = float(t_last[b])
+                _lib.check(lib.tpnet_step_batch(stp, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, 0, n_cap, op_p, on_p,
+                                                ws_p, ws_n, stream), "step_batch")
+                now = t_last_l[b]
         rp._now_host = now
         rp._params_valid = False
         rp._now_dirty = True
+        rp._table_written()
         if G > 1 and merge_outputs:
             dist.all_reduce(out_pos, group=self.group)
             if out_neg is not None:
