@@ -120,7 +120,10 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
         if (rc) return rc;
         const bool have_readout = out_pos || out_neg;
         static const int no3 = TPNET_DEV_INT(NO_PLAN3, 0);
-        const bool plan3 = !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && wplan3_applies(st, Ec, batch, K);
+        // the hashed planner costs ~45 us + 0.76 us per batch, the sorted one ~200 us + 0.63 us per batch (C2, profiles/r03_C2.md):
+        // chunks of up to 768 batches take the first, longer ones the second
+        static const int max3 = TPNET_DEV_INT(PLAN3_MAX_BATCHES, 768);
+        const bool plan3 = !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && nb <= max3 && wplan3_applies(st, Ec, batch, K);
         // a plan may be replayed when the whole stream is ONE chunk and the caller vouches (tag) that the stream arrays and
         // the table's per-node state are what the plan in this workspace was built for
         PlanBuilt now{};
