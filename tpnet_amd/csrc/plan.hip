@@ -590,12 +590,14 @@ int wplan_window_batches(int64_t batch, int d, int L) {
 
 // Contributions per (node, window) above which a workgroup per column part walks the chain instead of one lane group: a lane
 // group keeps 8 rows in flight, so a chain of n contributions is n / 8 dependent memory round trips -- the latency floor of a
-// launch, which has to stay below the launch's bandwidth time, i.e. scale with the window (measured, tools/short_trace.sh:
-// 20 batches in 2 windows of 10 -> pipeline 127 us at 96, 85 us at 32; 24-batch windows of long streams: 96 as before).
-uint32_t wplan_heavy_threshold(int K) {
+// launch, which has to stay below the launch's bandwidth time, i.e. scale with the bytes of a window (batches x edges x row
+// length).  Measured (tools/short_trace.sh, tools/sweep_c1c5.sh): C2 (d=128) 20 batches in 2 windows: 127 us at 96, 85 us at 32;
+// C1 (d=64, B=200, windows of 64 batches): 198 M edges/s at 96, 281 M at 32; rows of 256 / 512 floats and the 24-batch
+// windows of long C2 streams: 96 (128: -0..10 %).
+uint32_t wplan_heavy_threshold(int K, int64_t batch, int d) {
     static const int env = TPNET_DEV_INT(WIN_HEAVY, 0);
     if (env > 0) return (uint32_t)env;
-    const int t = 4 * K;
+    const int64_t t = (int64_t)K * batch * d / 24576;
     return (uint32_t)(t < 16 ? 16 : (t > 96 ? 96 : t));
 }
 
@@ -670,7 +672,7 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
     out->wtab = take(wplan3_table_bytes(Ec));
     out->wzero_bytes = (size_t)(p - reinterpret_cast<char*>(out->wmask));
     out->wblk = (uint32_t*)take(wplan3_blk_bytes(Ec, batch));
-    out->heavy_thr = wplan_heavy_threshold(K);
+    out->heavy_thr = wplan_heavy_threshold(K, batch, d);
     out->chains = reinterpret_cast<Chain*>(out->base.light);
     out->chains_sparse = reinterpret_cast<Chain*>(out->base.heavy);
     // the second sort's keys live where the first sort's unsorted keys were (8 bytes per contribution, dead by then), its

@@ -287,7 +287,7 @@ size_t wplan3_blk_bytes(int64_t Ec, int64_t batch);
 int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                  const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
                  bool want_readout, bool replay, hipStream_t s);
-uint32_t wplan_heavy_threshold(int K);
+uint32_t wplan_heavy_threshold(int K, int64_t batch, int d);
 // pipeline step j of a chunk of nw windows: layer i of window j-i+1 (i = 1..L) and the readout of window j-L, whichever
 // exist, in ONE launch; j = 0 .. nw+L-1.
 int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t j, int64_t Ec, int64_t batch,
