@@ -183,7 +183,7 @@ int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* 
     // kernel's 8-pair workgroups spread a short list over more CUs
     static const int64_t mfma_from = (int64_t)TPNET_DEV_INT(FEATURE_MFMA_FROM, 2048);
     if (m.w1 && m.w2f && n >= mfma_from && pair_feature_mfma_supported(st) && !(reinterpret_cast<uintptr_t>(out) & 15))
-        return launch_pair_feature_bf16(st, u, v, n, now, lambda, flags, m.w1, m.b1, m.w2f, m.b2, out_gram, out, s, true);
+        return launch_pair_feature_bf16(st, u, v, n, now, lambda, flags, m.w1, m.b1, m.w2f, m.b2, out_gram, out, s, mlp_f32_mode());
     TPNET_DISPATCH(({
         constexpr int GPB = FB / LPP;
         const int ppb = (GPB > FSUB && n <= 256 * FSUB) ? FSUB : GPB;

@@ -6,7 +6,12 @@
 // pre-permuted as in mlp.hip).  The eight partial Y tiles are added in a FIXED order through LDS (run-to-run identical
 // bits).  The features never leave the chip; the weights of a wave (its 32 rows of W1, its 32 columns of W2: 48 VGPRs)
 // are loaded once per workgroup.  bf16 operands, fp32 accumulation: 2e-2 class like tpnet_mlp64_bf16 -- opt-in.  L = 3.
-// F32 = true: the same kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation -- differs from
+// MODE 2 (the default fp32-CLASS path): the bf16 matrix cores with SPLIT operands -- every f32 operand x = hi + lo with hi =
+// bf16(x), lo = bf16(x - hi) (16 bits of significand between them), every product as hi*hi + hi*lo + lo*hi in fp32 accumulators:
+// relative error ~2^-16 per product, the accuracy class of the fp32 paths (<= 2e-5 of the output scale against the torch
+// layers, exact on small integers), at 24 bf16 MFMAs per wave and tile instead of 64 fp32 ones of four times the cycles.  Same
+// inputs as MODE 1 (tpnet_mlp::w1, w2f: the split happens in registers).
+// MODE 1 (F32): the same kernel on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulation -- differs from
 // the torch layers in summation order only), which makes ONE launch the default get_pair_wise_feature for lists of any length:
 // k-step s of layer 1 takes features (s, s + 32) (lane half h reads 32 consecutive floats of its pair's LDS row and of its W1
 // row), k-step s of layer 2 takes the hidden units that register s of the two lane halves holds (W2 gathered to match).
@@ -21,7 +26,20 @@ static constexpr int MB = 512;            // threads per workgroup: 8 waves = th
 static constexpr int MF = 64, MH = 256;
 static constexpr int TS = 68;             // floats per LDS row of the feature / partial tiles (64 + 4: bank spread)
 
-template <int LPP, int VPL, int W, bool FULL, bool F32>
+// 8 consecutive floats (16-byte aligned) -> hi = bf16(x), lo = bf16(x - hi)
+__device__ __forceinline__ void split8(const float* __restrict__ x, bf16x8& hi, bf16x8& lo) {
+    const float4 a = *reinterpret_cast<const float4*>(x);
+    const float4 b = *reinterpret_cast<const float4*>(x + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 t = (__bf16)v[j];
+        hi[j] = t;
+        lo[j] = (__bf16)(v[j] - (float)t);
+    }
+}
+
+template <int LPP, int VPL, int W, bool FULL, int MODE>
 __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const int64_t* __restrict__ u,
                                                           const int64_t* __restrict__ v, int64_t n, double now,
                                                           double lambda, uint32_t flags, const void* __restrict__ w1v,
@@ -36,6 +54,7 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     const float* __restrict__ w1f = reinterpret_cast<const float*>(w1v);
     const float* __restrict__ w2f = reinterpret_cast<const float*>(w2v);
     constexpr int L = 3;
+    constexpr bool F32 = MODE == 1, X3 = MODE == 2;
     constexpr int GPB = MB / LPP;             // pairs per readout pass
     constexpr int PT = 32 / GPB;              // passes per 32-pair tile
     static_assert(GPB * PT == 32 && LPP >= 16, "k_pair_feature_bf16: 16, 32 or 64 lanes per pair");
@@ -49,8 +68,18 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
     // ---- this wave's weights: rows [32 wave, 32 wave + 32) of W1 as A operand, the matching columns of (permuted) W2
     bf16x8 a1[4], a2[2][2];
+    bf16x8 a1l[X3 ? 4 : 1], a2l[X3 ? 2 : 1][2];          // MODE 2: the low halves of the split weights
     float f1[F32 ? 32 : 1], f2[2][F32 ? 16 : 1];
-    if constexpr (F32) {
+    if constexpr (X3) {
+        // the bf16 kernel's operand layout, taken from the f32 sources: A of layer 1 = W1[32 wave + r][16 s + 8 h + j]; A of layer 2
+        // = W2[32 t + r][32 wave + 16 s2 + 8 (j>>2) + 4 h + (j&3)] = w2f[..][8 s2 + j] (the gathered f32 layout lists them in order)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) split8(w1f + (wave * 32 + r) * MF + 16 * s + 8 * h, a1[s], a1l[s]);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) split8(w2f + (((wave * 2 + t2) * 64 + lane) * 16) + 8 * s2, a2[s2][t2], a2l[s2][t2]);
+    } else if constexpr (F32) {
         // layer 1: A[m = hidden 32 wave + r][k] with k-step s <-> features (s, s + 32): lane half h holds W1[..][32 h + s]
 #pragma unroll
         for (int q4 = 0; q4 < 8; ++q4) {
@@ -80,15 +109,22 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     for (int q = 0; q < 16; ++q) bias1[q] = b1[wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h];
 
     const int64_t ntiles = (n + 31) / 32;
+    // features that already exist: a tile is 512 float4, one per thread; the NEXT tile's piece is fetched while this tile's
+    // matrix products run (a tile is otherwise one global round trip + three barriers deep: 8.7 -> ~5 us per tile)
+    static_assert(32 * (MF / 4) == MB, "one float4 of the feature tile per thread");
+    const int frow = tid / (MF / 4), fcol = tid % (MF / 4);
+    float4 fnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (feat_in && (int64_t)blockIdx.x < ntiles) {
+        const int64_t p = (int64_t)blockIdx.x * 32 + frow;
+        if (p < n) fnext = *reinterpret_cast<const float4*>(feat_in + p * MF + 4 * fcol);
+    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- the features of the tile's 32 pairs -> LDS
         if (feat_in) {
-            for (int i = tid; i < 32 * (MF / 4); i += MB) {
-                const int row = i / (MF / 4), c = i % (MF / 4);
-                const int64_t p = tile * 32 + row;
-                const float4 x = p < n ? *reinterpret_cast<const float4*>(feat_in + p * MF + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(feat + row * TS + 4 * c) = x;
-            }
+            *reinterpret_cast<float4*>(feat + frow * TS + 4 * fcol) = fnext;
+            const int64_t pn = (tile + gridDim.x) * 32 + frow;
+            fnext = (tile + gridDim.x < ntiles && pn < n) ? *reinterpret_cast<const float4*>(feat_in + pn * MF + 4 * fcol)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         } else
 #pragma unroll 1
         for (int pass = 0; pass < PT; ++pass) {
@@ -124,6 +160,33 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
                 x = x > 0.0f ? x : 0.0f;
                 y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[0][q], x, y0, 0, 0, 0);
                 y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[1][q], x, y1, 0, 0, 0);
+            }
+        } else if constexpr (X3) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 bxh, bxl;
+                split8(feat + r * TS + 16 * s + 8 * h, bxh, bxl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[s], bxh, acc, 0, 0, 0);     // the small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bxl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s], bxh, acc, 0, 0, 0);
+            }
+            bf16x8 bhh[2], bhl[2];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float x = acc[q] + bias1[q];
+                x = x > 0.0f ? x : 0.0f;
+                const __bf16 hi = (__bf16)x;
+                bhh[q >> 3][q & 7] = hi;
+                bhl[q >> 3][q & 7] = (__bf16)(x - (float)hi);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[s2][0], bhh[s2], y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[s2][1], bhh[s2], y1, 0, 0, 0);
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][0], bhl[s2], y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][1], bhl[s2], y1, 0, 0, 0);
+                y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][0], bhh[s2], y0, 0, 0, 0);
+                y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[s2][1], bhh[s2], y1, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -194,6 +257,12 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     }
 }
 
+// the fp32-class dense layers: 2 = split bf16 operands (default), 1 = fp32 MFMA (developer builds: TPNET_DEV_MLP_F32_MODE=1)
+int mlp_f32_mode() {
+    static const int m = TPNET_DEV_INT(MLP_F32_MODE, 2);
+    return m == 1 ? 1 : 2;
+}
+
 bool pair_feature_mfma_supported(const tpnet_state& st) {
     const Geom gm = pick_geom(st.d);
     return st.L == 3 && gm.w == 4 && gm.lpp >= 16;
@@ -201,7 +270,7 @@ bool pair_feature_mfma_supported(const tpnet_state& st) {
 
 int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                              uint32_t flags, const void* w1, const float* b1, const void* w2p, const float* b2,
-                             float* out_gram, float* out, hipStream_t s, bool f32, const float* feat_in) {
+                             float* out_gram, float* out, hipStream_t s, int mode, const float* feat_in) {
     if (n == 0) return TPNET_OK;
     if (st.L != 3 || (flags & TPNET_FLAG_PACKED)) return TPNET_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(b2)) & 15) return TPNET_ERR_BAD_ARG;
@@ -209,14 +278,19 @@ int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int6
     if (gm.w != 4 || gm.lpp < 16) return TPNET_ERR_BAD_ARG;       // narrow / scalar rows: readout kernel + tpnet_mlp64_bf16
     const bool full = st.d == gm.lpp * gm.vpl * 4;
     const int64_t tiles = (n + 31) / 32;
-    const int grid = (int)(tiles < 2048 ? tiles : 2048);
+    // (a workgroup's first act is to load its 128 KB of weights: no more workgroups than the chip holds at once -- 3 per CU by
+    // their 43 KB of LDS -- so that each amortises them over several tiles: 80 000 rows 51 -> 3x us)
+    const int grid = (int)(tiles < 768 ? tiles : 768);
 #define TPNET_PF(LPP_, VPL_, FULL_)                                                                                          \
     do {                                                                                                                     \
-        if (f32)                                                                                                             \
-            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, true>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now, \
+        if (mode == 2)                                                                                                       \
+            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, 2>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now,    \
+                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
+        else if (mode == 1)                                                                                                  \
+            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, 1>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now,    \
                                lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
         else                                                                                                                 \
-            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, false>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now, \
+            hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, 0>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now,    \
                                lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
     } while (0)
     if (gm.lpp == 16 && gm.vpl == 1) { if (full) TPNET_PF(16, 1, true); else TPNET_PF(16, 1, false); }
@@ -240,7 +314,7 @@ extern "C" int tpnet_pair_feature_bf16(const tpnet_state* st, const int64_t* u, 
     if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1) return TPNET_ERR_BAD_ARG;
     if (n < 0 || (n > 0 && (!u || !v || !out || !w1_bf16 || !b1 || !w2p_bf16 || !b2))) return TPNET_ERR_BAD_ARG;
     return launch_pair_feature_bf16(*st, u, v, n, now_time, lambda, flags, w1_bf16, b1, w2p_bf16, b2, out_gram, out,
-                                    (hipStream_t)stream, false, nullptr);
+                                    (hipStream_t)stream, 0, nullptr);
 }
 
 extern "C" int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, float* y, void* stream) {
@@ -251,5 +325,5 @@ extern "C" int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, 
     tpnet_state st{};                      // (not dereferenced when the tile comes from `x`; geometry of d = 128 picks the 32-lane kernel)
     st.N = 1; st.d = 128; st.L = 3;
     return launch_pair_feature_bf16(st, nullptr, nullptr, n, 0.0, 0.0, 0, mlp->w1, mlp->b1, mlp->w2f, mlp->b2, nullptr, y,
-                                    (hipStream_t)stream, true, x);
+                                    (hipStream_t)stream, mlp_f32_mode(), x);
 }

@@ -168,7 +168,8 @@ int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* 
 bool pair_feature_mfma_supported(const tpnet_state& st);
 int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                              uint32_t flags, const void* w1, const float* b1, const void* w2p, const float* b2,
-                             float* out_gram, float* out, hipStream_t s, bool f32, const float* feat_in = nullptr);
+                             float* out_gram, float* out, hipStream_t s, int mode, const float* feat_in = nullptr);
+int mlp_f32_mode();
 
 // the plan of ONE batch by one workgroup (plan.hip, k_plan_one): same Plan contents as plan_build for batch 0 of a chunk
 static constexpr int64_t PLAN_ONE_MAX = 2048;

@@ -745,7 +745,9 @@ class RandomProjectionModule(nn.Module):
         if n > (self._eng["stage"].max_pairs if mfma else _ff.MAX_PAIRS):
             # a long list: with the matrix-core kernel still one launch, from a device copy of the ids -- except the encoder's
             # pattern on wide rows, which the caller below serves with the anchored readout + the matrix-core mlp
-            if not mfma or (self.dim > 128 and n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:])):
+            # (rows of <= 128 floats on long lists: the 512-thread workgroups of the one-kernel version cost the readout its
+            # occupancy -- 80 000 pairs at d=128: 87 us against 42 + 34 us for readout kernel + dense-layer kernel)
+            if not mfma or self.dim <= 128 or (n % 2 == 0 and np.array_equal(src[: n // 2], src[n // 2:])):
                 return None
             u, v = self._to_device(self._check_ids(src, "src_node_ids"), self._check_ids(dst, "dst_node_ids"))
             flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
