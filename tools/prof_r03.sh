@@ -9,6 +9,8 @@ declare -A ARGS
 ARGS[timed20]="--config $CFG --batches 20 --reps 6 --schedule auto"
 ARGS[epoch]="--config $CFG --edges -1 --reps 3"
 ARGS[long]="--config $CFG --batches 2048 --reps 2"
+ARGS[batch]="--config $CFG --batches ${NB:-60} --reps 2"
+ARGS[b1000]="--config $CFG --batch 1000 --batches 600 --reps 2"
 for mode in ${MODES:-timed20 epoch long}; do
   O=$R/gpurun_out/r03_${CFG}_$mode
   rm -rf $O

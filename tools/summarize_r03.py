@@ -20,7 +20,9 @@ def main(cfg):
     entries = []
     for mode, what in (("timed20", "the driver's 20 timed batches (one run_stream call, per-batch schedule)"),
                        ("epoch", f"ONE epoch of the config's own stream ({c['E']} edges), cold plan"),
-                       ("long", "2 048 batches of the stream (the long-stream regime)")):
+                       ("long", "2 048 batches of the stream (the long-stream regime)"),
+                       ("batch", "a run of full batches (batches of 10 000 edges take the per-batch kernel)"),
+                       ("b1000", "the config's rows in batches of 1 000 edges, 600 batches: wide rows on the windowed schedule")):
         base = os.path.join(ROOT, "gpurun_out", f"r03_{cfg}_{mode}")
         ks = newest(f"{base}/trace/*/*_kernel_stats.csv")
         tr_f = newest(f"{base}/trace/*/*_kernel_trace.csv")
@@ -44,7 +46,7 @@ def main(cfg):
         if "--edges" in toks:
             E = c["E"] if int(toks[toks.index("--edges") + 1]) < 0 else int(toks[toks.index("--edges") + 1])
         else:
-            E = int(toks[toks.index("--batches") + 1]) * B
+            E = int(toks[toks.index("--batches") + 1]) * (int(toks[toks.index("--batch") + 1]) if "--batch" in toks else B)
         epl = E * reps / len(dur)
         avg = st.mean(dur)
         bpl = bytes_per_edge(d, 3) * epl
