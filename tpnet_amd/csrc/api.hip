@@ -61,7 +61,12 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     // packed rows of (2L+2)(2L+3)/2 floats: every chunk's output must start on a 16-byte boundary (launch_wstep)
     const int NN = 2 * st.L + 2;
     if ((flags & TPNET_FLAG_PACKED) && ((NN * (NN + 1) / 2) % 4) != 0 && Ew % 4 != 0) Ew *= (Ew % 2 == 0) ? 2 : 4;
-    const int64_t cap = wplan_max_chunk_edges(batch, st.d, st.L);          // the version log of a chunk is bounded
+    int64_t cap = wplan_max_chunk_edges(batch, st.d, st.L);                // the version log of a chunk is bounded
+    // batches that fit one workgroup's LDS: chunks of at most 64 windows, which the hashed planner serves (wplan3.hip) -- ONE set
+    // of plan kernels whatever the stream's length (a chunk that falls to the sorted planner meets rocPRIM's large-size sort
+    // kernels for the first time in the middle of a long call: HIP resolves a kernel at its first launch, ~0.3 ms each)
+    if (batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED) && cap > (int64_t)WIN_MAX_WINDOWS * Ew)
+        cap = (int64_t)WIN_MAX_WINDOWS * Ew;
     const int64_t hard = cap / Ew * Ew;
     const int64_t lim = (E <= cap) ? E : hard;
     if ((lim + batch - 1) / batch < 4) return 0;
@@ -121,8 +126,8 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
         const bool have_readout = out_pos || out_neg;
         static const int no3 = TPNET_DEV_INT(NO_PLAN3, 0);
         // the hashed planner costs ~45 us + 0.76 us per batch, the sorted one ~200 us + 0.63 us per batch (C2, profiles/r03_C2.md):
-        // chunks of up to 768 batches take the first, longer ones the second
-        static const int max3 = TPNET_DEV_INT(PLAN3_MAX_BATCHES, 768);
+        // 4 % of a long stream's time, paid for having one set of plan kernels (see window_chunk)
+        static const int max3 = TPNET_DEV_INT(PLAN3_MAX_BATCHES, 1 << 30);
         const bool plan3 = !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && nb <= max3 && wplan3_applies(st, Ec, batch, K);
         // a plan may be replayed when the whole stream is ONE chunk and the caller vouches (tag) that the stream arrays and
         // the table's per-node state are what the plan in this workspace was built for
