@@ -13,8 +13,11 @@ for s in $1; do
 import csv,glob
 import os; f=max(glob.glob("$R/gpurun_out/st_trace/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'k_wwriteback' in r['Kernel_Name']]
-a,b=idx[-2]+1,idx[-1]+1
+starts=[i for i,r in enumerate(rows) if 'k_wsort' in r['Kernel_Name'] or 'k_make_keys_w' in r['Kernel_Name']]
+a=starts[-1]-1 if 'fillBuffer' in rows[starts[-1]-1]['Kernel_Name'] else starts[-1]
+b=a
+while b < len(rows) and not ('k_wpipe' in rows[b]['Kernel_Name']): b+=1
+while b < len(rows) and ('k_wpipe' in rows[b]['Kernel_Name'] or 'k_wwriteback' in rows[b]['Kernel_Name']): b+=1
 t0=int(rows[a]['Start_Timestamp'])
 wp=[]; first=None; plan=[]
 for r in rows[a:b]:
@@ -26,6 +29,6 @@ for r in rows[a:b]:
     elif first is None: plan.append('%s %.1f-%.1f' % (n.replace('void ','').replace('tpnet::','')[:9], s/1000, e/1000))
     last=e/1000
 print("   plan: " + '; '.join(plan))
-print("   pipeline from %.1f us; k_wpipe x%d: %s  sum %.1f; write-back ends %.1f" % (first, len(wp), ' '.join('%.0f'%x for x in wp[:12]) + (' ...' if len(wp)>12 else ''), sum(wp), last))
+print("   pipeline from %.1f us; k_wpipe x%d: %s  sum %.1f; call ends %.1f" % (first, len(wp), ' '.join('%.0f'%x for x in wp[:12]) + (' ...' if len(wp)>12 else ''), sum(wp), last))
 PY
 done
