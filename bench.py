@@ -591,6 +591,29 @@ def main():
             lr = roof_pass(*args_r)
             lr["value"] = Kr * B / (lr["stream_ms_events"] * 1e-3)
             lr["unit"] = "edges/s (HIP events around the whole call: planning and write-back included)"
+            # the longest stream that is ONE chunk (64 windows of 24 batches), run again after a reset: the plan is replayed
+            kwin = max(2, min(64, 24576 // B))                       # batches per window of a long stream
+            Kc = min(Kr, min(64, ((4 << 30) // (2 * L * d * 4)) // (kwin * B)) * kwin)       # 64 windows, or what 4 GiB of version log hold
+            slc = slice(W * Bg, (W + Kc) * Bg)
+            bpe = bytes_per_edge(d, L)
+
+            def one_chunk(replay):
+                rp.reset_random_projections()
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                rp.run_stream(d_src[slc], d_dst[slc], d_neg[slc], d_t[slc], B, out_pos=o_pos[:Kc * B], out_neg=o_neg[:Kc * B],
+                              t_end=float(t[(W + Kc) * B - 1]), replay=replay)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0_, rp.last_stream_replayed
+            one_chunk(False)
+            cold = float(np.median([one_chunk(False)[0] for _ in range(3)]))
+            one_chunk(None)
+            reps = [one_chunk(None) for _ in range(3)]
+            rep_t = float(np.median([r_[0] for r_ in reps]))
+            lr["one_chunk"] = {"batches": Kc, "what": "wall clock around run_stream on the longest stream that is one chunk, after a reset",
+                               "cold": {"value": Kc * B / cold, "end_to_end_frac": bpe * Kc * B / cold / 1e9 / HBM_PEAK_GBS},
+                               "replay": {"value": Kc * B / rep_t, "end_to_end_frac": bpe * Kc * B / rep_t / 1e9 / HBM_PEAK_GBS,
+                                          "plan_replayed": bool(all(r_[1] for r_ in reps))}}
             extra["long_stream"] = lr
             del o_pos, o_neg
 

@@ -845,7 +845,8 @@ class RandomProjectionModule(nn.Module):
         if E == 0:
             return out_pos, out_neg
         ws = self._workspace(E, batch_size, stream=True, keep_plan=True)
-        st = self._state()
+        self._st_ref()                                   # (the cached tpnet_state struct: rebuilt only when a buffer moved)
+        st = self.__dict__["_st_cache"][2]
         nb = (E + batch_size - 1) // batch_size
         lid = self._next_launch_ids(nb)
         flags = (_lib.FLAG_NOT_SCALE if (self.not_scale or raw or packed) else 0)
