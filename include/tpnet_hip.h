@@ -374,6 +374,25 @@ int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, in
                        const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
                        uint32_t flags, void* scratch, size_t scratch_bytes, float* out, void* stream);
 
+/* The first half of tpnet_encoder_gram alone: the rows [src; other] at tile(t, 2), their anchors and their K sampled neighbours,
+ * laid out in `scratch` (rounded up to 256): nodes int64[2B] | times double[2B] | a1 int64[2B] | a2 int64[2B] | neigh int64[2B][K]. */
+int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
+                       const int64_t* other, const double* t, int64_t B, int32_t K, void* scratch, size_t scratch_bytes,
+                       void* stream);
+
+/* The encoder's call INCLUDING self.mlp (models/TPNet.py:311-324, 129; L = 3, rows of one chunk of 16-byte vectors): gram =
+ * tpnet_pair_gram_anchored's output [2][n_rows*K][64] (kept: what a backward pass needs), out = mlp(gram) in the fp32 class
+ * (tpnet_mlp64_f32's kernel), both on `stream`: the encoder's call as ONE crossing. */
+int tpnet_anchored_features(const tpnet_state* st, const int64_t* neigh, const int64_t* a1, const int64_t* a2, int64_t n_rows,
+                            int32_t K, double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* gram,
+                            float* out, void* stream);
+/* tpnet_encoder_rows + tpnet_anchored_features: the encoder's whole readout for one (src, other) batch, ids resident on the
+ * device, self.mlp included, ONE call. */
+int tpnet_encoder_features(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
+                           const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
+                           uint32_t flags, const tpnet_mlp* mlp, void* scratch, size_t scratch_bytes, float* gram, float* out,
+                           void* stream);
+
 /* ---- the step behind the path (BASELINE config 5): self.mlp = Linear(64,256)->ReLU->Linear(256,64)
  * (models/TPNet.py:64-65,129) fused in one kernel on the bf16 matrix cores, fp32 accumulate, L = 3 only.
  * x [n][64] f32 (the readout's features), y [n][64] f32.  w1_bf16: [256][64] bf16 = mlp[0].weight; w2p_bf16: [64][256]

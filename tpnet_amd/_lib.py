@@ -96,6 +96,11 @@ SIGNATURES = {
     "tpnet_encoder_scratch_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "tpnet_encoder_gram": (C.c_int, [_SP, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                      C.c_uint32, _P, C.c_size_t, _P, _P]),
+    "tpnet_encoder_rows": (C.c_int, [_SP, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, _P, C.c_size_t, _P]),
+    "tpnet_anchored_features": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp),
+                                          _P, _P, _P]),
+    "tpnet_encoder_features": (C.c_int, [_SP, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                         C.c_uint32, C.POINTER(Mlp), _P, C.c_size_t, _P, _P, _P]),
     "tpnet_mlp64_bf16": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "tpnet_mlp64_bwd_partial_floats": (C.c_int64, []),
     "tpnet_mlp64_bwd_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P]),

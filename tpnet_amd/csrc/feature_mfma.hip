@@ -278,9 +278,10 @@ int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int6
     if (gm.w != 4 || gm.lpp < 16) return TPNET_ERR_BAD_ARG;       // narrow / scalar rows: readout kernel + tpnet_mlp64_bf16
     const bool full = st.d == gm.lpp * gm.vpl * 4;
     const int64_t tiles = (n + 31) / 32;
-    // (a workgroup's first act is to load its 128 KB of weights: no more workgroups than the chip holds at once -- 3 per CU by
-    // their 43 KB of LDS -- so that each amortises them over several tiles: 80 000 rows 51 -> 3x us)
-    const int grid = (int)(tiles < 768 ? tiles : 768);
+    // (a workgroup's first act is to load its 128 KB of weights: one workgroup per CU, each amortising them over many tiles --
+    // 80 000 rows: 51 us with a workgroup per tile up to 2 048, 39 us with 768, 32.5 us with 256; 800 000 rows: 244 / 237)
+    static const int grid_cap = TPNET_DEV_INT(MLP_GRID, 256);
+    const int grid = (int)(tiles < grid_cap ? tiles : grid_cap);
 #define TPNET_PF(LPP_, VPL_, FULL_)                                                                                          \
     do {                                                                                                                     \
         if (mode == 2)                                                                                                       \

@@ -212,15 +212,12 @@ size_t tpnet_encoder_scratch_bytes(int64_t B, int32_t K) {
     return (size_t)(8 * B + 2 * B * (int64_t)K) * 8 + 256;
 }
 
-int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
-                       const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
-                       uint32_t flags, void* scratch, size_t scratch_bytes, float* out, void* stream) {
-    if (!st || !sampler || B < 0 || K < 1 || num_nodes < 1 || (B > 0 && (!src || !other || !t || !scratch || !out)))
-        return TPNET_ERR_BAD_ARG;
-    if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
+int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
+                       const int64_t* other, const double* t, int64_t B, int32_t K, void* scratch, size_t scratch_bytes,
+                       void* stream) {
+    if (!st || !sampler || B < 0 || K < 1 || num_nodes < 1 || (B > 0 && (!src || !other || !t || !scratch))) return TPNET_ERR_BAD_ARG;
     if (B == 0) return TPNET_OK;
     if (scratch_bytes < tpnet_encoder_scratch_bytes(B, K)) return TPNET_ERR_WORKSPACE;
-    if (!tpnet_pair_gram_anchored_supported(st)) return TPNET_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int64_t* nodes = (int64_t*)(((size_t)scratch + 255) / 256 * 256);
     double* t2 = (double*)(nodes + 2 * B);
@@ -230,8 +227,22 @@ int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, in
     int g0 = (int)((2 * B + 255) / 256);
     if (g0 > 1024) g0 = 1024;
     hipLaunchKernelGGL(k_encoder_rows, dim3(g0), dim3(256), 0, s, src, other, t, B, nodes, t2, a1, a2);
-    int rc = tpnet_sample_recent(sampler, E, num_nodes, nodes, t2, 2 * B, K, neigh, nullptr, nullptr, stream);
+    return tpnet_sample_recent(sampler, E, num_nodes, nodes, t2, 2 * B, K, neigh, nullptr, nullptr, stream);
+}
+
+int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
+                       const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
+                       uint32_t flags, void* scratch, size_t scratch_bytes, float* out, void* stream) {
+    if (!st || !out) return TPNET_ERR_BAD_ARG;
+    if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
+    if (B == 0) return TPNET_OK;
+    if (!tpnet_pair_gram_anchored_supported(st)) return TPNET_ERR_BAD_ARG;
+    int rc = tpnet_encoder_rows(st, sampler, E, num_nodes, src, other, t, B, K, scratch, scratch_bytes, stream);
     if (rc) return rc;
+    int64_t* nodes = (int64_t*)(((size_t)scratch + 255) / 256 * 256);
+    int64_t* a1 = nodes + 4 * B;
+    int64_t* a2 = a1 + 2 * B;
+    int64_t* neigh = a2 + 2 * B;
     const int NN = 2 * st->L + 2;
     return tpnet_pair_gram_anchored(st, neigh, a1, a2, 2 * B, K, now_time, lambda, flags, out,
                                     out + (size_t)(2 * B) * (size_t)K * (size_t)(NN * NN), stream);

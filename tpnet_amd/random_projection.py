@@ -677,9 +677,39 @@ class RandomProjectionModule(nn.Module):
                                                 out[1].data_ptr(), self._stream()), "pair_gram_anchored")
         return out
 
+    def _overlapped_mlp(self):
+        """The prepared fp32 weights of self.mlp if the encoder's one-call path applies (readout chunks and their dense layers side
+        by side, tpnet_anchored_features): L = 3, the reference's Linear-ReLU-Linear on this GPU, not the opt-in bf16 layers."""
+        if self.fused_mlp or self.num_layer != 3:
+            return None
+        prep = _ff.prepared(self.mlp, self.pair_wise_feature_dim)
+        return prep if (prep is not None and prep[1].w1) else None
+
     def get_pair_wise_feature_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids):
         """Extension: the encoder's call (models/TPNet.py:313-316) from its natural arguments; [2*n*K, (2L+2)^2] in the
         reference's row order, self.mlp applied."""
+        prep = self._overlapped_mlp() if self._plist()[0].device.type == "cuda" else None
+        if prep is not None and isinstance(neighbor_ids, torch.Tensor) and neighbor_ids.is_cuda:
+            self._ensure_engine()
+            lib = _lib.load()
+            if lib.tpnet_pair_gram_anchored_supported(self._st_ref()):
+                n, K = neighbor_ids.shape
+                wd = self._check_ids(neighbor_ids.reshape(-1), "neighbor_ids")
+                a1, a2 = self._to_device(self._check_ids(first_anchor_ids, "first_anchor_ids"),
+                                         self._check_ids(second_anchor_ids, "second_anchor_ids"))
+                NG = self.pair_wise_feature_dim
+                flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+
+                def launch(gram):
+                    out = torch.empty((2 * n * K, NG), dtype=torch.float32, device=self._eng["dev"])
+                    _lib.check(lib.tpnet_anchored_features(self._st_ref(), wd.data_ptr(), a1.data_ptr(), a2.data_ptr(), n, K,
+                                                           self._now_host, float(self.time_decay_weight), flags, prep[2],
+                                                           gram.data_ptr(), out.data_ptr(), _raw_stream(self._eng["dev_index"])),
+                               "anchored_features")
+                    return out
+                if _ff.needs_grad(prep[4]):
+                    return _ff.apply_with_grad(self.mlp, launch, 2 * n * K, NG)
+                return launch(torch.empty((2 * n * K, NG), dtype=torch.float32, device=self._eng["dev"]))
         g = self.pair_gram_anchored(neighbor_ids, first_anchor_ids, second_anchor_ids)
         return self._apply_mlp(g.view(-1, self.pair_wise_feature_dim))
 
@@ -699,14 +729,28 @@ class RandomProjectionModule(nn.Module):
         NG = self.pair_wise_feature_dim
         nbytes = lib.tpnet_encoder_scratch_bytes(B, K)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        out = torch.empty((2, 2 * B * K, NG), dtype=torch.float32, device=dev)
         flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        off = (-scratch.data_ptr()) % 256 + 64 * B
+        neigh = scratch[off: off + 16 * B * K].view(torch.int64).view(2 * B, K)
+        prep = self._overlapped_mlp()
+        if prep is not None and lib.tpnet_pair_gram_anchored_supported(self._st_ref()):
+            # ONE call, self.mlp included: the dense layers of a chunk of rows run beside the readout of the next one
+            def launch(gram):
+                out = torch.empty((4 * B * K, NG), dtype=torch.float32, device=dev)
+                _lib.check(lib.tpnet_encoder_features(self._st_ref(), sampler._buf.data_ptr(), sampler.E, sampler.num_nodes,
+                                                      src_ids.data_ptr(), other_ids.data_ptr(), times.data_ptr(), B, K,
+                                                      self._now_host, float(self.time_decay_weight), flags, prep[2],
+                                                      scratch.data_ptr(), nbytes, gram.data_ptr(), out.data_ptr(),
+                                                      _raw_stream(self._eng["dev_index"])), "encoder_features")
+                return out
+            if _ff.needs_grad(prep[4]):
+                return _ff.apply_with_grad(self.mlp, launch, 4 * B * K, NG), neigh
+            return launch(torch.empty((4 * B * K, NG), dtype=torch.float32, device=dev)), neigh
+        out = torch.empty((2, 2 * B * K, NG), dtype=torch.float32, device=dev)
         _lib.check(lib.tpnet_encoder_gram(self._st_ref(), sampler._buf.data_ptr(), sampler.E, sampler.num_nodes, src_ids.data_ptr(),
                                           other_ids.data_ptr(), times.data_ptr(), B, K, self._now_host,
                                           float(self.time_decay_weight), flags, scratch.data_ptr(), nbytes, out.data_ptr(),
                                           _raw_stream(self._eng["dev_index"])), "encoder_gram")
-        off = (-scratch.data_ptr()) % 256 + 64 * B
-        neigh = scratch[off: off + 16 * B * K].view(torch.int64).view(2 * B, K)
         return self._apply_mlp(out.view(-1, NG)), neigh
 
     @staticmethod
