@@ -308,11 +308,13 @@ def main():
     def time_leg(run, k_steps):
         """W untimed steps, then exactly k_steps timed ones between barrier + synchronize; max over ranks."""
         if W > 1:
-            # the W warm-up steps as TWO calls: the first two calls of a process pay one-time costs (lazy kernel loading,
-            # allocator and stream set-up in the runtime) that a single short call does not absorb (measured: the call after
-            # one 5-step call takes 340 us for 20 steps, after two calls 210 us)
-            run(0, W // 2)
-            run(W // 2, W)
+            # the W warm-up steps as up to FOUR calls: the first calls of a process pay one-time costs (lazy kernel loading,
+            # allocator and stream set-up in the runtime, cold host caches) that a single short call does not absorb
+            # (tools/sync_latency.py, 20 steps at C2: call 3 of a process 181-199 us, call 4 180-187, call 5 175-177, steady 172-175)
+            ncall = min(W, 4)
+            cuts = [W * i // ncall for i in range(ncall + 1)]
+            for a_, b_ in zip(cuts[:-1], cuts[1:]):
+                run(a_, b_)
         elif W > 0:
             run(0, W)
         barrier()

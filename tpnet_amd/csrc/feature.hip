@@ -14,15 +14,20 @@ namespace tpnet {
 static constexpr int FB = 256;        // threads per workgroup
 static constexpr int FSUB = 8;        // pairs per pass of the dense layers
 
-template <int LPP, int VPL, int W, int L, bool FULL>
+template <int LPP, int VPL, int W, int L, bool FULL, int SUBP>
 __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_t* __restrict__ u,
                                                      const int64_t* __restrict__ v, int64_t n, double now, double lambda,
                                                      uint32_t flags, tpnet_mlp M, float* __restrict__ out_gram,
-                                                     float* __restrict__ out, int ppb) {
+                                                     float* __restrict__ out, int ppb_arg) {
+#ifdef TPNET_DEV
+    const int ppb = ppb_arg & 0xFF, dbg_skip = ppb_arg >> 8;       // diagnostic builds: stop after a phase (timing brackets)
+#else
+    const int ppb = ppb_arg;
+#endif
     using C = GramCfg<LPP, L>;
     constexpr int GPB = FB / LPP;                 // pairs per pass of the readout
     constexpr int NG = C::NG, H = 4 * NG;
-    constexpr int SUB = GPB < FSUB ? GPB : FSUB;
+    constexpr int SUB = GPB < SUBP ? GPB : SUBP;     // pairs per pass of the dense layers (and per workgroup when the list is short)
     constexpr int KQ = FB / NG;                   // layer 2: the hidden axis is cut into KQ slices, one per group of NG threads
     constexpr int KCH = (H + KQ - 1) / KQ;        // hidden units per slice
     // (the readout's reduction through LDS only where its tile and the dense layers' tiles fit 64 KB together)
@@ -37,28 +42,15 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
     const float* __restrict__ w1t = M.w1t;        // [NG][H]: w1t[k][j] = mlp[0].weight[j][k]
     const float* __restrict__ w2t = M.w2t;        // [H][NG]: w2t[k][o] = mlp[2].weight[o][k]
-    // L = 3 (H == FB): thread j IS hidden unit j and thread (kq, o) owns one slice of one output for the whole kernel, so
-    // its 64 + 64 weights are loaded ONCE, ahead of the first readout (whose memory round trips hide the loads), and stay
-    // in registers for every tile of the block: the dense layers then touch only LDS
-    // Register-resident weights (a thread's 64 + 64 weights in ONE burst of 128 independent loads) were measured and are
-    // compiled out by default: issued ahead of the first readout (TPNET_FEATURE_WREG = 1) they queue up in front of its own
-    // loads (C2, 1000 pairs: 17.6 us against 13.9 us with four bursts of 32 behind the readout); issued right behind the
-    // readout (= 2) the kernel needs ~600 live registers and spills to scratch.
-#ifndef TPNET_FEATURE_WREG
-#define TPNET_FEATURE_WREG 0
-#endif
-    constexpr bool WREG = TPNET_FEATURE_WREG != 0 && (H == FB) && (KQ * NG == FB);
-    constexpr bool WLATE = TPNET_FEATURE_WREG == 2;
+    // L = 3 (H == FB): thread j IS hidden unit j and thread (kq, o) owns one slice of one output, so a thread's 64 + 64 weights
+    // are two bursts of independent loads into registers, issued ONCE per workgroup right behind its first readout (both
+    // bursts before the first layer's arithmetic, so the second one's round trip hides behind it) and kept for every further
+    // tile.  (Issued ahead of the first readout they queue up in front of its own loads -- vector loads return in order:
+    // C2, 1000 pairs, 17.6 us against 13.9 us.)
+    constexpr bool WREG = (H == FB) && (KQ * NG == FB);
     float w1r[WREG ? NG : 1], w2r[WREG ? KCH : 1];
     float b1r = 0.0f;
-    if constexpr (WREG && !WLATE) {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) w1r[k] = w1t[k * H + tid];
-        const int kq = tid / NG, o = tid - kq * NG;
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) w2r[i] = w2t[(kq * KCH + i) * NG + o];
-        b1r = M.b1[tid];
-    }
+    bool have_w = false;
     // ppb = pairs per workgroup and pass (<= GPB): a short list is spread over more workgroups with idle lane groups rather
     // than over few full ones (200 pairs at d=64: 13 workgroups of 16 pairs and two dense passes each, or 25 of 8 and one)
     for (int64_t base = (int64_t)blockIdx.x * ppb; base < n; base += (int64_t)gridDim.x * ppb) {
@@ -67,19 +59,26 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
         gram_pair<LPP, VPL, W, L, FULL, false, false, LR>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
                                                           feat + g * NG, gl, nullptr, stage);
+        if constexpr (WREG) {
+            if (!have_w) {
+                const int kq = tid / NG, o = tid - kq * NG;
+#pragma unroll
+                for (int k = 0; k < NG; ++k) w1r[k] = w1t[k * H + tid];
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) w2r[i] = w2t[(kq * KCH + i) * NG + o];
+                b1r = M.b1[tid];
+                have_w = true;
+            }
+        }
         __syncthreads();
         const int npair = (n - base < ppb) ? (int)(n - base) : ppb;
         if (out_gram) {                           // the pre-mlp features, for a backward pass (training)
             for (int i = tid; i < npair * NG; i += FB) out_gram[base * NG + i] = feat[i];
         }
-        if constexpr (WREG && WLATE) {
-#pragma unroll
-            for (int k = 0; k < NG; ++k) w1r[k] = w1t[k * H + tid];
-            const int kq = tid / NG, o = tid - kq * NG;
-#pragma unroll
-            for (int i = 0; i < KCH; ++i) w2r[i] = w2t[(kq * KCH + i) * NG + o];
-            b1r = M.b1[tid];
-        }
+#ifdef TPNET_DEV
+        if (dbg_skip == 1) { for (int i = tid; i < npair * NG; i += FB) out[base * NG + i] = feat[i]; __syncthreads(); continue; }
+        if (dbg_skip == 2) { float a_ = b1r; if constexpr (WREG) { for (int k = 0; k < NG; ++k) a_ += w1r[k] + w2r[k]; } if (tid < npair * NG) out[base * NG + tid] = a_ + feat[tid]; __syncthreads(); continue; }
+#endif
         for (int p0 = 0; p0 < npair; p0 += SUB) {
             // ---- hidden = relu(W1 f + b1): thread j owns hidden unit j for the SUB pairs of this pass.  Its NG weights are
             // fetched in bursts of 32 independent loads (a k loop with a load per step is a chain of L2 round trips)
@@ -91,6 +90,7 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
                 for (int k = 0; k < NG; ++k) {
 #pragma unroll
                     for (int q = 0; q < SUB; ++q) acc[q] = fmaf(feat[(p0 + q) * NG + k], w1r[k], acc[q]);
+                    if (k % 8 == 7) __builtin_amdgcn_sched_barrier(0);     // (keeps the LDS reads of later k out of the live set)
                 }
 #pragma unroll
                 for (int q = 0; q < SUB; ++q) {
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
                 for (int i = 0; i < KCH; ++i) {
 #pragma unroll
                     for (int q = 0; q < SUB; ++q) acc[q] = fmaf(hid[(kq * KCH + i) * SUB + q], w2r[i], acc[q]);
+                    if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int q = 0; q < SUB; ++q) part[(kq * SUB + q) * NG + o] = acc[q];
@@ -184,13 +185,24 @@ int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* 
     static const int64_t mfma_from = (int64_t)TPNET_DEV_INT(FEATURE_MFMA_FROM, 2048);
     if (m.w1 && m.w2f && n >= mfma_from && pair_feature_mfma_supported(st) && !(reinterpret_cast<uintptr_t>(out) & 15))
         return launch_pair_feature_bf16(st, u, v, n, now, lambda, flags, m.w1, m.b1, m.w2f, m.b2, out_gram, out, s, mlp_f32_mode());
-    TPNET_DISPATCH(({
-        constexpr int GPB = FB / LPP;
-        const int ppb = (GPB > FSUB && n <= 256 * FSUB) ? FSUB : GPB;
-        const int grid = grid_for(n, ppb, 256 * 8);
-        hipLaunchKernelGGL((k_pair_feature<LPP, VPL, W, L, FULL>), dim3(grid), dim3(FB), 0, s, st, u, v, n, now, lambda,
-                           flags, m, out_gram, out, ppb);
-    }));
+    // pairs per workgroup: a short list is spread over as many CUs as it has tiles of 2 / 4 / 8 pairs -- a workgroup's dense
+    // layers are 2 * 64 * 256 fmaf per pair on ONE wave per SIMD plus 128 KB of weights through its CU's L2 port, so the call's
+    // latency falls with the tile until the launch fills the chip (C2, 1000 pairs: 13.9 us with 8 pairs per workgroup)
+    static const int sub_dev = TPNET_DEV_INT(FEATURE_SUB, 0);
+    static const int skip_dev = TPNET_DEV_INT(FEATURE_SKIP, 0);
+    const int sub = sub_dev ? sub_dev : (n <= 512 ? 2 : n <= 1536 ? 4 : 8);
+#define TPNET_FEATURE_LAUNCH(SUBP_)                                                                                          \
+    TPNET_DISPATCH(({                                                                                                        \
+        constexpr int GPB = FB / LPP;                                                                                        \
+        const int ppb = GPB < SUBP_ ? GPB : ((SUBP_ < FSUB || n <= 256 * FSUB) ? SUBP_ : GPB);                                   \
+        const int grid = grid_for(n, ppb, 256 * 8);                                                                          \
+        hipLaunchKernelGGL((k_pair_feature<LPP, VPL, W, L, FULL, SUBP_>), dim3(grid), dim3(FB), 0, s, st, u, v, n, now, lambda, \
+                           flags, m, out_gram, out, ppb | (skip_dev << 8));                                                  \
+    }))
+    if (sub == 2) TPNET_FEATURE_LAUNCH(2);
+    else if (sub == 4) TPNET_FEATURE_LAUNCH(4);
+    else TPNET_FEATURE_LAUNCH(FSUB);
+#undef TPNET_FEATURE_LAUNCH
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }

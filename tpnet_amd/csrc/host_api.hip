@@ -3,7 +3,7 @@
 // train_link_prediction.py:359-373) and the stock path pays one pageable host->device copy per array.  Here the ids are
 // checked and copied into a slot of a pinned, device-mapped ring on the host, and the kernels read the slot directly: the
 // per-batch call is host-bound (a batch is microseconds of GPU work), so what counts is the number of runtime calls per
-// API call -- one kernel launch + one event record for a readout, two launches + one event record for an update.
+// API call -- one kernel launch for a readout, two launches for an update, and one event record per FILLED slot of the ring.
 // (Measured and not kept: the update's plan kernel on a helper stream beside the batch's two readouts -- the GPU side would
 // allow it, but two cross-stream event waits and two more event records cost the call 11 us of host time, and the per-batch
 // loop is host-bound: C2 59-69 us per batch against 60.)
@@ -17,27 +17,46 @@ struct tpnet_stage {
     char* dev_base = nullptr;    // its device address
     size_t slot_bytes = 0;
     int32_t n_slots = 0;
-    int32_t pos = 0;
-    hipEvent_t* ev = nullptr;    // recorded behind the launch that reads the slot
+    int32_t pos = 0;             // the slot being filled
+    size_t off = 0;              // bytes of it handed out
+    bool open = false;           // launches that read the slot being filled have been enqueued (on `cur`) since it was entered
+    hipStream_t cur = nullptr;
+    hipEvent_t* ev = nullptr;    // recorded when a slot is LEFT: behind every launch that read it
     bool* used = nullptr;
 };
 
 namespace tpnet {
 
-static int stage_acquire(tpnet_stage* sg, size_t bytes, char** host, char** dev) {
+// A call's arrays are carved from the slot being filled; the slot is left -- ONE event record for all the launches that read
+// it -- when the next request does not fit (or arrives on another stream), and a slot is entered again only after its event
+// has completed.  A decoder-sized call (16-24 KB) therefore costs an event record once per ~10-16 calls instead of per call:
+// an event record is a barrier packet in the queue, ~6 us of GPU timeline between two kernels (rocprofv3 kernel trace of the
+// per-batch loop at C2: 66 us per batch with an event per call, 48 us of kernels).
+static int stage_acquire(tpnet_stage* sg, size_t bytes, hipStream_t s, char** host, char** dev) {
     if (!sg || bytes > sg->slot_bytes) return TPNET_ERR_BAD_ARG;
-    const int k = sg->pos;
-    if (sg->used[k]) TPNET_HIP_TRY(hipEventSynchronize(sg->ev[k]));   // the launch that read this slot last is done
-    *host = sg->base + (size_t)k * sg->slot_bytes;
-    *dev = sg->dev_base + (size_t)k * sg->slot_bytes;
+    if (sg->off + bytes > sg->slot_bytes || (sg->open && s != sg->cur)) {
+        if (sg->open) {
+            TPNET_HIP_TRY(hipEventRecord(sg->ev[sg->pos], sg->cur));
+            sg->used[sg->pos] = true;
+            sg->open = false;
+        }
+        sg->pos = (sg->pos + 1) % sg->n_slots;
+        sg->off = 0;
+        if (sg->used[sg->pos]) {
+            TPNET_HIP_TRY(hipEventSynchronize(sg->ev[sg->pos]));   // the launches that read this slot last are done
+            sg->used[sg->pos] = false;
+        }
+    }
+    *host = sg->base + (size_t)sg->pos * sg->slot_bytes + sg->off;
+    *dev = sg->dev_base + (size_t)sg->pos * sg->slot_bytes + sg->off;
     return TPNET_OK;
 }
 
-static int stage_release(tpnet_stage* sg, hipStream_t s) {
-    const int k = sg->pos;
-    TPNET_HIP_TRY(hipEventRecord(sg->ev[k], s));
-    sg->used[k] = true;
-    sg->pos = (k + 1) % sg->n_slots;
+// the launches that read `bytes` from the acquired address are enqueued on s
+static int stage_release(tpnet_stage* sg, size_t bytes, hipStream_t s) {
+    sg->off += (bytes + 255) / 256 * 256;
+    sg->open = true;
+    sg->cur = s;
     return TPNET_OK;
 }
 
@@ -93,6 +112,7 @@ int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out) {
 
 int tpnet_stage_destroy(tpnet_stage* sg) {
     if (!sg) return TPNET_OK;
+    if (sg->open) (void)hipDeviceSynchronize();          // launches of the slot being filled: no event covers them yet
     for (int i = 0; i < sg->n_slots; ++i) {
         if (sg->used[i]) (void)hipEventSynchronize(sg->ev[i]);
         (void)hipEventDestroy(sg->ev[i]);
@@ -128,18 +148,18 @@ int tpnet_host_pair_feature(const tpnet_state* st, tpnet_stage* stage, const int
     if (n < 0 || (n > 0 && (!h_u || !h_v || !out)) || !stage) return TPNET_ERR_BAD_ARG;
     if (n == 0) return TPNET_OK;
     char *host = nullptr, *dev = nullptr;
-    int rc = stage_acquire(stage, (size_t)n * 16, &host, &dev);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = stage_acquire(stage, (size_t)n * 16, s, &host, &dev);
     if (rc) return rc;
     int64_t* hu = reinterpret_cast<int64_t*>(host);
-    if (!copy_ids(hu, h_u, n, st->N) || !copy_ids(hu + n, h_v, n, st->N)) return TPNET_ERR_INDEX;   // slot not consumed
+    if (!copy_ids(hu, h_u, n, st->N) || !copy_ids(hu + n, h_v, n, st->N)) return TPNET_ERR_INDEX;   // nothing consumed
     const int64_t* du = reinterpret_cast<const int64_t*>(dev);
-    hipStream_t s = (hipStream_t)stream;
     if (mlp)
         rc = launch_pair_feature(*st, du, du + n, n, now_time, lambda, flags, *mlp, out_gram, out, s);
     else
         rc = launch_pair_gram(*st, du, du + n, n, now_time, lambda, flags, out, s);
     if (rc) return rc;
-    return stage_release(stage, s);
+    return stage_release(stage, (size_t)n * 16, s);
 }
 
 int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst,
@@ -157,15 +177,15 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
         const size_t pb = (plan_bytes(B, B) + 255) / 256 * 256;
         if (!workspace || pb + (size_t)B * 24 > ws_bytes) return TPNET_ERR_WORKSPACE;
         char *host = nullptr, *dev = nullptr;
-        int rc = stage_acquire(stage, (size_t)B * 24, &host, &dev);
+        hipStream_t s = (hipStream_t)stream;
+        int rc = stage_acquire(stage, (size_t)B * 24, s, &host, &dev);
         if (rc) return rc;
         int64_t* hs = reinterpret_cast<int64_t*>(host);
         if (!copy_ids(hs, h_src, B, st->N) || !copy_ids(hs + B, h_dst, B, st->N)) return TPNET_ERR_INDEX;
         memcpy(hs + 2 * B, h_t, (size_t)B * 8);
-        hipStream_t s = (hipStream_t)stream;
         int64_t* d = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(workspace) + pb);
         TPNET_HIP_TRY(hipMemcpyAsync(d, host, (size_t)B * 24, hipMemcpyHostToDevice, s));
-        rc = stage_release(stage, s);
+        rc = stage_release(stage, (size_t)B * 24, s);
         if (rc) return rc;
         return tpnet_update(st, d, d + B, reinterpret_cast<const double*>(d + 2 * B), B, now_time, lambda, launch_id, flags,
                             workspace, pb, stream);
@@ -174,16 +194,16 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
     int rc = plan_carve(workspace, ws_bytes, B, B, &p);
     if (rc) return rc;
     char *host = nullptr, *dev = nullptr;
-    rc = stage_acquire(stage, (size_t)B * 24, &host, &dev);
+    hipStream_t s = (hipStream_t)stream;
+    rc = stage_acquire(stage, (size_t)B * 24, s, &host, &dev);
     if (rc) return rc;
     int64_t* hs = reinterpret_cast<int64_t*>(host);
     if (!copy_ids(hs, h_src, B, st->N) || !copy_ids(hs + B, h_dst, B, st->N)) return TPNET_ERR_INDEX;
     memcpy(hs + 2 * B, h_t, (size_t)B * 8);
     const int64_t* ds = reinterpret_cast<const int64_t*>(dev);
-    hipStream_t s = (hipStream_t)stream;
     rc = plan_one(*st, p, ds, ds + B, reinterpret_cast<const double*>(ds + 2 * B), B, now_time, lambda, flags, s);
     if (rc) return rc;
-    rc = stage_release(stage, s);                                      // the plan kernel is the only reader of the slot
+    rc = stage_release(stage, (size_t)B * 24, s);                      // the plan kernel is the only reader of the slot
     if (rc) return rc;
     StreamArgs a{};
     a.own_mod = 1;

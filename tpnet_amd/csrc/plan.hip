@@ -12,6 +12,19 @@
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
+#ifdef TPNET_STAMPS
+// diagnostic build only: wave 0 of workgroup 0 records (shader clock, 100 MHz wall clock) at the phase boundaries of k_plan_one
+#define PSTAMP(slot)                                                                          \
+    do {                                                                                      \
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            dbg[(slot) * 2 + 0] = __builtin_amdgcn_s_memtime();                               \
+            dbg[(slot) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                           \
+        }                                                                                     \
+    } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
+
 namespace tpnet {
 
 static constexpr uint32_t HEAVY_THRESHOLD = 8u;  // contributions per target above which an item is "heavy"
@@ -326,7 +339,7 @@ template <int BS, int IPT>
 __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restrict__ src_c, const int64_t* __restrict__ dst_c,
                                                  const double* __restrict__ t_c, int64_t Ec, int32_t Bfull, int64_t N,
                                                  int node_bits, double now_time, const double* __restrict__ t_prev,
-                                                 double lambda, int L, uint32_t heavy_threshold, uint32_t* err) {
+                                                 double lambda, int L, uint32_t heavy_threshold, uint32_t* err, int eager) {
     // workgroup b plans batch b of the chunk: edges [b * Bfull, ...), sorted positions [2 * b * Bfull, ...) (as plan_build lays
     // a chunk out); a single-batch call is the chunk of one batch
     const int64_t bb = blockIdx.x;
@@ -352,6 +365,8 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
     static_assert(sizeof(U) + 3 * (NC / 2) * 4 + 8 <= 64 * 1024, "k_plan_one: LDS budget");
     const int tid = threadIdx.x;
     const int nc = 2 * B;
+    [[maybe_unused]] unsigned long long* dbg = p.dbg;     // (phase stamps of diagnostic builds)
+    PSTAMP(0);
     if (tid == 0) { n_light = 0; n_heavy = 0; }
     // every thread's edges in ONE burst of independent loads (src / dst / t may sit in host memory: a load is microseconds)
     constexpr int EPT = IPT / 2;
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
         }
     }
     __syncthreads();
+    PSTAMP(1);
     uint32_t keys[IPT], vals[IPT];
     const uint32_t pad_key = 1u << node_bits;            // above every node id: padding sorts last
 #pragma unroll
@@ -398,12 +414,14 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
     }
     Sort().sort(keys, vals, u.sort, 0u, (unsigned)(node_bits + 1));
     __syncthreads();
+    PSTAMP(2);
 #pragma unroll
     for (int q = 0; q < IPT; ++q) {
         u.s.key[tid * IPT + q] = keys[q];
         u.s.val[tid * IPT + q] = vals[q];
     }
     __syncthreads();
+    PSTAMP(3);
     auto contrib = [&](uint32_t val, int32_t& partner, float& w) {
         const bool side = val >= (uint32_t)B;
         const int e = side ? (int)val - B : (int)val;
@@ -412,43 +430,66 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
         partner = ok ? (int32_t)((side ? es : ed) & 0x7FFFFFFFu) : 0;
         w = ok ? e_w[e] : 0.0f;
     };
-    for (int j = tid; j < nc; j += BS) {
-        const uint32_t key = u.s.key[j];
-        int32_t partner;
-        float w;
-        contrib(u.s.val[j], partner, w);
-        p.s_partner[j] = partner;
-        p.s_coef[j] = w;
-        p.s_target[j] = (int32_t)key;
-        if (j == 0 || u.s.key[j - 1] != key) {
-            // run length by galloping + binary search on the sorted keys (LDS)
-            int lo = j, hi, step = 1;
-            for (;;) {
-                const int nx = lo + step;
-                if (nx >= nc) { hi = nc; break; }
-                if (u.s.key[nx] != key) { hi = nx; break; }
-                lo = nx;
-                step <<= 1;
+    const int lane = tid & 63;
+    for (int jb = 0; jb < nc; jb += BS) {                // (uniform trip count: the list appends below are wave-wide)
+        const int j = jb + tid;
+        Item it;
+        bool lead = false;
+        if (j < nc) {
+            const uint32_t key = u.s.key[j];
+            int32_t partner;
+            float w;
+            contrib(u.s.val[j], partner, w);
+            p.s_partner[j] = partner;
+            p.s_coef[j] = w;
+            p.s_target[j] = (int32_t)key;
+            lead = j == 0 || u.s.key[j - 1] != key;
+            if (lead) {
+                // run length by galloping + binary search on the sorted keys (LDS)
+                int lo = j, hi, step = 1;
+                for (;;) {
+                    const int nx = lo + step;
+                    if (nx >= nc) { hi = nc; break; }
+                    if (u.s.key[nx] != key) { hi = nx; break; }
+                    lo = nx;
+                    step <<= 1;
+                }
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (u.s.key[mid] == key) lo = mid; else hi = mid;
+                }
+                it.j0 = (uint32_t)(2 * e0 + j);                    // chunk-relative position in the sorted arrays
+                it.cnt = (uint32_t)(hi - j);
+                it.target = (int32_t)key;
+                it.p0 = partner;
+                it.w0 = w;
+                it.p1 = 0;
+                it.w1 = 0.0f;
+                it.pad = 0;
+                if (it.cnt >= 2) contrib(u.s.val[j + 1], it.p1, it.w1);
             }
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (u.s.key[mid] == key) lo = mid; else hi = mid;
-            }
-            Item it;
-            it.j0 = (uint32_t)(2 * e0 + j);                    // chunk-relative position in the sorted arrays
-            it.cnt = (uint32_t)(hi - j);
-            it.target = (int32_t)key;
-            it.p0 = partner;
-            it.w0 = w;
-            it.p1 = 0;
-            it.w1 = 0.0f;
-            it.pad = 0;
-            if (it.cnt >= 2) contrib(u.s.val[j + 1], it.p1, it.w1);
-            if (it.cnt > heavy_threshold) p.heavy[atomicAdd(&n_heavy, 1u)] = it;
-            else p.light[atomicAdd(&n_light, 1u)] = it;
+        }
+        // list appends, one LDS atomic per wave and list (a typical batch has ~1500 leaders: as many same-address atomics)
+        const bool hv = lead && it.cnt > heavy_threshold, lt = lead && !hv;
+        const unsigned long long ml = __ballot(lt), mh = __ballot(hv);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ml) {
+            const int first = __ffsll((long long)ml) - 1;
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(&n_light, (uint32_t)__popcll(ml));
+            base = __shfl(base, first);
+            if (lt) p.light[base + (uint32_t)__popcll(ml & below)] = it;
+        }
+        if (mh) {
+            const int first = __ffsll((long long)mh) - 1;
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(&n_heavy, (uint32_t)__popcll(mh));
+            base = __shfl(base, first);
+            if (hv) p.heavy[base + (uint32_t)__popcll(mh & below)] = it;
         }
     }
     __syncthreads();
+    PSTAMP(4);
     if (tid == 0) {
         BatchDesc D;
         D.e0 = e0;
@@ -458,11 +499,14 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
         D.now = (bb == 0) ? (t_prev ? *t_prev : now_time) : t_c[e0 - 1];   // clock left by the previous batch (TPNet.py:99)
         D.n_light = n_light;
         D.n_heavy = n_heavy;
-        const double g = exp(-lambda * (t_last - D.now));
+        // the dense decay's factors only where a dense decay will read them (k_decay_desc, eager mode): exp + pow in f64 are
+        // ~2 us of this one thread's time behind the kernel's last barrier
+        const double g = eager ? exp(-lambda * (t_last - D.now)) : 1.0;
         for (int i = 0; i < TPNET_MAX_LAYERS; ++i)
-            D.decay[i] = (i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;
+            D.decay[i] = (eager && i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;
         p.desc[bb] = D;
     }
+    PSTAMP(5);
 }
 
 int64_t plan_one_max_batch() {
@@ -487,7 +531,7 @@ int plan_blocks(const tpnet_state& st, const Plan& p, const int64_t* src, const 
     static const int bs_env = TPNET_DEV_INT(PLAN_ONE_BS, 0);   // developer override
 #define TPNET_PLAN_ONE(BS_, IPT_)                                                                                         \
     hipLaunchKernelGGL((k_plan_one<BS_, IPT_>), dim3((unsigned)nbl), dim3(BS_), 0, s, p, src, dst, t, Ec, (int32_t)B, st.N,   \
-                       node_bits, now_time, t_prev_dev, lambda, (int)st.L, thr, st.err)
+                       node_bits, now_time, t_prev_dev, lambda, (int)st.L, thr, st.err, (flags & TPNET_FLAG_EAGER_DECAY) ? 1 : 0)
     const int64_t nc = 2 * B;
     if (nc <= 512) {
         if (bs_env == 512) TPNET_PLAN_ONE(256, 2); else TPNET_PLAN_ONE(256, 2);
