@@ -11,7 +11,7 @@ import csv,glob,os,sys,statistics as st
 f=sorted(glob.glob('$R/gpurun_out/fv_trace/*/*_kernel_trace.csv'), key=os.path.getmtime)[-1]
 rows=list(csv.DictReader(open(f)))
 out=[]
-for name in ('k_pair_feature<','k_plan_one','k_step'):
+for name in ('k_pair_feature<','k_pair_feature_bf16','k_plan_one','k_step'):
     d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1000 for r in rows if name in r['Kernel_Name']]
     r0=[r for r in rows if name in r['Kernel_Name']]
     if d: out.append(f"{name} n={len(d)} median {st.median(d):.2f} us grid {r0[0]['Grid_Size_X']} vgpr {r0[0].get('VGPR_Count','')}")

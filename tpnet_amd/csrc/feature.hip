@@ -37,8 +37,13 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
     __shared__ __attribute__((aligned(16))) float feat[GPB * NG];
     __shared__ __attribute__((aligned(16))) float hid[SUB * H];          // [hidden unit][pair of the pass]
     __shared__ __attribute__((aligned(16))) float part[KQ * SUB * NG];   // [slice][pair][output]
+#ifdef TPNET_STAMPS
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(out_gram);   // diagnostic build: out_gram is the stamp buffer
+    out_gram = nullptr;
+#endif
     const int tid = threadIdx.x;
     const int gl = tid % LPP, g = tid / LPP;
+    STAMP(0);
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
     const float* __restrict__ w1t = M.w1t;        // [NG][H]: w1t[k][j] = mlp[0].weight[j][k]
     const float* __restrict__ w2t = M.w2t;        // [H][NG]: w2t[k][o] = mlp[2].weight[o][k]
@@ -50,15 +55,18 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
     constexpr bool WREG = (H == FB) && (KQ * NG == FB);
     float w1r[WREG ? NG : 1], w2r[WREG ? KCH : 1];
     float b1r = 0.0f;
-    bool have_w = false;
     // ppb = pairs per workgroup and pass (<= GPB): a short list is spread over more workgroups with idle lane groups rather
     // than over few full ones (200 pairs at d=64: 13 workgroups of 16 pairs and two dense passes each, or 25 of 8 and one)
+    // (Measured and not kept: the first tile's ids, then the weights, then the readout -- the compiler sinks the second burst
+    // to its first use whatever the scheduling barriers say, and the kernel is 12.4 us against 11.8.)
+    bool have_w = false;
     for (int64_t base = (int64_t)blockIdx.x * ppb; base < n; base += (int64_t)gridDim.x * ppb) {
         const int64_t p = base + g;
         const bool valid = g < ppb && p < n;
         const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
         gram_pair<LPP, VPL, W, L, FULL, false, false, LR>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
                                                           feat + g * NG, gl, nullptr, stage);
+        STAMP(1);
         if constexpr (WREG) {
             if (!have_w) {
                 const int kq = tid / NG, o = tid - kq * NG;
@@ -71,6 +79,7 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
             }
         }
         __syncthreads();
+        STAMP(2);
         const int npair = (n - base < ppb) ? (int)(n - base) : ppb;
         if (out_gram) {                           // the pre-mlp features, for a backward pass (training)
             for (int i = tid; i < npair * NG; i += FB) out_gram[base * NG + i] = feat[i];
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
                 }
             }
             __syncthreads();
+            STAMP(3);
             // ---- out = W2 hidden + b2: thread (slice kq, output o) sums its slice of the hidden axis for all SUB pairs,
             // weights again in bursts of up to 32 independent loads; the KQ partial sums meet in LDS
             if constexpr (WREG) {
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
                 for (int q = 0; q < SUB; ++q) part[(kq * SUB + q) * NG + o] = acc[q];
             }
             __syncthreads();
+            STAMP(4);
             for (int idx = tid; idx < SUB * NG; idx += FB) {
                 const int q = idx / NG, o = idx - q * NG;
                 float sum = part[idx];
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(FB) void k_pair_feature(tpnet_state S, const int64_
                 if (p0 + q < npair) out[(base + p0 + q) * NG + o] = sum + M.b2[o];
             }
             __syncthreads();
+            STAMP(5);
         }
     }
 }

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
                                                           double lambda, uint32_t flags, const void* __restrict__ w1v,
                                                           const float* __restrict__ b1, const void* __restrict__ w2v,
                                                           const float* __restrict__ b2, float* __restrict__ out_gram,
-                                                          float* __restrict__ out, const float* __restrict__ feat_in) {
+                                                          float* __restrict__ out, const float* __restrict__ feat_in, int tp) {
+    // tp = pairs per tile: 32, or GPB (ONE readout pass per tile: a short list spreads over twice / four times the CUs and a
+    // workgroup's readout is one memory round-trip chain deep instead of PT of them; columns of the matrix products beyond tp
+    // compute on stale LDS rows and are never stored -- a pair is one column, nothing crosses columns)
     // feat_in != NULL: the dense layers alone on features that already exist ([n][64] f32): the tile is loaded, not formed
     // bf16: w1 = bf16 [256][64], w2p = bf16 [64][256] (hidden axis permuted per 32-tile, fused_mlp.permute_w2)
     // f32:  w1 = f32 [256][64] (mlp[0].weight as is), w2f = f32 [8 waves][2 output tiles][64 lanes][16 k-steps]
@@ -66,6 +69,14 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE);
+    const int64_t ntiles = (n + tp - 1) / tp;
+    // the first tile's ids BEFORE the weights: vector loads return in order, and the ids (host-mapped memory in the per-batch
+    // calls: a PCIe round trip) are the head of the readout's dependent chain -- the weights' 128 KB arrive underneath it
+    int64_t uu0 = 0, vv0 = 0;
+    if (!feat_in && (int64_t)blockIdx.x < ntiles) {
+        const int64_t p = (int64_t)blockIdx.x * tp + g;
+        if (g < tp && p < n) { uu0 = u[p]; vv0 = v[p]; }
+    }
     // ---- this wave's weights: rows [32 wave, 32 wave + 32) of W1 as A operand, the matching columns of (permuted) W2
     bf16x8 a1[4], a2[2][2];
     bf16x8 a1l[X3 ? 4 : 1], a2l[X3 ? 2 : 1][2];          // MODE 2: the low halves of the split weights
@@ -108,7 +119,6 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
 #pragma unroll
     for (int q = 0; q < 16; ++q) bias1[q] = b1[wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h];
 
-    const int64_t ntiles = (n + 31) / 32;
     // features that already exist: a tile is 512 float4, one per thread; the NEXT tile's piece is fetched while this tile's
     // matrix products run (a tile is otherwise one global round trip + three barriers deep: 8.7 -> ~5 us per tile)
     static_assert(32 * (MF / 4) == MB, "one float4 of the feature tile per thread");
@@ -127,18 +137,19 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
         } else
 #pragma unroll 1
-        for (int pass = 0; pass < PT; ++pass) {
+        for (int pass = 0; pass * GPB < tp; ++pass) {
             const int pidx = pass * GPB + g;
-            const int64_t p = tile * 32 + pidx;
-            const bool valid = p < n;
-            const int64_t uu = valid ? u[p] : 0, vv = valid ? v[p] : 0;
+            const int64_t p = tile * tp + pidx;
+            const bool valid = pidx < tp && p < n;
+            const bool first = pass == 0 && tile == (int64_t)blockIdx.x;
+            const int64_t uu = first ? uu0 : (valid ? u[p] : 0), vv = first ? vv0 : (valid ? v[p] : 0);
             gram_pair<LPP, VPL, W, L, FULL, false, false, false>(S, uu, vv, valid, READER_BID, now, lambda, do_scale,
                                                                  feat + pidx * TS, gl, nullptr, stage1);
         }
         __syncthreads();
-        const int npair = (n - tile * 32 < 32) ? (int)(n - tile * 32) : 32;
+        const int npair = (n - tile * tp < tp) ? (int)(n - tile * tp) : tp;
         if (out_gram) {                           // the pre-mlp features, for a backward pass (training)
-            for (int i = tid; i < npair * MF; i += MB) out_gram[tile * 32 * MF + i] = feat[(i / MF) * TS + (i % MF)];
+            for (int i = tid; i < npair * MF; i += MB) out_gram[tile * tp * MF + i] = feat[(i / MF) * TS + (i % MF)];
         }
         // ---- layer 1, hidden tile `wave`: H^T = W1 . X^T; lane (r, h) holds X[pair r][16 s + 8 h + j] as B operand
         f32x16 acc, y0, y1;
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(MB) void k_pair_feature_bf16(tpnet_state S, const i
                 y.y = ((s0.y + s1.y) + (s2.y + s3.y)) + bb.y;
                 y.z = ((s0.z + s1.z) + (s2.z + s3.z)) + bb.z;
                 y.w = ((s0.w + s1.w) + (s2.w + s3.w)) + bb.w;
-                *reinterpret_cast<float4*>(out + (tile * 32 + pair) * MF + o) = y;
+                *reinterpret_cast<float4*>(out + (tile * tp + pair) * MF + o) = y;
             }
         }
         __syncthreads();                          // the tiles are reused by the next tile of this workgroup
@@ -277,7 +288,11 @@ int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int6
     const Geom gm = pick_geom(st.d);
     if (gm.w != 4 || gm.lpp < 16) return TPNET_ERR_BAD_ARG;       // narrow / scalar rows: readout kernel + tpnet_mlp64_bf16
     const bool full = st.d == gm.lpp * gm.vpl * 4;
-    const int64_t tiles = (n + 31) / 32;
+    // pairs per tile: one readout pass (GPB pairs) while the list has fewer than two 32-pair tiles per CU
+    const int gpb = MB / gm.lpp;
+    static const int tp_dev = TPNET_DEV_INT(FEATURE_TP, 0);
+    const int tp = feat_in ? 32 : (tp_dev ? (tp_dev < gpb ? gpb : (tp_dev > 32 ? 32 : tp_dev)) : ((gpb < 32 && n <= 256 * 64) ? gpb : 32));
+    const int64_t tiles = (n + tp - 1) / tp;
     // (a workgroup's first act is to load its 128 KB of weights: one workgroup per CU, each amortising them over many tiles --
     // 80 000 rows: 51 us with a workgroup per tile up to 2 048, 39 us with 768, 32.5 us with 256; 800 000 rows: 244 / 237)
     static const int grid_cap = TPNET_DEV_INT(MLP_GRID, 256);
@@ -286,13 +301,13 @@ int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int6
     do {                                                                                                                     \
         if (mode == 2)                                                                                                       \
             hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, 2>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now,    \
-                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
+                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in, tp);                                         \
         else if (mode == 1)                                                                                                  \
             hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, 1>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now,    \
-                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
+                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in, tp);                                         \
         else                                                                                                                 \
             hipLaunchKernelGGL((k_pair_feature_bf16<LPP_, VPL_, 4, FULL_, 0>), dim3(grid), dim3(MB), 0, s, st, u, v, n, now,    \
-                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in);                                         \
+                               lambda, flags, w1, b1, w2p, b2, out_gram, out, feat_in, tp);                                         \
     } while (0)
     if (gm.lpp == 16 && gm.vpl == 1) { if (full) TPNET_PF(16, 1, true); else TPNET_PF(16, 1, false); }
     else if (gm.lpp == 16) { if (full) TPNET_PF(16, 2, true); else TPNET_PF(16, 2, false); }
