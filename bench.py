@@ -150,7 +150,7 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
                             "what": f"+ 2 x get_pair_wise_feature on 4*B*K = {4 * B * K} pairs (K = {K}) per batch, host index arrays in the "
                                     "reference's tile / repeat layout (built before the clock starts)"}
     # the same unit with the ids resident on the device end to end (SURVEY section 8 f-3 -> f-2 -> f-1): the batch's src / dst /
-    # neg / t go up in ONE pinned copy, the device sampler draws the K most recent neighbours of the 2B nodes (the neighbour ids
+    # neg / t are staged through the pinned ring (read in place by the row set-up kernel), the device sampler draws the K most recent neighbours of the 2B nodes (the neighbour ids
     # never visit the host), the anchored readout pairs every neighbour with the edge's two endpoints (no index arrays at
     # all), self.mlp runs behind it; then the decoder-level calls as above.  fp32 class; `bf16_mlp`: self.mlp on the bf16 matrix
     # cores (opt-in RandomProjectionModule.fused_mlp, 1e-2 class).
@@ -168,9 +168,8 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
                         torch.cuda.synchronize()
                         t0_ = time.perf_counter()
                     s = slice(b * B, (b + 1) * B)
-                    s_d, d_d, n_d, t_d = rp._to_device(src[s], dst[s], neg[s], t[s])
-                    for other in (d_d, n_d):
-                        rp.encoder_pair_features(smp, s_d, other, t_d, K)
+                    for other in (dst[s], neg[s]):
+                        rp.encoder_pair_features(smp, src[s], other, t[s], K)
                     rp.get_pair_wise_feature(src[s], dst[s])
                     rp.get_pair_wise_feature(src[s], neg[s])
                     rp.update(src[s], dst[s], t[s])
@@ -179,7 +178,7 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
             return {"value": nbe * B / el_, "unit": "edges/s", "us_per_batch": el_ / nbe * 1e6, "what": label}
         if _lib_anchored_ok(rp):
             res["encoder_level_device"] = device_loop(
-                f"ids resident on the device: 1 pinned copy of the batch + 2 x encoder_pair_features (device sampler, K = {K}; "
+                f"neighbour ids resident on the device: 2 x encoder_pair_features on the batch's host arrays (staged, no copy; device sampler, K = {K}; "
                 f"anchored readout of 4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls")
             if rp.num_layer == 3:
                 rp.fused_mlp = True

@@ -35,7 +35,8 @@ extern "C" {
                                3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream);
                                4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
                                     (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored;
-                               5: + tpnet_run_stream_tagged / tpnet_plan_tag (a stream's plan replayed across epochs) */
+                               5: + tpnet_run_stream_tagged / tpnet_plan_tag (a stream's plan replayed across epochs), the encoder's call as one
+                                    crossing (tpnet_anchored_features, tpnet_encoder_features, tpnet_host_encoder_features) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -392,6 +393,14 @@ int tpnet_encoder_features(const tpnet_state* st, const void* sampler, int64_t E
                            const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
                            uint32_t flags, const tpnet_mlp* mlp, void* scratch, size_t scratch_bytes, float* gram, float* out,
                            void* stream);
+
+/* tpnet_encoder_features with the batch's src / other / times as HOST arrays (the reference's loop slices them from the edge
+ * list on the host, train_link_prediction.py:325-340): staged through `stage` (B <= slot_bytes / 24), read in place by the row
+ * set-up kernel; no copy is enqueued.  TPNET_ERR_INDEX for an id outside [0, N). */
+int tpnet_host_encoder_features(const tpnet_state* st, tpnet_stage* stage, const void* sampler, int64_t E, int64_t num_nodes,
+                                const int64_t* h_src, const int64_t* h_other, const double* h_t, int64_t B, int32_t K,
+                                double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, void* scratch,
+                                size_t scratch_bytes, float* gram, float* out, void* stream);
 
 /* ---- the step behind the path (BASELINE config 5): self.mlp = Linear(64,256)->ReLU->Linear(256,64)
  * (models/TPNet.py:64-65,129) fused in one kernel on the bf16 matrix cores, fp32 accumulate, L = 3 only.

@@ -325,5 +325,12 @@ def test_encoder_call_with_device_resident_ids(d, L, K):
             got, neigh_d = rp.encoder_pair_features(gpu, dev(src[s]), dev(other), dev(t[s]), K)
             np.testing.assert_array_equal(neigh_d.cpu().numpy(), neigh_h)
             np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-4, atol=2e-4)
+            # the batch's arrays handed over as the reference's loop holds them (host numpy slices, staged through the pinned
+            # ring, no copy enqueued): the same kernels on the same ids -> the same bits
+            got_h, neigh_dh = rp.encoder_pair_features(gpu, src[s], other, t[s], K)
+            np.testing.assert_array_equal(neigh_dh.cpu().numpy(), neigh_h)
+            np.testing.assert_array_equal(got_h.detach().cpu().numpy(), got.detach().cpu().numpy())
         rp.update(src[s], dst[s], t[s])
     rp.check_device_errors()
+    with pytest.raises(IndexError):
+        rp.encoder_pair_features(gpu, np.array([1, N], dtype=np.int64), np.array([1, 2], dtype=np.int64), np.array([2e6, 2e6]), K)

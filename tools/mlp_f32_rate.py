@@ -15,7 +15,7 @@ def timeit(fn, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 with torch.no_grad():
-    for n in (2000, 20000, 80000, 800000):
+    for n in (2000, 8192, 20000, 80000, 80007, 800000):
         x = torch.rand(n, 64, device="cuda") * 12           # log(1 + G) features: 0 .. ~12
         want = mlp(x.double().cpu().to(torch.float64)) if False else None
         ref = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64)).double().cuda()

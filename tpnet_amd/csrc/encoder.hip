@@ -10,6 +10,11 @@
 namespace tpnet {
 
 static int mlp_rows(const tpnet_mlp* mlp, const float* x, int64_t n, float* y, hipStream_t s) {
+    // long lists: every wave its own tiles, split weights in LDS (mlp_x3.hip)
+    if (n >= mlp_x3_from() && mlp_f32_mode() == 2 && mlp_x3_available() &&
+        launch_mlp_rows_x3(x, n, reinterpret_cast<const float*>(mlp->w1), mlp->b1, reinterpret_cast<const float*>(mlp->w2f),
+                           mlp->b2, y, s) == TPNET_OK)
+        return TPNET_OK;
     tpnet_state st{};                      // (not dereferenced when the tile comes from `x`; geometry of d = 128 picks the 32-lane kernel)
     st.N = 1; st.d = 128; st.L = 3;
     return launch_pair_feature_bf16(st, nullptr, nullptr, n, 0.0, 0.0, 0, mlp->w1, mlp->b1, mlp->w2f, mlp->b2, nullptr, y, s,

@@ -338,6 +338,11 @@ extern "C" int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, 
     if (n == 0) return TPNET_OK;
     if (mlp->F != 64 || mlp->H != 256 || !mlp->w1 || !mlp->w2f || !mlp->b1 || !mlp->b2) return TPNET_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TPNET_ERR_BAD_ARG;
+    // long lists: every wave its own tiles, split weights in LDS (mlp_x3.hip)
+    if (n >= mlp_x3_from() && mlp_f32_mode() == 2 && mlp_x3_available() &&
+        launch_mlp_rows_x3(x, n, reinterpret_cast<const float*>(mlp->w1), mlp->b1, reinterpret_cast<const float*>(mlp->w2f),
+                           mlp->b2, y, (hipStream_t)stream) == TPNET_OK)
+        return TPNET_OK;
     tpnet_state st{};                      // (not dereferenced when the tile comes from `x`; geometry of d = 128 picks the 32-lane kernel)
     st.N = 1; st.d = 128; st.L = 3;
     return launch_pair_feature_bf16(st, nullptr, nullptr, n, 0.0, 0.0, 0, mlp->w1, mlp->b1, mlp->w2f, mlp->b2, nullptr, y,

@@ -210,4 +210,32 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
     return launch_step(*st, a, p, 0, B, (int32_t)B, lambda, launch_id, flags | ROLE_UPDATE, s);
 }
 
+// The encoder's whole readout for one (src, other) batch (tpnet_encoder_features) with the BATCH's arrays on the host -- what the
+// reference's loop holds (train_link_prediction.py:325-340: numpy slices of the edge list): the three arrays go through the staging
+// ring and the row set-up kernel reads them there, so the call enqueues no copy (a pinned copy + its cross-queue barrier is ~20 us
+// of GPU timeline per batch in the rocprofv3 trace of bench.py's encoder-level loop).  Ids outside [0, N) give TPNET_ERR_INDEX.
+int tpnet_host_encoder_features(const tpnet_state* st, tpnet_stage* stage, const void* sampler, int64_t E, int64_t num_nodes,
+                                const int64_t* h_src, const int64_t* h_other, const double* h_t, int64_t B, int32_t K,
+                                double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, void* scratch,
+                                size_t scratch_bytes, float* gram, float* out, void* stream) {
+    if (!st || !stage || st->N < 1 || B < 0 || (B > 0 && (!h_src || !h_other || !h_t))) return TPNET_ERR_BAD_ARG;
+    if (B == 0) return TPNET_OK;
+    char *host = nullptr, *dev = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = stage_acquire(stage, (size_t)B * 24, s, &host, &dev);
+    if (rc) return rc;
+    int64_t* hs = reinterpret_cast<int64_t*>(host);
+    for (int64_t i = 0; i < B; ++i) {
+        if ((uint64_t)h_src[i] >= (uint64_t)st->N || (uint64_t)h_other[i] >= (uint64_t)st->N) return TPNET_ERR_INDEX;
+        hs[i] = h_src[i];
+        hs[B + i] = h_other[i];
+    }
+    memcpy(hs + 2 * B, h_t, (size_t)B * 8);
+    const int64_t* ds = reinterpret_cast<const int64_t*>(dev);
+    rc = tpnet_encoder_features(st, sampler, E, num_nodes, ds, ds + B, reinterpret_cast<const double*>(ds + 2 * B), B, K, now_time,
+                                lambda, flags, mlp, scratch, scratch_bytes, gram, out, stream);
+    if (rc) return rc;
+    return stage_release(stage, (size_t)B * 24, s);                   // (the row set-up kernel is the only reader of the slot)
+}
+
 }  // extern "C"

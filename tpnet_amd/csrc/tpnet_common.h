@@ -166,6 +166,11 @@ int launch_pair_feature(const tpnet_state& st, const int64_t* u, const int64_t* 
 // readout + mlp on the matrix cores (feature_mfma.hip): bf16 (opt-in class) or fp32 (f32 = true: w1 = f32 [256][64], w2 = the
 // gathered f32 layout of tpnet_mlp::w2f)
 bool pair_feature_mfma_supported(const tpnet_state& st);
+// mlp_x3.hip: the fp32-class dense layers on existing feature rows, every wave its own 32-row tiles, split weights in LDS
+bool mlp_x3_available();
+int64_t mlp_x3_from();
+int launch_mlp_rows_x3(const float* x, int64_t n, const float* w1f, const float* b1, const float* w2f, const float* b2, float* y,
+                       hipStream_t s);
 int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int64_t* v, int64_t n, double now, double lambda,
                              uint32_t flags, const void* w1, const float* b1, const void* w2p, const float* b2,
                              float* out_gram, float* out, hipStream_t s, int mode, const float* feat_in = nullptr);

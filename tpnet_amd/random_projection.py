@@ -717,14 +717,28 @@ class RandomProjectionModule(nn.Module):
                               num_neighbors: int):
         """Extension: the encoder's whole readout for one (src, other) batch with the ids resident on the device
         (models/TPNet.py:280-324): `sampler` = a GpuRecentNeighborSampler, src_ids / other_ids int64 [B] and times float64 [B] on
-        the device.  Returns (features [4*B*K, (2L+2)^2] in the reference's row order with self.mlp applied, neighbour ids
+        the device, or all three as host numpy arrays (the reference's batch slices: staged, no copy enqueued).  Returns (features [4*B*K, (2L+2)^2] in the reference's row order with self.mlp applied, neighbour ids
         [2B, K] on the device).  One FFI call = row set-up + neighbour sampling + anchored readout; self.mlp behind it."""
         self._ensure_engine()
         dev = self._dev()
-        B, K = int(src_ids.numel()), int(num_neighbors)
-        for name, x, dt in (("src_ids", src_ids, torch.int64), ("other_ids", other_ids, torch.int64), ("times", times, torch.float64)):
-            if x.device != dev or x.dtype != dt or x.dim() != 1 or x.numel() != B or not x.is_contiguous():
-                raise ValueError(f"encoder_pair_features: {name} must be a contiguous {dt} tensor of {B} elements on {dev}")
+        host = isinstance(src_ids, np.ndarray)
+        if host:
+            # the batch's arrays as the reference's loop holds them (numpy slices of the edge list): staged through the pinned ring
+            # and read there by the row set-up kernel -- no copy is enqueued
+            src_ids = self._host_ids(src_ids, "src_ids")
+            other_ids = self._host_ids(other_ids, "other_ids")
+            times = np.ascontiguousarray(np.asarray(times), dtype=np.float64)
+            B, K = int(src_ids.size), int(num_neighbors)
+            if other_ids is None or other_ids.size != B or times.size != B:
+                raise ValueError("encoder_pair_features: src_ids, other_ids and times must be host arrays of one length")
+            if B > self._eng["stage"].max_host_batch:
+                s_d, o_d, t_d = self._to_device(self._check_ids(src_ids, "src_ids"), self._check_ids(other_ids, "other_ids"), times)
+                return self.encoder_pair_features(sampler, s_d, o_d, t_d, num_neighbors)
+        else:
+            B, K = int(src_ids.numel()), int(num_neighbors)
+            for name, x, dt in (("src_ids", src_ids, torch.int64), ("other_ids", other_ids, torch.int64), ("times", times, torch.float64)):
+                if x.device != dev or x.dtype != dt or x.dim() != 1 or x.numel() != B or not x.is_contiguous():
+                    raise ValueError(f"encoder_pair_features: {name} must be a contiguous {dt} tensor of {B} elements on {dev}")
         lib = _lib.load()
         NG = self.pair_wise_feature_dim
         nbytes = lib.tpnet_encoder_scratch_bytes(B, K)
@@ -737,6 +751,13 @@ class RandomProjectionModule(nn.Module):
             # ONE call, self.mlp included: the dense layers of a chunk of rows run beside the readout of the next one
             def launch(gram):
                 out = torch.empty((4 * B * K, NG), dtype=torch.float32, device=dev)
+                if host:
+                    _lib.check(lib.tpnet_host_encoder_features(
+                        self._st_ref(), self._eng["stage"].handle, sampler._buf.data_ptr(), sampler.E, sampler.num_nodes,
+                        src_ids.ctypes.data, other_ids.ctypes.data, times.ctypes.data, B, K, self._now_host,
+                        float(self.time_decay_weight), flags, prep[2], scratch.data_ptr(), nbytes, gram.data_ptr(), out.data_ptr(),
+                        _raw_stream(self._eng["dev_index"])), "host_encoder_features")
+                    return out
                 _lib.check(lib.tpnet_encoder_features(self._st_ref(), sampler._buf.data_ptr(), sampler.E, sampler.num_nodes,
                                                       src_ids.data_ptr(), other_ids.data_ptr(), times.data_ptr(), B, K,
                                                       self._now_host, float(self.time_decay_weight), flags, prep[2],
@@ -746,6 +767,9 @@ class RandomProjectionModule(nn.Module):
             if _ff.needs_grad(prep[4]):
                 return _ff.apply_with_grad(self.mlp, launch, 4 * B * K, NG), neigh
             return launch(torch.empty((4 * B * K, NG), dtype=torch.float32, device=dev)), neigh
+        if host:
+            s_d, o_d, t_d = self._to_device(self._check_ids(src_ids, "src_ids"), self._check_ids(other_ids, "other_ids"), times)
+            return self.encoder_pair_features(sampler, s_d, o_d, t_d, num_neighbors)
         out = torch.empty((2, 2 * B * K, NG), dtype=torch.float32, device=dev)
         _lib.check(lib.tpnet_encoder_gram(self._st_ref(), sampler._buf.data_ptr(), sampler.E, sampler.num_nodes, src_ids.data_ptr(),
                                           other_ids.data_ptr(), times.data_ptr(), B, K, self._now_host,
