@@ -369,7 +369,8 @@ def main():
         out_neg = torch.empty((K * Bg, NG), dtype=torch.float32, device=dev)
         # buffers are touched once before any clock starts (torch.empty hands out pages the GPU has never mapped; their
         # first touch inside a 200 us timed region showed as 25 % run-to-run spread)
-        rp._workspace(K * Bg, Bg, stream=True).zero_()
+        rp.reserve_stream(K * Bg, Bg)                # (the timed call's workspace exists before the warm-up steps run)
+        rp._eng["ws"].zero_()
         out_pos.zero_()
         out_neg.zero_()
         import gc

@@ -934,7 +934,8 @@ def test_version_protocol_under_multi_pass_grids(d, B, N):
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 400, 64, 50), (64, 2, 3000, 200, 90), (128, 3, 9000, 1000, 20),
                                         (256, 3, 500, 500, 13), (16, 4, 300, 100, 70), (512, 1, 200, 2048, 5),
-                                        (120, 3, 260, 40, 200), (128, 3, 50, 1000, 12)])
+                                        (120, 3, 260, 40, 200), (128, 3, 50, 1000, 12),
+                                        (16, 3, 60000, 100, 40)])      # (many nodes, few edges: the chain table is hashed)
 def test_three_launch_planner_equals_chunk_planner(d, L, N, B, nb):
     """Both planners of the windowed schedule describe the same runs (blocks of 8 contributions in index order, the same
     versions read): features and state are equal bit for bit, whatever the window length each picks."""

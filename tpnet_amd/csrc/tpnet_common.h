@@ -269,7 +269,7 @@ struct WPlan {
     uint32_t* rhead;      // [2*Ec] sorted position -> first position of its (node, batch) run
     unsigned long long* wmask;   // [N] hashed planner (wplan3.hip): bit w = the node is a target in window w of the chunk
     uint32_t* wcls;       // [2][WIN_MAX_WINDOWS][8] chains per (window, length class); placement cursors; then [WIN_MAX_WINDOWS] position cursors
-    void* wtab;           // two open-addressing tables of wplan3_table_bytes(Ec) bytes in all
+    void* wtab;           // the chain table, then the runs' per-batch segments: wplan3_table_bytes(Ec, batch) bytes in all
     size_t wzero_bytes;   // wmask, wcls and wtab are contiguous: what one fill has to zero before a plan
     uint32_t* wblk;       // per-workgroup counts / bases of the hashed planner (wplan3_blk_bytes)
     uint32_t heavy_thr;   // contributions per (node, window) above which a workgroup per column part walks the chain
@@ -288,7 +288,7 @@ int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const
 // replay = the workspace still holds this plan of the SAME stream on the SAME table state: only the negatives' readout
 // references are formed again
 bool wplan3_applies(const tpnet_state& st, int64_t Ec, int64_t batch, int K);
-size_t wplan3_table_bytes(int64_t Ec);
+size_t wplan3_table_bytes(int64_t Ec, int64_t batch);
 size_t wplan3_blk_bytes(int64_t Ec, int64_t batch);
 int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                  const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,

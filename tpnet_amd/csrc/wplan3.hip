@@ -31,7 +31,11 @@ static constexpr uint32_t WT_WIN_LAST = 2u;         // bflags: tail of its node'
 static constexpr uint32_t WT_STRUCT_MASK = WREF_RUN_HEAD | WREF_RUN_TAIL | WREF_BLK_HEAD | WREF_BLK_TAIL;
 static constexpr int WCLS = 8;                      // length classes of a window's chain list (class 0: workgroup-walked)
 
-// open-addressing tables (linear probing, at most half full, zeroed before every plan): key 0 = empty
+// H1, runs: one open-addressing SEGMENT per batch (linear probing inside the segment, at most two thirds full), built by the
+// batch's workgroup in LDS and written out whole with plain stores -- no global atomics, nothing to zero.  (One chunk-wide
+// table claimed with atomicCAS cost k_wsort 25 of its 37 us: ~240 000 scattered returning atomics per epoch of C2.)
+// H2, chains: indexed [window][node] where that fits the table's bytes (one non-returning atomic OR per run marks the batch);
+// else open addressing over the whole table (key 0 = empty; zeroed before every plan).
 struct HEnt {
     unsigned long long key;
     uint32_t a, b;
@@ -46,6 +50,18 @@ struct CEnt {                  // chain table: one entry per (node, window)
 };
 static_assert(sizeof(CEnt) == 32, "CEnt must be 32 bytes");
 
+#ifdef TPNET_STAMPS
+#define WSTAMP(slot)                                                                          \
+    do {                                                                                      \
+        if (q.dbg && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {                       \
+            q.dbg[(slot) * 2 + 0] = __builtin_amdgcn_s_memtime();                             \
+            q.dbg[(slot) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                         \
+        }                                                                                     \
+    } while (0)
+#else
+#define WSTAMP(slot) do { } while (0)
+#endif
+
 struct WTmp {              // scratch of the stages, aliased onto arrays of the base plan that this planner does not use
     uint32_t* bkey;        // [nc] target node of the contribution at this batch-sorted position (batch b owns [2 e0(b), ...))
     int32_t* bpart;        // [nc] its partner
@@ -58,17 +74,29 @@ struct WTmp {              // scratch of the stages, aliased onto arrays of the 
     uint32_t* bflags;      // [nc] WREF_* structure bits | WT_*
     HEnt* h1;              // (node, batch) -> a = chunk-relative batch-sorted position of the run's head, b = its length
     CEnt* h2;              // (node, window) -> the batches the node is a target in, its chain
-    uint32_t hcap;         // entries of each
+    uint32_t hcap;         // entries of H2
+    uint32_t seg;          // entries of a batch's segment of H1
+    uint32_t direct2;      // H2 is indexed [window][node] (n2 nodes per window)
+    uint32_t n2;
     uint32_t* blkcnt;      // [nblk][9] per workgroup of k_wchains: chain heads per length class, positions their chains need
     uint32_t* blkbase;     // [nblk][9] k_wscan: the same, summed over the earlier workgroups of the window
     uint32_t* boff;        // [nc] chain heads: what the chain heads before it in its workgroup claimed (positions)
     uint32_t* wtot;        // [WIN_MAX_WINDOWS][9] k_wscan: the window's totals of the same counters
     uint32_t bpb;          // workgroups of k_wchains per batch
+    unsigned long long* dbg;   // diagnostic builds (-DTPNET_STAMPS): phase stamps of workgroup `stamp block`
 };
 
-static inline uint32_t wplan3_table_entries(size_t nc) { return (uint32_t)(2 * nc + 1021); }   // at most half full
-size_t wplan3_table_bytes(int64_t Ec) {
-    return (size_t)wplan3_table_entries(2 * (size_t)Ec) * (sizeof(HEnt) + sizeof(CEnt)) + 256;
+static inline uint32_t wplan3_table_entries(size_t nc) { return (uint32_t)(2 * nc + 1021); }   // H2: at most half full
+// contributions a workgroup of k_wsort sorts (its BS * IPT), and the segment of H1 it builds: the LDS of its three per-edge arrays
+static inline uint32_t wplan3_nc_block(int64_t batch) {
+    const int64_t n2 = 2 * batch;
+    return n2 <= 512 ? 512u : n2 <= 1024 ? 1024u : n2 <= 2048 ? 2048u : 4096u;
+}
+static inline uint32_t wplan3_seg(int64_t batch) { return wplan3_nc_block(batch) / 2 * 3; }
+static inline size_t wplan3_h2_bytes(int64_t Ec) { return (size_t)wplan3_table_entries(2 * (size_t)Ec) * sizeof(CEnt); }
+size_t wplan3_table_bytes(int64_t Ec, int64_t batch) {
+    const size_t nb = (size_t)((Ec + batch - 1) / batch);
+    return wplan3_h2_bytes(Ec) + 256 + nb * wplan3_seg(batch) * sizeof(HEnt) + 256;
 }
 static inline uint32_t wplan3_bpb(int64_t batch) { return (uint32_t)((2 * batch + 255) / 256); }
 size_t wplan3_blk_bytes(int64_t Ec, int64_t batch) {
@@ -78,6 +106,7 @@ size_t wplan3_blk_bytes(int64_t Ec, int64_t batch) {
 
 static WTmp wtmp_of(const WPlan& p, size_t nc) {
     WTmp q;
+    q.dbg = p.base.dbg;
     uint32_t* ki = reinterpret_cast<uint32_t*>(p.base.keys_in);     // 8 nc bytes
     uint32_t* ko = reinterpret_cast<uint32_t*>(p.base.keys_out);    // 8 nc bytes
     uint32_t* hv = reinterpret_cast<uint32_t*>(p.base.heavy);       // 32 nc bytes (the chunk planner's chains_sparse)
@@ -91,9 +120,12 @@ static WTmp wtmp_of(const WPlan& p, size_t nc) {
     q.rprevb = hv + 2 * nc;
     q.bflags = hv + 3 * nc;
     const uint32_t cap = wplan3_table_entries(nc);
-    q.h1 = reinterpret_cast<HEnt*>(p.wtab);
-    q.h2 = reinterpret_cast<CEnt*>(q.h1 + cap);
+    q.h2 = reinterpret_cast<CEnt*>(p.wtab);                          // (first: the fill of a plan ends behind what H2 uses)
+    q.h1 = reinterpret_cast<HEnt*>(reinterpret_cast<char*>(p.wtab) + (wplan3_h2_bytes((int64_t)(nc / 2)) + 255) / 256 * 256);
     q.hcap = cap;
+    q.seg = 0;
+    q.direct2 = 0;
+    q.n2 = 0;
     q.boff = p.rhead;
     q.wtot = p.wcls;
     return q;
@@ -115,71 +147,79 @@ __device__ __forceinline__ uint32_t hmix(unsigned long long k) {
 __device__ __forceinline__ unsigned long long hkey(uint32_t node, uint32_t minor) {      // minor: batch (H1) / window (H2), < 2^16
     return ((unsigned long long)(node + 1u) << 16) | (unsigned long long)minor;
 }
-__device__ __forceinline__ void hinsert(HEnt* __restrict__ T, uint32_t cap, unsigned long long key, uint32_t a, uint32_t b) {
-    uint32_t i = hmix(key) % cap;
-    for (;;) {                                           // (keys are distinct and the table is at most half full: terminates)
-        const unsigned long long old = atomicCAS(&T[i].key, 0ull, key);
-        if (old == 0ull || old == key) { T[i].a = a; T[i].b = b; return; }
-        i = (i + 1 == cap) ? 0u : i + 1;
-    }
-}
-__device__ __forceinline__ bool hfind(const HEnt* __restrict__ T, uint32_t cap, unsigned long long key, uint32_t& a, uint32_t& b) {
-    uint32_t i = hmix(key) % cap;
+// the run of (node, batch): a = chunk-relative batch-sorted position of its head, b = its length (false: the node is no target there)
+__device__ __forceinline__ bool hfind(const HEnt* __restrict__ T, uint32_t seg, unsigned long long key, uint32_t& a, uint32_t& b) {
+    const HEnt* __restrict__ S = T + (size_t)(key & 0xFFFFull) * seg;
+    uint32_t i = hmix(key) % seg;
     for (;;) {
-        const uint4 e = *reinterpret_cast<const uint4*>(T + i);
+        const uint4 e = *reinterpret_cast<const uint4*>(S + i);
         const unsigned long long k = ((unsigned long long)e.y << 32) | e.x;
         if (k == key) { a = e.z; b = e.w; return true; }
         if (k == 0ull) { a = 0; b = 0; return false; }
-        i = (i + 1 == cap) ? 0u : i + 1;
+        i = (i + 1 == seg) ? 0u : i + 1;
     }
 }
 
 // G probes at once: all first loads are issued before any is looked at (a loop per probe would be G dependent round
-// trips); a probe that lands on another key's slot walks on alone (rare: the tables are at most half full)
+// trips); a probe that lands on another key's slot walks on alone (rare: a segment is at most two thirds full)
 template <int G>
-__device__ __forceinline__ void hfind_multi(const HEnt* __restrict__ T, uint32_t cap, const unsigned long long* key,
+__device__ __forceinline__ void hfind_multi(const HEnt* __restrict__ T, uint32_t seg, const unsigned long long* key,
                                             const bool* valid, uint32_t* a, uint32_t* b) {
     uint32_t idx[G];
     uint4 e[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        idx[g] = hmix(key[g]) % cap;
-        e[g] = *reinterpret_cast<const uint4*>(T + (valid[g] ? idx[g] : 0u));
+        idx[g] = hmix(key[g]) % seg;
+        e[g] = *reinterpret_cast<const uint4*>(T + (valid[g] ? (size_t)(key[g] & 0xFFFFull) * seg + idx[g] : (size_t)0));
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         a[g] = 0;
         b[g] = 0;
         if (!valid[g]) continue;
+        const HEnt* __restrict__ S = T + (size_t)(key[g] & 0xFFFFull) * seg;
         uint32_t i = idx[g];
         uint4 x = e[g];
         for (;;) {
             const unsigned long long k = ((unsigned long long)x.y << 32) | x.x;
             if (k == key[g]) { a[g] = x.z; b[g] = x.w; break; }
             if (k == 0ull) break;
-            i = (i + 1 == cap) ? 0u : i + 1;
-            x = *reinterpret_cast<const uint4*>(T + i);
+            i = (i + 1 == seg) ? 0u : i + 1;
+            x = *reinterpret_cast<const uint4*>(S + i);
         }
     }
 }
 
-// chain table: A marks the batch in the node's entry of the window (created by whoever comes first)
-__device__ __forceinline__ void cmark(CEnt* __restrict__ T, uint32_t cap, unsigned long long key, unsigned bit) {
-    uint32_t i = hmix(key ^ 0x5bd1e995ull) % cap;
+// chain table: A marks batch `bit` of window w in the node's entry (hashed: created by whoever comes first)
+__device__ __forceinline__ void cmark(const WTmp& q, uint32_t node, uint32_t w, unsigned bit) {
+    if (q.direct2) {
+        (void)__hip_atomic_fetch_or(&q.h2[(size_t)w * q.n2 + node].mask, 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const unsigned long long key = hkey(node, w);
+    uint32_t i = hmix(key ^ 0x5bd1e995ull) % q.hcap;
     for (;;) {
-        const unsigned long long old = atomicCAS(&T[i].key, 0ull, key);
-        if (old == 0ull || old == key) { atomicOr(&T[i].mask, 1ull << bit); return; }
-        i = (i + 1 == cap) ? 0u : i + 1;
+        const unsigned long long old = atomicCAS(&q.h2[i].key, 0ull, key);
+        if (old == 0ull || old == key) {
+            (void)__hip_atomic_fetch_or(&q.h2[i].mask, 1ull << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        i = (i + 1 == q.hcap) ? 0u : i + 1;
     }
 }
-// the entry of `key` (nullptr: none)
-__device__ __forceinline__ CEnt* cfind(CEnt* __restrict__ T, uint32_t cap, unsigned long long key) {
-    uint32_t i = hmix(key ^ 0x5bd1e995ull) % cap;
+// the entry of (node, window) (nullptr: the node is no target in the window)
+__device__ __forceinline__ CEnt* cfind(const WTmp& q, uint32_t node, uint32_t w) {
+    if (q.direct2) {
+        CEnt* e = q.h2 + ((size_t)w * q.n2 + node);
+        return e->mask ? e : nullptr;
+    }
+    const unsigned long long key = hkey(node, w);
+    uint32_t i = hmix(key ^ 0x5bd1e995ull) % q.hcap;
     for (;;) {
-        const unsigned long long k = T[i].key;
-        if (k == key) return T + i;
+        const unsigned long long k = q.h2[i].key;
+        if (k == key) return q.h2 + i;
         if (k == 0ull) return nullptr;
-        i = (i + 1 == cap) ? 0u : i + 1;
+        i = (i + 1 == q.hcap) ? 0u : i + 1;
     }
 }
 
@@ -204,12 +244,19 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
         typename Sort::storage_type sort;
         struct { uint32_t key[NC]; uint32_t ustart[NC]; } s;     // sorted keys; then the heads of the distinct targets' runs
     } u;
-    __shared__ uint32_t e_src[NC / 2], e_dst[NC / 2];   // endpoint (0 if out of range) | bit 31: the EDGE has a bad endpoint
-    __shared__ float e_w[NC / 2];
+    // per edge: endpoints (0 if out of range) | bit 31: the EDGE has a bad endpoint; time weight.  Dead once the sorted arrays are
+    // stored: the batch's segment of H1 is then built in the same 3 * NC / 2 words
+    __shared__ uint32_t e_all[3 * (NC / 2)];
+    uint32_t* const e_src = e_all;
+    uint32_t* const e_dst = e_all + NC / 2;
+    float* const e_w = reinterpret_cast<float*>(e_all + NC);
+    constexpr uint32_t SEG = 3 * (NC / 2);
     __shared__ uint32_t wsum[BS / 64];
     static_assert(sizeof(U) + 3 * (NC / 2) * 4 + (BS / 64) * 4 <= 64 * 1024, "k_wsort: LDS budget");
+    static_assert(NC <= 65535 / 2 * 2, "k_wsort: run indices");
     const int tid = threadIdx.x;
     const int nc = 2 * B;
+    WSTAMP(0);
     constexpr int EPT = IPT / 2;
     int64_t rs[EPT], rd[EPT];
     double rt[EPT];
@@ -238,6 +285,7 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
         }
     }
     __syncthreads();
+    WSTAMP(1);
     uint32_t keys[IPT], vals[IPT];
     const uint32_t pad_key = 1u << node_bits;            // above every node id: padding sorts last
 #pragma unroll
@@ -254,6 +302,7 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
     }
     Sort().sort(keys, vals, u.sort, 0u, (unsigned)(node_bits + 1));
     __syncthreads();
+    WSTAMP(2);
 #pragma unroll
     for (int k = 0; k < IPT; ++k) u.s.key[tid * IPT + k] = keys[k];
     __syncthreads();
@@ -288,6 +337,8 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
+    WSTAMP(3);
+    for (uint32_t i = tid; i < SEG; i += BS) e_all[i] = 0u;      // (every thread has read its edges' entries: the barrier above)
     uint32_t base = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < BS / 64; ++i) {
@@ -304,20 +355,33 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
         }
     }
     __syncthreads();
+    WSTAMP(4);
+    // ---- the runs: the batch's segment of H1 in LDS (slot = run + 1; the runs' nodes are distinct: a claim needs no key
+    // compare), the node's entry of the chain table marked with this batch
     for (uint32_t r = tid; r < total; r += BS) {
         const uint32_t st = u.s.ustart[r];
-        const uint32_t en = (r + 1 < total) ? u.s.ustart[r + 1] : (uint32_t)nc;
-        // the run's entry of H1 and the node's entry of the chain table: both claims in flight together
-        const unsigned long long k1 = hkey(u.s.key[st], (uint32_t)bb), k2 = hkey(u.s.key[st], (uint32_t)(bb / KW));
-        uint32_t i1 = hmix(k1) % q.hcap, i2 = hmix(k2 ^ 0x5bd1e995ull) % q.hcap;
-        unsigned long long o1 = atomicCAS(&q.h1[i1].key, 0ull, k1);
-        unsigned long long o2 = atomicCAS(&q.h2[i2].key, 0ull, k2);
-        while (o1 != 0ull && o1 != k1) { i1 = (i1 + 1 == q.hcap) ? 0u : i1 + 1; o1 = atomicCAS(&q.h1[i1].key, 0ull, k1); }
-        q.h1[i1].a = (uint32_t)(g0 + st);
-        q.h1[i1].b = en - st;
-        while (o2 != 0ull && o2 != k2) { i2 = (i2 + 1 == q.hcap) ? 0u : i2 + 1; o2 = atomicCAS(&q.h2[i2].key, 0ull, k2); }
-        (void)__hip_atomic_fetch_or(&q.h2[i2].mask, 1ull << (unsigned)(bb % KW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t node = u.s.key[st];
+        uint32_t i = hmix(hkey(node, (uint32_t)bb)) % SEG;
+        while (atomicCAS(&e_all[i], 0u, r + 1u) != 0u) i = (i + 1 == SEG) ? 0u : i + 1;
+        cmark(q, node, (uint32_t)(bb / KW), (unsigned)(bb % KW));
     }
+    __syncthreads();
+    {
+        HEnt* __restrict__ S = q.h1 + (size_t)bb * SEG;
+        for (uint32_t i = tid; i < SEG; i += BS) {
+            const uint32_t v = e_all[i];
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            if (v) {
+                const uint32_t r = v - 1u;
+                const uint32_t st = u.s.ustart[r];
+                const uint32_t en = (r + 1 < total) ? u.s.ustart[r + 1] : (uint32_t)nc;
+                const unsigned long long k1 = hkey(u.s.key[st], (uint32_t)bb);
+                e = make_uint4((uint32_t)k1, (uint32_t)(k1 >> 32), (uint32_t)(g0 + st), en - st);
+            }
+            *reinterpret_cast<uint4*>(S + i) = e;
+        }
+    }
+    WSTAMP(5);
     if (tid == 0) {
         BatchDesc D;
         D.e0 = e0;
@@ -327,10 +391,12 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
         D.now = (bb == 0) ? (t_prev ? *t_prev : now_time) : t_c[e0 - 1];   // clock left by the previous batch (TPNet.py:99)
         D.n_light = 0;
         D.n_heavy = 0;
-        const double g = exp(-lambda * (t_last - D.now));
-        for (int i = 0; i < TPNET_MAX_LAYERS; ++i) D.decay[i] = (i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;
+        // (the dense decay's factors are read by the eager mode only, which never takes the windowed schedule: no exp / pow here --
+        // ~2 us of this one thread's time at the tail of the workgroup)
+        for (int i = 0; i < TPNET_MAX_LAYERS; ++i) D.decay[i] = 1.0f;
         desc[bb] = D;
     }
+    WSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -361,7 +427,7 @@ __global__ __launch_bounds__(256) void k_wchains(WPlan p, WTmp q, int64_t Ec, in
     if (active) {
         // the batches of the window the node is a target in (A marked them): probe H1 for this batch and the EARLIER ones --
         // and, where there is no earlier one (the chain's first run: its head needs the chain's length), the later ones too
-        ce = cfind(q.h2, q.hcap, hkey(node, (uint32_t)w));
+        ce = cfind(q, node, (uint32_t)w);
         const unsigned kb = (unsigned)(b - bw0);
         const unsigned long long mask = ce->mask;
         const unsigned long long before = mask & ((1ull << kb) - 1ull);
@@ -381,7 +447,7 @@ __global__ __launch_bounds__(256) void k_wchains(WPlan p, WTmp q, int64_t Ec, in
                 if (valid[g]) todo &= todo - 1ull;
                 keys[g] = hkey(node, (uint32_t)(bw0 + bit[g]));
             }
-            hfind_multi<G>(q.h1, q.hcap, keys, valid, st, len);
+            hfind_multi<G>(q.h1, q.seg, keys, valid, st, len);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (valid[g]) {
@@ -471,7 +537,7 @@ __device__ __forceinline__ void chain_of(const WPlan& p, const WTmp& q, int64_t 
 }
 __device__ __forceinline__ void chain_of(const WPlan& p, const WTmp& q, int64_t Bfull, uint32_t node, int64_t w, uint32_t& base,
                                          uint32_t& cnt, int64_t& last_b) {
-    chain_of(p, q, Bfull, cfind(q.h2, q.hcap, hkey(node, (uint32_t)w)), w, base, cnt, last_b);
+    chain_of(p, q, Bfull, cfind(q, node, (uint32_t)w), w, base, cnt, last_b);
 }
 
 __device__ __forceinline__ VRef version_before_window_m(const WPlan& p, const WTmp& q, int64_t Bfull, int64_t node, int64_t w,
@@ -505,13 +571,13 @@ __device__ __forceinline__ VRef version_before_window(const WPlan& p, const WTmp
 __device__ __forceinline__ VRef version_before_batch(const WPlan& p, const WTmp& q, int64_t Bfull, int64_t node, int64_t b,
                                                      const NodeMeta* __restrict__ meta) {
     const int64_t w = b / p.K, bw0 = w * p.K;
-    const CEnt* ce = cfind(q.h2, q.hcap, hkey((uint32_t)node, (uint32_t)w));
+    const CEnt* ce = cfind(q, (uint32_t)node, (uint32_t)w);
     if (ce) {
         const unsigned long long before = ce->mask & ((1ull << (unsigned)(b - bw0)) - 1ull);
         if (before) {
             const int64_t bp = bw0 + (63 - __clzll((long long)before));      // the latest earlier batch with a run of the node
             uint32_t s, l;
-            hfind(q.h1, q.hcap, hkey((uint32_t)node, (uint32_t)bp), s, l);
+            hfind(q.h1, q.seg, hkey((uint32_t)node, (uint32_t)bp), s, l);
             // the run's tail sits at chain base + contributions before the run + (its length - 1)
             uint32_t base, cnt;
             int64_t lb;
@@ -664,8 +730,8 @@ __global__ __launch_bounds__(256) void k_wrefs(WPlan p, WTmp q, const int64_t* _
         OwnSide s0, s1;
         side_load(q, x0, s0);
         side_load(q, x1, s1);
-        const CEnt* c0 = cfind(q.h2, q.hcap, hkey(s0.node, (uint32_t)w));
-        const CEnt* c1 = cfind(q.h2, q.hcap, hkey(s1.node, (uint32_t)w));
+        const CEnt* c0 = cfind(q, s0.node, (uint32_t)w);
+        const CEnt* c1 = cfind(q, s1.node, (uint32_t)w);
         s0.wm = p.wmask[s0.node];
         s1.wm = p.wmask[s1.node];
         side_version(p, q, Bfull, w, c0, meta, s0);
@@ -693,6 +759,10 @@ int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, cons
     const int64_t nc = 2 * Ec;
     WTmp q = wtmp_of(p, (size_t)nc);
     q.bpb = wplan3_bpb(batch);
+    q.seg = wplan3_seg(batch);
+    const int64_t nw = (nb + p.K - 1) / p.K;
+    q.direct2 = (nw * st.N <= (int64_t)q.hcap) ? 1u : 0u;
+    q.n2 = (uint32_t)st.N;
     q.blkcnt = p.wblk;
     q.blkbase = p.wblk + (size_t)nb * q.bpb * 9;
     int node_bits = 1;
@@ -708,8 +778,10 @@ int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, cons
         }
         return TPNET_OK;
     }
-    // tables, window mask, class counters and window cursors (contiguous in the workspace: ONE fill)
-    TPNET_HIP_TRY(hipMemsetAsync(p.wmask, 0, p.wzero_bytes, s));
+    // window mask, class counters, window cursors and what the chain table uses (contiguous in the workspace: ONE fill; the
+    // runs' table is written whole by k_wsort)
+    const size_t h2_used = (q.direct2 ? (size_t)nw * (size_t)st.N : (size_t)q.hcap) * sizeof(CEnt);
+    TPNET_HIP_TRY(hipMemsetAsync(p.wmask, 0, p.wzero_bytes + h2_used, s));
     // A
     {
 #define TPNET_WSORT(BS_, IPT_)                                                                                              \

@@ -884,6 +884,12 @@ class RandomProjectionModule(nn.Module):
     plan_replay = True             # run_stream: replay the plan of a stream that is run again on the same table state
     last_stream_replayed = False
 
+    def reserve_stream(self, max_edges: int, batch_size: int):
+        """Extension: size the stream workspace for run_stream calls of up to `max_edges` edges in batches of `batch_size` now, so
+        that the first call of that size neither asks the library for the size nor grows the buffer."""
+        self._ensure_engine()
+        self._workspace(int(max_edges), int(batch_size), stream=True)
+
     def run_stream(self, src: torch.Tensor, dst: torch.Tensor, neg, t: torch.Tensor, batch_size: int,
                    want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None,
                    raw: bool = False, packed: bool = False, schedule: str = None, replay: bool = None):
