@@ -31,7 +31,7 @@ static constexpr uint32_t WT_WIN_LAST = 2u;         // bflags: tail of its node'
 static constexpr uint32_t WT_STRUCT_MASK = WREF_RUN_HEAD | WREF_RUN_TAIL | WREF_BLK_HEAD | WREF_BLK_TAIL;
 static constexpr int WCLS = 8;                      // length classes of a window's chain list (class 0: workgroup-walked)
 
-// H1, runs: one open-addressing SEGMENT per batch (linear probing inside the segment, at most two thirds full), built by the
+// H1, runs: one open-addressing SEGMENT per batch (linear probing inside the segment, at most a third full), built by the
 // batch's workgroup in LDS and written out whole with plain stores -- no global atomics, nothing to zero.  (One chunk-wide
 // table claimed with atomicCAS cost k_wsort 25 of its 37 us: ~240 000 scattered returning atomics per epoch of C2.)
 // H2, chains: indexed [window][node] where that fits the table's bytes (one non-returning atomic OR per run marks the batch);
@@ -92,7 +92,7 @@ static inline uint32_t wplan3_nc_block(int64_t batch) {
     const int64_t n2 = 2 * batch;
     return n2 <= 512 ? 512u : n2 <= 1024 ? 1024u : n2 <= 2048 ? 2048u : 4096u;
 }
-static inline uint32_t wplan3_seg(int64_t batch) { return wplan3_nc_block(batch) / 2 * 3; }
+static inline uint32_t wplan3_seg(int64_t batch) { return wplan3_nc_block(batch) * 3; }   // (16-bit slots in 3 * NC / 2 words)
 static inline size_t wplan3_h2_bytes(int64_t Ec) { return (size_t)wplan3_table_entries(2 * (size_t)Ec) * sizeof(CEnt); }
 size_t wplan3_table_bytes(int64_t Ec, int64_t batch) {
     const size_t nb = (size_t)((Ec + batch - 1) / batch);
@@ -161,7 +161,7 @@ __device__ __forceinline__ bool hfind(const HEnt* __restrict__ T, uint32_t seg, 
 }
 
 // G probes at once: all first loads are issued before any is looked at (a loop per probe would be G dependent round
-// trips); a probe that lands on another key's slot walks on alone (rare: a segment is at most two thirds full)
+// trips); a probe that lands on another key's slot walks on alone (rare: a segment is at most a third full)
 template <int G>
 __device__ __forceinline__ void hfind_multi(const HEnt* __restrict__ T, uint32_t seg, const unsigned long long* key,
                                             const bool* valid, uint32_t* a, uint32_t* b) {
@@ -250,7 +250,8 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
     uint32_t* const e_src = e_all;
     uint32_t* const e_dst = e_all + NC / 2;
     float* const e_w = reinterpret_cast<float*>(e_all + NC);
-    constexpr uint32_t SEG = 3 * (NC / 2);
+    constexpr uint32_t SEG = 3 * NC;                  // slots of 16 bits: at most a third full (a probe that walks is a dependent
+                                                      // round trip for every reader of the table: short clusters matter more than bytes)
     __shared__ uint32_t wsum[BS / 64];
     static_assert(sizeof(U) + 3 * (NC / 2) * 4 + (BS / 64) * 4 <= 64 * 1024, "k_wsort: LDS budget");
     static_assert(NC <= 65535 / 2 * 2, "k_wsort: run indices");
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     WSTAMP(3);
-    for (uint32_t i = tid; i < SEG; i += BS) e_all[i] = 0u;      // (every thread has read its edges' entries: the barrier above)
+    for (uint32_t i = tid; i < SEG / 2; i += BS) e_all[i] = 0u;      // (every thread has read its edges' entries: the barrier above)
     uint32_t base = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < BS / 64; ++i) {
@@ -362,14 +363,25 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
         const uint32_t st = u.s.ustart[r];
         const uint32_t node = u.s.key[st];
         uint32_t i = hmix(hkey(node, (uint32_t)bb)) % SEG;
-        while (atomicCAS(&e_all[i], 0u, r + 1u) != 0u) i = (i + 1 == SEG) ? 0u : i + 1;
+        for (;;) {                                       // claim the first empty 16-bit slot from i on (two slots per LDS word)
+            const uint32_t sh = (i & 1u) * 16u;
+            uint32_t old = e_all[i >> 1];
+            bool done = false;
+            while (((old >> sh) & 0xFFFFu) == 0u) {
+                const uint32_t seen = atomicCAS(&e_all[i >> 1], old, old | ((r + 1u) << sh));
+                if (seen == old) { done = true; break; }
+                old = seen;                              // (the word's other slot was claimed meanwhile, or this one)
+            }
+            if (done) break;
+            i = (i + 1 == SEG) ? 0u : i + 1;
+        }
         cmark(q, node, (uint32_t)(bb / KW), (unsigned)(bb % KW));
     }
     __syncthreads();
     {
         HEnt* __restrict__ S = q.h1 + (size_t)bb * SEG;
         for (uint32_t i = tid; i < SEG; i += BS) {
-            const uint32_t v = e_all[i];
+            const uint32_t v = (e_all[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
             uint4 e = make_uint4(0u, 0u, 0u, 0u);
             if (v) {
                 const uint32_t r = v - 1u;
