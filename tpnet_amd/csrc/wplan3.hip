@@ -68,10 +68,10 @@ struct WTmp {              // scratch of the stages, aliased onto arrays of the 
     float* bcoef;          // [nc] its time weight
     uint32_t* bval;        // [nc] its pre-sort index inside the batch (side * ne + edge)
     uint32_t* binv;        // [nc] chunk-relative pre-sort index -> chunk-relative batch-sorted position
-    uint32_t* bsb;         // [nc] contributions of the node in EARLIER batches of the window
-    uint32_t* bri;         // [nc] rank inside its (node, batch) run
-    uint32_t* rprevb;      // [nc] batch of the node's previous run inside the window (bsb > 0); chain heads: their place in the window's list of their length class
-    uint32_t* bflags;      // [nc] WREF_* structure bits | WT_*
+    uint32_t* bsb;         // [nc] at a run's HEAD: contributions of the node in EARLIER batches of the window
+    uint32_t* bri;         // [nc] rank inside its (node, batch) run (k_wsort)
+    uint32_t* rprevb;      // [nc] at a run's HEAD: batch of the node's previous run inside the window (bsb > 0); chain heads: their place in the window's list of their length class
+    uint32_t* bflags;      // [nc] WREF_* structure bits (k_wsort) | WT_* (k_wchains)
     HEnt* h1;              // (node, batch) -> a = chunk-relative batch-sorted position of the run's head, b = its length
     CEnt* h2;              // (node, window) -> the batches the node is a target in, its chain
     uint32_t hcap;         // entries of H2
@@ -348,15 +348,35 @@ __global__ __launch_bounds__(BS) void k_wsort(WTmp q, BatchDesc* __restrict__ de
         total += v;
     }
     uint32_t rank = base + inc - hcount;
+    uint32_t myrun[IPT];                                 // the run every item of this thread belongs to
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         if (hd[k]) {
             u.s.ustart[rank] = (uint32_t)(tid * IPT + k);
             ++rank;
         }
+        myrun[k] = rank - 1u;                            // (item 0 is a head: never underflows for j < nc)
     }
     __syncthreads();
     WSTAMP(4);
+    // every contribution's rank inside its run and the structure bits that follow from it (k_wchains adds the chain's bits)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid * IPT + k;
+        if (j < nc) {
+            const uint32_t st = u.s.ustart[myrun[k]];
+            const uint32_t en = (myrun[k] + 1 < total) ? u.s.ustart[myrun[k] + 1] : (uint32_t)nc;
+            const uint32_t ri = (uint32_t)j - st;
+            const bool tail = (uint32_t)j + 1u == en;
+            uint32_t fl = 0;
+            if (ri == 0) fl |= WREF_RUN_HEAD;
+            if (tail) fl |= WREF_RUN_TAIL;
+            if (ri % WIN_BLOCK == 0) fl |= WREF_BLK_HEAD;
+            if (ri % WIN_BLOCK == WIN_BLOCK - 1 || tail) fl |= WREF_BLK_TAIL;
+            q.bri[g0 + j] = ri;
+            q.bflags[g0 + j] = fl;
+        }
+    }
     // ---- the runs: the batch's segment of H1 in LDS (slot = run + 1; the runs' nodes are distinct: a claim needs no key
     // compare), the node's entry of the chain table marked with this batch
     for (uint32_t r = tid; r < total; r += BS) {
@@ -432,21 +452,21 @@ __global__ __launch_bounds__(256) void k_wchains(WPlan p, WTmp q, int64_t Ec, in
     if (threadIdx.x < WCLS) l_cls[threadIdx.x] = 0;
     if (threadIdx.x == WCLS) l_pos = 0;
     __syncthreads();
-    const uint32_t node = active ? q.bkey[x] : 0u;
-    uint32_t same_before = 0, same_total = 0, own_start = 0, own_len = 0;
-    int64_t prev_b = -1, last_b = b;
-    CEnt* ce = nullptr;
-    if (active) {
-        // the batches of the window the node is a target in (A marked them): probe H1 for this batch and the EARLIER ones --
-        // and, where there is no earlier one (the chain's first run: its head needs the chain's length), the later ones too
-        ce = cfind(q, node, (uint32_t)w);
-        const unsigned kb = (unsigned)(b - bw0);
-        const unsigned long long mask = ce->mask;
-        const unsigned long long before = mask & ((1ull << kb) - 1ull);
-        const unsigned long long after = (kb >= 63) ? 0ull : (mask >> (kb + 1)) << (kb + 1);
-        if (before) prev_b = bw0 + (63 - __clzll((long long)before));
-        if (after) last_b = bw0 + (63 - __clzll((long long)after));
-        unsigned long long todo = (1ull << kb) | before | (before ? 0ull : after);
+    // a CHAIN HEAD -- the head of its node's first run in the window -- walks the node's runs of the window (the batches A marked
+    // in the chain table; the probes of up to G runs are in flight together) and leaves with every run's head what the run's
+    // contributions need: the chain's contributions before the run, the batch of the previous run.  (Every contribution used to
+    // probe for all earlier runs of its node itself: 2.1 M probes per epoch of C2 against 0.2 M.)
+    const bool run_head = active && q.bri[x] == 0u;
+    const uint32_t node = run_head ? q.bkey[x] : 0u;
+    CEnt* ce = run_head ? cfind(q, node, (uint32_t)w) : nullptr;
+    const unsigned kb = (unsigned)(b - bw0);
+    const unsigned long long mask = ce ? ce->mask : 0ull;
+    const bool chain_head = run_head && (mask & ((1ull << kb) - 1ull)) == 0ull;
+    uint32_t same_total = 0;
+    if (chain_head) {
+        unsigned long long todo = mask;
+        uint32_t prefix = 0, last_tail = 0;
+        int64_t prev_b = -1;
         while (todo) {
             uint32_t st[G], len[G];
             unsigned long long keys[G];
@@ -463,16 +483,17 @@ __global__ __launch_bounds__(256) void k_wchains(WPlan p, WTmp q, int64_t Ec, in
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (valid[g]) {
-                    same_total += len[g];
-                    if (bit[g] < kb) same_before += len[g];
-                    else if (bit[g] == kb) { own_start = st[g]; own_len = len[g]; }
+                    q.bsb[st[g]] = prefix;
+                    if (prev_b >= 0) q.rprevb[st[g]] = (uint32_t)prev_b;
+                    prefix += len[g];
+                    prev_b = bw0 + bit[g];
+                    last_tail = st[g] + len[g] - 1u;
                 }
             }
         }
+        same_total = prefix;
+        q.bflags[last_tail] |= WT_WIN_LAST;              // (only this thread touches the chain's flags in this kernel)
     }
-    const uint32_t ri = (uint32_t)x - own_start;
-    const bool run_head = active && ri == 0, run_tail = active && ri + 1 == own_len;
-    const bool chain_head = run_head && same_before == 0;
     const int cls = wchain_class(same_total, p.heavy_thr);
     uint32_t off = 0, rank = 0;
     if (chain_head) {
@@ -481,27 +502,15 @@ __global__ __launch_bounds__(256) void k_wchains(WPlan p, WTmp q, int64_t Ec, in
     }
     __syncthreads();
     if (threadIdx.x <= WCLS) q.blkcnt[(size_t)blockIdx.x * 9 + threadIdx.x] = threadIdx.x < WCLS ? l_cls[threadIdx.x] : l_pos;
-    if (!active) return;
-    uint32_t fl = 0;
-    if (run_head) fl |= WREF_RUN_HEAD;
-    if (run_tail) fl |= WREF_RUN_TAIL;
-    if (ri % WIN_BLOCK == 0) fl |= WREF_BLK_HEAD;
-    if (ri % WIN_BLOCK == WIN_BLOCK - 1 || run_tail) fl |= WREF_BLK_TAIL;
-    if (run_tail && last_b == b) fl |= WT_WIN_LAST;
-    uint32_t aux = (uint32_t)(prev_b < 0 ? 0 : prev_b);
     if (chain_head) {
-        fl |= WT_CHAIN_HEAD;
         // the chain's range of positions starts at (window) + (earlier workgroups of the window: k_wscan) + off
+        q.bflags[x] |= WT_CHAIN_HEAD;
         ce->xh = (uint32_t)x;
         ce->cnt = same_total;
         atomicOr(p.wmask + node, 1ull << (unsigned)w);
         q.boff[x] = off;
-        aux = rank;                                       // (a chain head has no previous run in the window: the slot is free)
+        q.rprevb[x] = rank;                              // (a chain head has no previous run in the window: the slot is free)
     }
-    q.bflags[x] = fl;
-    q.bsb[x] = same_before;
-    q.bri[x] = ri;
-    q.rprevb[x] = aux;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -623,11 +632,11 @@ __device__ __forceinline__ void side_load(const WTmp& q, int64_t x, OwnSide& o) 
     o.x = x;
     o.node = q.bkey[x];
     o.partner = q.bpart[x];
-    o.sb = q.bsb[x];
     o.ri = q.bri[x];
     o.fl = q.bflags[x];
-    o.aux = q.rprevb[x];
     o.coef = q.bcoef[x];
+    o.sb = q.bsb[x - o.ri];                               // (per run, kept with the run's head by k_wchains)
+    o.aux = q.rprevb[x - o.ri];
 }
 
 __device__ __forceinline__ void side_version(const WPlan& p, const WTmp& q, int64_t Bfull, int64_t w, const CEnt* ce,
