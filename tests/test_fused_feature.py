@@ -334,3 +334,30 @@ def test_encoder_call_with_device_resident_ids(d, L, K):
     rp.check_device_errors()
     with pytest.raises(IndexError):
         rp.encoder_pair_features(gpu, np.array([1, N], dtype=np.int64), np.array([1, 2], dtype=np.int64), np.array([2e6, 2e6]), K)
+
+
+@pytest.mark.gpu
+def test_staging_ring_wraps_without_reusing_a_slot_in_flight():
+    """The host-array calls carve their arrays from the slot of the pinned ring being filled and record ONE event when a slot is
+    left (host_api.hip): 700 calls of mixed sizes walk the 8 slots several times over; every call's result must be the one its
+    own ids give (a slot handed out again before the kernel that read it finished would show as another call's features)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    rng = np.random.RandomState(11)
+    N = 500
+    rp = _module(N, 64, 3)
+    for src, dst, t in _stream(rng, N, 200, 3, hubs=False):
+        rp.update(src, dst, t)
+    sizes = [1000, 7, 1024, 333, 2048, 64]
+    calls = []
+    with torch.no_grad():
+        for i in range(700):
+            n = sizes[i % len(sizes)]
+            u, v = rng.randint(0, N, n).astype(np.int64), rng.randint(0, N, n).astype(np.int64)
+            calls.append((u, v, rp.pair_gram(u, v)))                       # enqueued back to back: no synchronisation in between
+        torch.cuda.synchronize()
+        for i in range(0, 700, 7):
+            u, v, got = calls[i]
+            want = rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda())      # ids resident on the device: no ring
+            assert torch.equal(got, want), i
+    rp.check_device_errors()
