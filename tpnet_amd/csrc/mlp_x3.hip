@@ -12,6 +12,9 @@
 // Measured: 80 000 rows 32.5 -> 23 us, 800 000 rows 224 -> 150 us (load + split + store alone: 12 / 97 us; matrix pipe busy 4.8 M x
 // 32 cycles per launch = 42 % of a 2.4 GHz clock).  Not kept: twelve waves per workgroup (157 us); slice w + 1's layer-1 products
 // issued ahead of slice w's vector work, with and without sched_group_barrier interleaving (162 us: more registers, no overlap won).
+// Nor: the weights of a step read from LDS one step ahead of their products behind scheduling barriers (164 us); one LDS block per
+// slice (every read base + 16-bit offset), the accumulators started from the bias and a one-instruction ReLU -- 130 vector instructions
+// per two slices instead of 225 -- at 153 us: neither the LDS round trips nor the vector work is what the launch waits for.
 #include "tpnet_common.h"
 
 namespace tpnet {
