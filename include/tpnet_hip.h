@@ -36,7 +36,8 @@ extern "C" {
                                4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
                                     (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored;
                                5: + tpnet_run_stream_tagged / tpnet_plan_tag (a stream's plan replayed across epochs), the encoder's call as one
-                                    crossing (tpnet_anchored_features, tpnet_encoder_features, tpnet_host_encoder_features) */
+                                    crossing (tpnet_anchored_features, tpnet_encoder_features, tpnet_host_encoder_features), the targeted
+                                    exchange's plan on the device (tpnet_xplan_targeted) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -348,6 +349,21 @@ int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* p
                              const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
                              int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
                              float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream);
+
+/* The targeted exchange's plan on the device (what tpnet_rows_step_targeted's callers need per batch): for rank `me` of G (owner(n)
+ * = n % G), from the stream's device arrays, two launches and no synchronisation:
+ *   recv_keys [nb][cap] uint32 (cap = tpnet_xplan_capacity()): the distinct remote nodes the rank reads in batch b, as (owner <<
+ *       bits(N) | node), ascending = the order the peers' messages land in the halo rows;
+ *   pack_ids  [nb][cap] int64: the local rows (node / G) the rank sends in batch b, ordered (reader, node), a row once per reader;
+ *   cnt       [nb][2][G] int64: rows received from each owner / rows sent to each reader (the host reads these back);
+ *   status    [2] uint32: ids outside [0, N) seen; batches whose lists exceeded cap (then the caller plans another way);
+ *   local_src / local_dst / local_neg [E] int64: every endpoint relabelled (owned: n / G; received in its batch: n_owned + its
+ *       place in the batch's receive list; else n_owned).
+ * TPNET_ERR_BAD_ARG when bits(N) + bits(G) > 31 or G > 64 (the caller plans another way). */
+int64_t tpnet_xplan_capacity(void);
+int tpnet_xplan_targeted(const int64_t* src, const int64_t* dst, const int64_t* neg, int64_t E, int64_t batch, int64_t N, int32_t G,
+                         int32_t me, int32_t n_owned, uint32_t* recv_keys, int64_t* pack_ids, int64_t* cnt, uint32_t* status,
+                         int64_t* local_src, int64_t* local_dst, int64_t* local_neg, void* stream);
 
 /* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
  * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,

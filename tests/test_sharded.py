@@ -625,3 +625,48 @@ def test_row_sharded_c4_table_two_ranks_on_one_gpu(exchange):
             want = rrows[:, [pos[int(x)] for x in mine]]
             np.testing.assert_array_equal(rows[0], want[0])            # layer 0: the same draw
             np.testing.assert_allclose(rows[1:], want[1:], rtol=1e-4, atol=1e-5 * cmp[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,N,E,B,with_neg", [(2, 211, 700, 100, True), (3, 3000, 905, 60, True), (8, 9000, 8000 * 3 - 17, 8000, True),
+                                              (4, 150, 333, 50, False), (8, 1 << 20, 5000, 1000, True)])
+def test_device_exchange_plan_equals_torch_plan(G, N, E, B, with_neg):
+    """tpnet_xplan_targeted (csrc/xplan.hip: the targeted exchange's plan in two launches) against plan_targeted + the torch
+    relabelling, for every rank of G: the same message sizes, the same pack order, the same halo slot for every endpoint --
+    hubs, ragged last batch, a global batch of 8 000 edges (24 000 items per batch) and a table of 2^20 nodes included."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import _lib
+    from tpnet_amd.sharded import ShardedStreamRunner
+    src, dst, neg, _ = _stream(G * 7 + B, N, E)
+    dev = torch.device("cuda:0")
+    ds, dd = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
+    dn = torch.from_numpy(neg).to(dev) if with_neg else None
+
+    class _Rp:                                  # (the planners only ask the module for its stream)
+        @staticmethod
+        def _stream():
+            return None
+    cap = int(_lib.load().tpnet_xplan_capacity())
+    for me in range(G):
+        r = object.__new__(ShardedStreamRunner)
+        r.G, r.me, r.N, r.n_cap, r.H, r.rp, r.group = G, me, N, (N + G - 1) // G, 3 * B, _Rp(), None
+        want = r.relabel_targeted(ds, dd, dn, B)
+        got = r.relabel_targeted_device(ds, dd, dn, B)
+        assert got is not None
+        np.testing.assert_array_equal(got["send_cnt"], want["send_cnt"])
+        np.testing.assert_array_equal(got["recv_cnt"], want["recv_cnt"])
+        for k in ("src", "dst") + (("neg",) if with_neg else ()):
+            assert torch.equal(got[k], want[k]), (me, k)
+        stot = want["send_cnt"].sum(axis=1)
+        s0 = np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
+        gp, wp = got["pack_ids"].cpu().numpy(), want["pack_ids"].cpu().numpy()
+        for b in range(len(stot)):
+            np.testing.assert_array_equal(gp[b * cap: b * cap + stot[b]], wp[s0[b]: s0[b] + stot[b]])
+    # an id outside [0, N) is an IndexError, as on the torch path
+    bad = ds.clone()
+    bad[5] = N
+    r = object.__new__(ShardedStreamRunner)
+    r.G, r.me, r.N, r.n_cap, r.H, r.rp, r.group = G, 0, N, (N + G - 1) // G, 3 * B, _Rp(), None
+    with pytest.raises(IndexError):
+        r.relabel_targeted_device(bad, dd, dn, B)

@@ -409,6 +409,51 @@ class ShardedStreamRunner:
                  unpack_ids=(n_cap + slot).contiguous(), pack_ids=(P["send_nodes"] // G).contiguous(), rtot=rtot, rstart=rstart)
         return P
 
+    device_plan = True         # the targeted exchange's plan by tpnet_xplan_targeted (two launches, one read-back) where it applies
+
+    def relabel_targeted_device(self, src, dst, neg, batch_size: int):
+        """relabel_targeted on the device (csrc/xplan.hip: one workgroup per batch sorts the batch's receive and send lists, one
+        thread per endpoint relabels) -- None where it does not apply (ids not on a GPU, 32-bit keys too narrow for N and G, a
+        batch whose lists exceed the kernel's capacity): the caller then takes the torch plan.  Same lists, same order."""
+        G, me, N, n_cap = self.G, self.me, self.N, self.n_cap
+        E, B = int(src.numel()), int(batch_size)
+        if G < 2 or G > 64 or not src.is_cuda or E == 0:
+            return None
+        if max(N - 1, 1).bit_length() + max(G - 1, 1).bit_length() > 31:
+            return None
+        for x in (src, dst) + ((neg,) if neg is not None else ()):
+            if x.dtype != torch.int64 or not x.is_contiguous() or x.device != src.device:
+                return None
+        lib = _lib.load()
+        nb = (E + B - 1) // B
+        dev = src.device
+        cap = int(lib.tpnet_xplan_capacity())
+        recv_keys = torch.empty((nb, cap), dtype=torch.int32, device=dev)
+        pack_ids = torch.empty((nb, cap), dtype=torch.int64, device=dev)
+        tail = torch.empty(nb * 2 * G + 1, dtype=torch.int64, device=dev)       # counts, then the two status words
+        cnt, status = tail[: nb * 2 * G], tail[nb * 2 * G:]
+        lsrc, ldst = torch.empty_like(src), torch.empty_like(dst)
+        lneg = torch.empty_like(neg) if neg is not None else None
+        rc = lib.tpnet_xplan_targeted(src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, E, B, N, G, me,
+                                      n_cap, recv_keys.data_ptr(), pack_ids.data_ptr(), cnt.data_ptr(), status.data_ptr(),
+                                      lsrc.data_ptr(), ldst.data_ptr(), lneg.data_ptr() if lneg is not None else None,
+                                      self.rp._stream())
+        if rc:
+            return None
+        host = tail.cpu().numpy()                                                # ONE read-back: message sizes + status
+        st = host[nb * 2 * G:].view(np.uint32)
+        if int(st[0]):
+            raise IndexError(f"node id out of range for {N} nodes")
+        if int(st[1]):
+            return None
+        c = host[: nb * 2 * G].reshape(nb, 2, G)
+        recv_cnt, send_cnt = np.ascontiguousarray(c[:, 0, :]), np.ascontiguousarray(c[:, 1, :])
+        rtot = recv_cnt.sum(axis=1)
+        if nb and int(rtot.max()) > self.H:
+            raise ValueError(f"a batch reads {int(rtot.max())} rows of other ranks but the shard has {self.H} halo rows")
+        return dict(src=lsrc, dst=ldst, neg=lneg, send_cnt=send_cnt, recv_cnt=recv_cnt, rtot=rtot, pack_ids=pack_ids.view(-1),
+                    sstart=np.arange(nb, dtype=np.int64) * cap, recv_keys_dev=recv_keys)
+
     def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
         """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
         grouped ncclSend / ncclRecv issued from C (tpnet_rows_step_targeted) whose receives land straight in the halo rows of
@@ -429,10 +474,12 @@ class ShardedStreamRunner:
         out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
         if E == 0:
             return out_pos, out_neg
-        ends = [src, dst] + ([neg] if neg is not None else [])      # (the lists key on batch * N + node: a bad id would alias)
-        if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
-            raise IndexError(f"node id out of range for {self.N} nodes")
-        R = self.relabel_targeted(src, dst, neg, B)
+        R = self.relabel_targeted_device(src, dst, neg, B) if self.device_plan else None   # (checks the ids' range itself)
+        if R is None:
+            ends = [src, dst] + ([neg] if neg is not None else [])  # (the lists key on batch * N + node: a bad id would alias)
+            if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
+                raise IndexError(f"node id out of range for {self.N} nodes")
+            R = self.relabel_targeted(src, dst, neg, B)
         last_idx = torch.clamp(torch.arange(1, nb + 1, device=dev) * B, max=E) - 1
         t_last = t[last_idx].cpu().numpy() if t_host_last is None else np.asarray(t_host_last, dtype=np.float64)
         ws = rp._workspace(E, B)
@@ -445,7 +492,7 @@ class ShardedStreamRunner:
         lid0 = rp._next_launch_ids(nb)
         scnt, rcnt = np.ascontiguousarray(R["send_cnt"]), np.ascontiguousarray(R["recv_cnt"])
         stot, rtot = scnt.sum(axis=1), R["rtot"]
-        sstart = np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
+        sstart = R["sstart"] if "sstart" in R else np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
         n_cap = self.n_cap
         # the rows a peer reads leave as two messages (layer 0; layers 1..L) and arrive STRAIGHT in the reader's halo rows of p0 and
         # of copy 0 of q: pack -> grouped send / recv -> step, no unpack launch (halo rows are never targets: their copy stays 0)
