@@ -989,7 +989,7 @@ __global__ void k_gather_chains(WPlan p, const uint32_t* __restrict__ lk, const 
             D.start = (uint32_t)a;
             D.n_heavy = (uint32_t)(h - a);
             D.n_chains = (uint32_t)(z - a);
-            D.pad = 0;
+            D.n_ext = D.n_heavy;
             p.wdesc[w] = D;
         }
         return;

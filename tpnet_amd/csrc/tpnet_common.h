@@ -234,7 +234,8 @@ struct WinDesc {          // per window: its slice of the chain list (sorted by 
     uint32_t start;       // first chain of the window in WPlan::chains
     uint32_t n_heavy;     // the first n_heavy are walked by a workgroup per column part ...
     uint32_t n_chains;    // ... the rest by one lane group each
-    uint32_t pad;
+    uint32_t n_ext;       // chains of length classes 0..2 (more than ~thr / 4 contributions): what a step with spare workgroups
+                          // walks by workgroups (>= n_heavy; the sorted planner: = n_heavy)
 };
 
 struct Chain {            // all contributions of ONE node inside ONE window: sorted positions [j0, j0 + cnt)

@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_wrefs(WPlan p, WTmp q, const int64_t* _
             D.start = at;
             D.n_heavy = t8[0];
             D.n_chains = n;
-            D.pad = 0;
+            D.n_ext = t8[0] + t8[1] + t8[2];
             p.wdesc[wv] = D;
         }
 #pragma unroll

@@ -448,6 +448,7 @@ struct WStep {
     int32_t dbg_layer;                 // diagnostic builds: the layer whose units are stamped (0: none)
     int32_t dbg_skip;                  // timing experiments: 1 = no hub chains, 2 = no chains, 4 = no readout
     uint32_t n_active;                 // layers that have a window at this step
+    uint32_t hub_ext;                  // this step walks the chains of length classes 1..2 by workgroups too (WinDesc::n_ext)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
         if (st.dbg_skip & 1) return;
 #endif
         const Chain* __restrict__ heavy = P.chains + wd.start;         // the window's longest chains
-        const uint32_t units = wd.n_heavy * (uint32_t)st.CP;
+        const uint32_t units = (st.hub_ext ? wd.n_ext : wd.n_heavy) * (uint32_t)st.CP;
         for (uint32_t h = rb; h < units; h += nblk)
             chain_heavy<LPH>(S, P, heavy[h / (uint32_t)st.CP], (int)(h % (uint32_t)st.CP), layer, lambda,
                              (uint32_t)(w * P.K), lds_u, dbg);
@@ -593,8 +594,9 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
 #ifdef TPNET_DEV
     if (st.dbg_skip & 2) return;
 #endif
-    const Chain* __restrict__ small = P.chains + wd.start + wd.n_heavy;   // the others, longest first: a block's chains are alike
-    const int64_t n_small = (int64_t)wd.n_chains - (int64_t)wd.n_heavy;
+    const uint32_t n_hub = st.hub_ext ? wd.n_ext : wd.n_heavy;
+    const Chain* __restrict__ small = P.chains + wd.start + n_hub;        // the others, longest first: a block's chains are alike
+    const int64_t n_small = (int64_t)wd.n_chains - (int64_t)n_hub;
     for (int64_t base = (int64_t)rb * GPB; base < n_small; base += (int64_t)nblk * GPB) {
         const int64_t idx = base + g;
         const bool valid = idx < n_small;
@@ -698,13 +700,25 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     auto win_edges = [&](int64_t w) { const int64_t e0 = w * p.Ew; return (Ec - e0 < p.Ew) ? Ec - e0 : p.Ew; };
     uint32_t nb = 0;
     for (int i = 0; i < TPNET_MAX_LAYERS; ++i) ws.w_upd[i] = -1;
+    // A step that carries ONE update layer (the pipeline's first step, and its last one beside the readouts) is bound by its longest single
+    // units, not by throughput -- a lane group walks a chain of 64..96 contributions in ~35 us, the step's other work is done in
+    // ~12 (block stamps, tools/wblocks.py) -- and has workgroups to spare: it walks the chains of length classes 1..2 by
+    // workgroups as well, on the hub workgroups the absent layers leave free.
+    static const int ext_env = TPNET_DEV_INT(WIN_HUB_EXT, 1);
+    int n_upd = 0;
+    for (int i = 0; i < L; ++i) n_upd += (j - i >= 0 && j - i < nw) ? 1 : 0;
+    const bool reads = have_readout && j - L >= 0 && j - L < nw;
+    // (measured, C2: the first step 38 -> 30 us at 24 batches per window, 28 -> 19 at 15, 21 -> 18 at 10; the last update step beside
+    // the readouts 44 -> 41, 31 -> 24, but 24 -> 27 at 10 batches per window; two update layers sharing the step: 41 -> 49, not taken)
+    ws.hub_ext = (ext_env == 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 1u : 0u;
+    const uint32_t hub_blocks = (uint32_t)(hb_env > 0 ? hb_env : 384) * (ws.hub_ext ? (uint32_t)(L / n_upd) : 1u);
     // hub chains first
     for (int i = 0; i < L; ++i) {
         const int64_t w = j - i;
         ws.seg[i] = nb;
         if (w >= 0 && w < nw) {
             ws.w_upd[i] = w;
-            nb += (uint32_t)(hb_env > 0 ? hb_env : 384);   // (four-law sweeps, tools/degree_sensitivity.py: 128 -> 256 -> 384, each step -5..-7 % on streams with heavy hubs, nothing lost elsewhere)
+            nb += hub_blocks;   // (four-law sweeps, tools/degree_sensitivity.py: 128 -> 256 -> 384, each step -5..-7 % on streams with heavy hubs, nothing lost elsewhere)
         }
     }
     ws.seg[L] = nb;
