@@ -990,6 +990,8 @@ __global__ void k_gather_chains(WPlan p, const uint32_t* __restrict__ lk, const 
             D.n_heavy = (uint32_t)(h - a);
             D.n_chains = (uint32_t)(z - a);
             D.n_ext = D.n_heavy;
+            D.n_ext1 = D.n_heavy;
+            D.pad0 = D.pad1 = D.pad2 = 0;
             p.wdesc[w] = D;
         }
         return;

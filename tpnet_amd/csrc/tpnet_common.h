@@ -236,6 +236,8 @@ struct WinDesc {          // per window: its slice of the chain list (sorted by 
     uint32_t n_chains;    // ... the rest by one lane group each
     uint32_t n_ext;       // chains of length classes 0..2 (more than ~thr / 4 contributions): what a step with spare workgroups
                           // walks by workgroups (>= n_heavy; the sorted planner: = n_heavy)
+    uint32_t n_ext1;      // chains of length classes 0..1 (more than ~thr / 2)
+    uint32_t pad0, pad1, pad2;
 };
 
 struct Chain {            // all contributions of ONE node inside ONE window: sorted positions [j0, j0 + cnt)

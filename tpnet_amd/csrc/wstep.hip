@@ -448,8 +448,18 @@ struct WStep {
     int32_t dbg_layer;                 // diagnostic builds: the layer whose units are stamped (0: none)
     int32_t dbg_skip;                  // timing experiments: 1 = no hub chains, 2 = no chains, 4 = no readout
     uint32_t n_active;                 // layers that have a window at this step
-    uint32_t hub_ext;                  // this step walks the chains of length classes 1..2 by workgroups too (WinDesc::n_ext)
+    uint32_t hub_ext;                  // 2 / 1: this step walks the chains of length classes 1..2 / of class 1 by workgroups too ...
+    uint32_t hub_blocks;               // ... where they fit ONE round of the layer's hub workgroups
 };
+
+// the chains of a window this step walks by workgroups: the heavy ones, and -- in a step with workgroups to spare -- the next one
+// or two length classes, as long as ONE round of the layer's hub workgroups takes them (a second round costs more than the lane
+// groups' tail it removes; on streams with very heavy hubs the classes are too many and the step stays as it was)
+__device__ __forceinline__ uint32_t hub_chains(const WStep& st, const WinDesc& wd) {
+    if (st.hub_ext == 2 && wd.n_ext * (uint32_t)st.CP <= st.hub_blocks) return wd.n_ext;
+    if (st.hub_ext >= 1 && wd.n_ext1 * (uint32_t)st.CP <= st.hub_blocks) return wd.n_ext1;
+    return wd.n_heavy;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // one pipeline step: block ranges = [hub chains of layer 1 | ... | of layer L | chains of layer 1 | ... | L | readout pairs]
@@ -584,7 +594,7 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
         if (st.dbg_skip & 1) return;
 #endif
         const Chain* __restrict__ heavy = P.chains + wd.start;         // the window's longest chains
-        const uint32_t units = (st.hub_ext ? wd.n_ext : wd.n_heavy) * (uint32_t)st.CP;
+        const uint32_t units = hub_chains(st, wd) * (uint32_t)st.CP;
         for (uint32_t h = rb; h < units; h += nblk)
             chain_heavy<LPH>(S, P, heavy[h / (uint32_t)st.CP], (int)(h % (uint32_t)st.CP), layer, lambda,
                              (uint32_t)(w * P.K), lds_u, dbg);
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
 #ifdef TPNET_DEV
     if (st.dbg_skip & 2) return;
 #endif
-    const uint32_t n_hub = st.hub_ext ? wd.n_ext : wd.n_heavy;
+    const uint32_t n_hub = hub_chains(st, wd);
     const Chain* __restrict__ small = P.chains + wd.start + n_hub;        // the others, longest first: a block's chains are alike
     const int64_t n_small = (int64_t)wd.n_chains - (int64_t)n_hub;
     for (int64_t base = (int64_t)rb * GPB; base < n_small; base += (int64_t)nblk * GPB) {
@@ -704,14 +714,17 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     // units, not by throughput -- a lane group walks a chain of 64..96 contributions in ~35 us, the step's other work is done in
     // ~12 (block stamps, tools/wblocks.py) -- and has workgroups to spare: it walks the chains of length classes 1..2 by
     // workgroups as well, on the hub workgroups the absent layers leave free.
-    static const int ext_env = TPNET_DEV_INT(WIN_HUB_EXT, 1);
+    static const int ext_env = TPNET_DEV_INT(WIN_HUB_EXT, 2);
     int n_upd = 0;
     for (int i = 0; i < L; ++i) n_upd += (j - i >= 0 && j - i < nw) ? 1 : 0;
     const bool reads = have_readout && j - L >= 0 && j - L < nw;
     // (measured, C2: the first step 38 -> 30 us at 24 batches per window, 28 -> 19 at 15, 21 -> 18 at 10; the last update step beside
     // the readouts 44 -> 41, 31 -> 24, but 24 -> 27 at 10 batches per window; two update layers sharing the step: 41 -> 49, not taken)
-    ws.hub_ext = (ext_env == 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 1u : 0u;
-    const uint32_t hub_blocks = (uint32_t)(hb_env > 0 ? hb_env : 384) * (ws.hub_ext ? (uint32_t)(L / n_upd) : 1u);
+    ws.hub_ext = (ext_env >= 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 2u : 0u;
+    if (ext_env == 2 && n_upd == 2 && !reads && p.K >= 14) ws.hub_ext = 1u;      // (two layers: the longest class only)
+    const uint32_t hub_blocks = ws.hub_ext ? (uint32_t)(hb_env > 0 ? hb_env : 384) * (uint32_t)L / (uint32_t)n_upd
+                                           : (uint32_t)(hb_env > 0 ? hb_env : 384);
+    ws.hub_blocks = hub_blocks;
     // hub chains first
     for (int i = 0; i < L; ++i) {
         const int64_t w = j - i;
