@@ -721,7 +721,8 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     // (measured, C2: the first step 38 -> 30 us at 24 batches per window, 28 -> 19 at 15, 21 -> 18 at 10; the last update step beside
     // the readouts 44 -> 41, 31 -> 24, but 24 -> 27 at 10 batches per window; two update layers sharing the step: 41 -> 49, not taken)
     ws.hub_ext = (ext_env >= 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 2u : 0u;
-    if (ext_env == 2 && n_upd == 2 && !reads && p.K >= 14) ws.hub_ext = 1u;      // (two layers: the longest class only)
+    if (ext_env >= 2 && n_upd == 2 && !reads && p.K >= 14) ws.hub_ext = 1u;      // (two layers: the longest class only, 42 -> 33 us;
+                                                                                 // in the full steps the same costs 55 -> 60 us: not taken)
     const uint32_t hub_blocks = ws.hub_ext ? (uint32_t)(hb_env > 0 ? hb_env : 384) * (uint32_t)L / (uint32_t)n_upd
                                            : (uint32_t)(hb_env > 0 ? hb_env : 384);
     ws.hub_blocks = hub_blocks;
