@@ -85,62 +85,76 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
         for (int x = 0; x < F; ++x) { sblk[x] = 0.0f; srun[x] = 0.0f; }
         bool firstblk = false;
         float cur_dec = 1.0f;
-        for (uint32_t r0 = 0; __any(r0 < c.cnt); r0 += LPP) {
+        // a lane's contribution of a round of LPP: partner, weight, reference, decays -- the NEXT round's five loads are issued
+        // before this round's rows are walked (one more dependent round trip per 32 contributions otherwise)
+        int32_t nx_pv = 0;
+        float nx_w = 0.0f, nx_glog = 1.0f, nx_decr = 1.0f;
+        uint32_t nx_ref = 0u;
+        auto fetch_meta = [&](uint32_t r0) {
             const uint32_t jm = c.j0 + r0 + (uint32_t)gl;
             const bool mine = r0 + (uint32_t)gl < c.cnt;
-            const int32_t my_pv = mine ? s_partner[jm] : 0;
-            const float my_w = mine ? s_coef[jm] : 0.0f;
-            const uint32_t my_ref = mine ? P.s_ref[jm] : 0u;
-            const float my_glog = mine ? P.s_g[jm] : 1.0f;
-            const float my_dec = mine ? pow_rep(P.s_dec[jm], layer) : 1.0f;
+            nx_pv = mine ? s_partner[jm] : 0;
+            nx_w = mine ? s_coef[jm] : 0.0f;
+            nx_ref = mine ? P.s_ref[jm] : 0u;
+            nx_glog = mine ? P.s_g[jm] : 1.0f;
+            nx_decr = mine ? P.s_dec[jm] : 1.0f;
+        };
+        fetch_meta(0u);
+        for (uint32_t r0 = 0; __any(r0 < c.cnt); r0 += LPP) {
+            const int32_t my_pv = nx_pv;
+            const float my_w = nx_w;
+            const uint32_t my_ref = nx_ref;
+            const float my_glog = nx_glog;
+            const float my_dec = pow_rep(nx_decr, layer);
+            if (__any(r0 + LPP < c.cnt)) fetch_meta(r0 + LPP);
             float my_gp;
             const float* my_row = partner_row(S, P, layer, my_pv, my_ref, my_glog, my_gp);
             const uint32_t n_here = (r0 < c.cnt) ? ((c.cnt - r0 < (uint32_t)LPP) ? c.cnt - r0 : (uint32_t)LPP) : 0u;
-            for (uint32_t k0 = 0; __any(k0 < n_here); k0 += U) {
-                const float* rp[U];
-                float w[U], gp[U], dc[U];
-                uint32_t fl[U];
-                bool ok[U];
+            // rows of U / 2 contributions at a time, TWO sets: a set's loads are issued before the other set is summed (with one
+            // set of U, a chain of 64..96 contributions was 9..12 dependent row fetches of ~2 us each: the tail of every pipeline
+            // step).  Measured and not kept: two sets of U, three sets of U / 2 -- 128 registers and spills.
+            constexpr int US = U / 2;                          // rows per set; two sets: 4..8 rows in flight at any time
+            float rA[US][F], rB[US][F];
+            auto issue = [&](uint32_t k0, float (&r)[US][F]) {
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
+                for (int k = 0; k < US; ++k) {
                     const int sl = (int)k0 + k;
-                    ok[k] = (uint32_t)sl < n_here;
-                    rp[k] = reinterpret_cast<const float*>(__shfl((long long)reinterpret_cast<uintptr_t>(my_row), sl, LPP));
-                    w[k] = __shfl(my_w, sl, LPP);
-                    gp[k] = __shfl(my_gp, sl, LPP);
-                    dc[k] = __shfl(my_dec, sl, LPP);
-                    fl[k] = (uint32_t)__shfl((int)my_ref, sl, LPP);
-                    if (!ok[k]) rp[k] = S.p0;                 // row 0 of layer 0: always a valid address
-                }
-                float r[U][F];
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
+                    const bool ok = (uint32_t)sl < n_here;
+                    const float* rp = reinterpret_cast<const float*>(__shfl((long long)reinterpret_cast<uintptr_t>(my_row), sl, LPP));
+                    if (!ok) rp = S.p0;                       // row 0 of layer 0: always a valid address
 #pragma unroll
                     for (int j = 0; j < VPL; ++j) {
                         const int vi = c0 + j * LPP + gl;
-                        ldv_maybe<W, FULL>(rp[k], vi, ok[k] && vi < nvec, &r[k][j * W]);
+                        ldv_maybe<W, FULL>(rp, vi, ok && vi < nvec, &r[k][j * W]);
                     }
                 }
+            };
+            auto consume = [&](uint32_t k0, const float (&r)[US][F]) {
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    if (ok[k]) {
+                for (int k = 0; k < US; ++k) {
+                    const int sl = (int)k0 + k;
+                    if ((uint32_t)sl < n_here) {
+                        const float w = __shfl(my_w, sl, LPP);
+                        const float gp = __shfl(my_gp, sl, LPP);
+                        const float dc = __shfl(my_dec, sl, LPP);
+                        const uint32_t fl = (uint32_t)__shfl((int)my_ref, sl, LPP);
                         const uint32_t pos = c.j0 + r0 + k0 + (uint32_t)k;      // chunk-relative sorted position
-                        const bool bh = (fl[k] & WREF_BLK_HEAD) != 0;
+                        const bool bh = (fl & WREF_BLK_HEAD) != 0;
 #pragma unroll
                         for (int x = 0; x < F; ++x) {
-                            const float m = (r[k][x] * gp[k]) * w[k];   // (P[i-1][partner], decayed) * time weight (TPNet.py:91-92)
+                            const float m = (r[k][x] * gp) * w;         // (P[i-1][partner], decayed) * time weight (TPNet.py:91-92)
                             sblk[x] = bh ? m : sblk[x] + m;             // scatter-add in index order (TPNet.py:93-96)
                         }
-                        if (fl[k] & WREF_RUN_HEAD) {
+                        if (fl & WREF_RUN_HEAD) {
                             firstblk = true;
-                            cur_dec = (pos == c.j0 && from_table) ? g0 : dc[k];
+                            cur_dec = (pos == c.j0 && from_table) ? g0 : dc;
                         }
-                        if (fl[k] & WREF_BLK_TAIL) {
+                        if (fl & WREF_BLK_TAIL) {
 #pragma unroll
                             for (int x = 0; x < F; ++x) srun[x] = firstblk ? sblk[x] : srun[x] + sblk[x];
                             firstblk = false;
                         }
-                        if (fl[k] & WREF_RUN_TAIL) {
+                        if (fl & WREF_RUN_TAIL) {
 #pragma unroll
                             for (int x = 0; x < F; ++x) {
                                 acc[x] *= cur_dec;                       // decay to the run's clock (TPNet.py:83-85)
@@ -154,6 +168,16 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
                             }
                         }
                     }
+                }
+            };
+            if (__any(n_here > 0u)) issue(0u, rA);
+            for (uint32_t k0 = 0; __any(k0 < n_here); k0 += 2 * US) {
+                const bool more1 = __any(k0 + US < n_here);
+                if (more1) issue(k0 + US, rB);
+                consume(k0, rA);
+                if (more1) {
+                    if (__any(k0 + 2 * US < n_here)) issue(k0 + 2 * US, rA);
+                    consume(k0 + US, rB);
                 }
             }
         }
