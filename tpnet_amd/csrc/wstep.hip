@@ -747,6 +747,7 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     ws.hub_ext = (ext_env >= 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 2u : 0u;
     if (ext_env >= 2 && n_upd == 2 && !reads && p.K >= 14) ws.hub_ext = 1u;      // (two layers: the longest class only, 42 -> 33 us;
                                                                                  // in the full steps the same costs 55 -> 60 us: not taken)
+    // (steps with three update layers, or two beside the readouts: no change with the longest class on workgroups -- measured)
     const uint32_t hub_blocks = ws.hub_ext ? (uint32_t)(hb_env > 0 ? hb_env : 384) * (uint32_t)L / (uint32_t)n_upd
                                            : (uint32_t)(hb_env > 0 ? hb_env : 384);
     ws.hub_blocks = hub_blocks;
