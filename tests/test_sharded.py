@@ -576,6 +576,7 @@ def _c4_worker(rank, world, port, exchange, q):
         mine = sample[sample % world == rank]
         rows = torch.stack(runner.rp.get_random_projections(mine // world)).cpu().numpy()      # local row = id // G
         shard_bytes = runner.table_bytes()
+        torch.cuda.empty_cache()                                         # (the shard's set-up temporaries: 5 GB of normals per rank)
         if rank == 0:
             ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=c["E"], dim_factor=10, num_layer=L, time_decay_weight=lam,
                                                    device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0),
@@ -604,13 +605,31 @@ def test_row_sharded_c4_table_two_ranks_on_one_gpu(exchange):
         pytest.fail("needs a GPU")
     if torch.cuda.get_device_properties(0).total_memory < 200e9:
         pytest.skip("needs ~150 GB of device memory (two 36 GB shards + the 72 GB control)")
+    # the workers need 36 + 36 + 72 GB of the card: whatever the tests before this one left cached in THIS process's allocator
+    # (the 72 GB table of the single-GPU C4 test, stream workspaces) goes back to the driver first
+    import gc
+    import queue as _queue
+    gc.collect()
+    torch.cuda.empty_cache()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
     for p in procs:
         p.start()
-    msgs = [q.get(timeout=900) for _ in range(4)]
+    msgs = []
+    waited = 0
+    while len(msgs) < 4:
+        try:
+            msgs.append(q.get(timeout=5))
+        except _queue.Empty:
+            waited += 5
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or waited > 600:                                    # a worker that died (out of memory, ...) must not hang the suite
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                pytest.fail(f"sharded C4 workers: exit codes {[p.exitcode for p in procs]} after {waited} s")
     for p in procs:
         p.join(timeout=300)
     cmp = [m for m in msgs if m[0] == "cmp"][0]
