@@ -132,23 +132,27 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
             per.append((np.tile(neigh.reshape(-1), 2),
                         np.concatenate([np.repeat(np.tile(anchors[0], 2), K), np.repeat(np.tile(anchors[1], 2), K)])))
         calls.append(per)
-    rp.reset_random_projections()
-    with torch.no_grad():
-        for b in range(nbe + 4):                 # (4 warm-up batches = 8 long calls: every slot of the pinned staging ring exists)
-            if b == 4:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            s = slice(b * B, (b + 1) * B)
-            for u_, v_ in calls[b]:
-                rp.get_pair_wise_feature(u_, v_)
-            rp.get_pair_wise_feature(src[s], dst[s])
-            rp.get_pair_wise_feature(src[s], neg[s])
-            rp.update(src[s], dst[s], t[s])
-        torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    def encoder_pass():
+        rp.reset_random_projections()
+        with torch.no_grad():
+            for b in range(nbe + 4):             # (4 warm-up batches = 8 long calls: every slot of the pinned staging ring exists)
+                if b == 4:
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                s = slice(b * B, (b + 1) * B)
+                for u_, v_ in calls[b]:
+                    rp.get_pair_wise_feature(u_, v_)
+                rp.get_pair_wise_feature(src[s], dst[s])
+                rp.get_pair_wise_feature(src[s], neg[s])
+                rp.update(src[s], dst[s], t[s])
+            torch.cuda.synchronize()
+        return time.perf_counter() - t0_
+    # (two passes, the faster one: a pass of 8 batches is ~3 ms, and one stray host stall -- a pinned allocation, a page fault in a
+    # fresh buffer -- has shown up as 3x the figure)
+    el = min(encoder_pass(), encoder_pass())
     res["encoder_level"] = {"value": nbe * B / el, "unit": "edges/s", "us_per_batch": el / nbe * 1e6,
                             "what": f"+ 2 x get_pair_wise_feature on 4*B*K = {4 * B * K} pairs (K = {K}) per batch, host index arrays in the "
-                                    "reference's tile / repeat layout (built before the clock starts)"}
+                                    "reference's tile / repeat layout (built before the clock starts; the module recognises the pattern and ships neighbours + anchors only)"}
     # the same unit with the ids resident on the device end to end (SURVEY section 8 f-3 -> f-2 -> f-1): the batch's src / dst /
     # neg / t are staged through the pinned ring (read in place by the row set-up kernel), the device sampler draws the K most recent neighbours of the 2B nodes (the neighbour ids
     # never visit the host), the anchored readout pairs every neighbour with the edge's two endpoints (no index arrays at

@@ -418,6 +418,11 @@ int tpnet_host_encoder_features(const tpnet_state* st, tpnet_stage* stage, const
                                 double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, void* scratch,
                                 size_t scratch_bytes, float* gram, float* out, void* stream);
 
+/* Host-side check (no GPU work): is (src, dst) of a get_pair_wise_feature call of n pairs the encoder's pattern (models/TPNet.py:
+ * 311-316: src = tile(neigh, 2), dst = concat(repeat(a1, K), repeat(a2, K)))?  Returns K >= 2, else 0 (N is unused: the ids' range
+ * is the caller's to check). */
+int64_t tpnet_host_encoder_pattern(const int64_t* src, const int64_t* dst, int64_t n, int64_t N);
+
 /* ---- the step behind the path (BASELINE config 5): self.mlp = Linear(64,256)->ReLU->Linear(256,64)
  * (models/TPNet.py:64-65,129) fused in one kernel on the bf16 matrix cores, fp32 accumulate, L = 3 only.
  * x [n][64] f32 (the readout's features), y [n][64] f32.  w1_bf16: [256][64] bf16 = mlp[0].weight; w2p_bf16: [64][256]

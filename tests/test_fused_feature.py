@@ -384,3 +384,58 @@ def test_staging_ring_wraps_without_reusing_a_slot_in_flight():
             want = rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda())      # ids resident on the device: no ring
             assert torch.equal(got, want), i
     rp.check_device_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,m", [(128, 20, 250), (64, 7, 700), (256, 20, 220), (120, 20, 250)])
+def test_encoder_pattern_on_host_arrays_is_recognised(d, K, m):
+    """The reference's encoder calls get_pair_wise_feature(tile(neigh, 2), concat(repeat(a1, K), repeat(a2, K))) on host arrays
+    (models/TPNet.py:311-316).  The module recognises the pattern in C (tpnet_host_encoder_pattern), ships neigh + the anchors
+    only and runs the anchored readout + dense layers as one call: same features as the general path on the same pairs --
+    consecutive equal anchors (runs longer than K), a list that is NOT the pattern, gradients, ids out of range."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import _lib
+    rng = np.random.RandomState(d + K)
+    N = 400
+    rp = _module(N, d, 3)
+    for src, dst, t in _stream(rng, N, 120, 3):
+        rp.update(src, dst, t)
+    neigh = rng.randint(0, N, (m, K)).astype(np.int64)
+    a1, a2 = rng.randint(1, N, m).astype(np.int64), rng.randint(1, N, m).astype(np.int64)
+    a1[5] = a1[4]                                               # two rows with the same anchor: a run of 2 K
+    a2[9:12] = 7
+    u = np.tile(neigh.reshape(-1), 2)
+    v = np.concatenate([np.repeat(a1, K), np.repeat(a2, K)])
+    n = u.size
+    lib = _lib.load()
+    assert lib.tpnet_host_encoder_pattern(u.ctypes.data, v.ctypes.data, n, N) % K == 0          # (K or a multiple that still fits)
+    with torch.no_grad():
+        got = rp.get_pair_wise_feature(u, v)
+        gram = rp.pair_gram(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda())               # the general kernel, device ids
+        want = rp.mlp(gram)
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    # not the pattern: one neighbour of the second half changed -> the general path, same result as the torch layers
+    u2 = u.copy()
+    u2[n // 2 + 3] = (u2[n // 2 + 3] + 1) % N
+    assert lib.tpnet_host_encoder_pattern(u2.ctypes.data, v.ctypes.data, n, N) == 0
+    with torch.no_grad():
+        got2 = rp.get_pair_wise_feature(u2, v)
+        want2 = rp.mlp(rp.pair_gram(torch.from_numpy(u2).cuda(), torch.from_numpy(v).cuda()))
+    assert (got2 - want2).abs().max().item() <= 2e-5 * max(1.0, want2.abs().max().item())
+    # gradients through the one-call path
+    got = rp.get_pair_wise_feature(u, v)
+    assert got.requires_grad
+    gram = rp.pair_gram(u, v)
+    want = rp.mlp(gram)
+    gy = torch.randn_like(want)
+    _assert_mlp_grads_close(rp.mlp, gram, gy, torch.autograd.grad(got, list(rp.mlp.parameters()), gy),
+                            torch.autograd.grad(want, list(rp.mlp.parameters()), gy))
+    # an id out of range is still an IndexError (the detector declines, the general path reports)
+    bad = v.copy()
+    bad[3] = N
+    with pytest.raises(IndexError):
+        rp.get_pair_wise_feature(u, bad)
+    rp.check_device_errors()

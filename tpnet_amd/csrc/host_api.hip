@@ -238,4 +238,36 @@ int tpnet_host_encoder_features(const tpnet_state* st, tpnet_stage* stage, const
     return stage_release(stage, (size_t)B * 24, s);                   // (the row set-up kernel is the only reader of the slot)
 }
 
+// Is (src, dst) of a get_pair_wise_feature call the ENCODER's pattern (models/TPNet.py:311-316): src = tile(neigh, 2), dst =
+// concat(repeat(a1, K), repeat(a2, K)) with one K for both halves?  One pass over the two host arrays: the halves of src compared,
+// K = gcd of the positions where dst changes inside a half (any K whose blocks are constant serves).  Returns K (>= 2), or 0 (not
+// the pattern).  The ids' range is the caller's to check.
+// The module then ships n/2 neighbour ids + 2 n/(2K) anchors instead of 2 n ids, and runs the anchored readout.
+int64_t tpnet_host_encoder_pattern(const int64_t* src, const int64_t* dst, int64_t n, int64_t N) {
+    if (!src || !dst || n < 4 || (n & 1) || N < 1) return 0;
+    const int64_t h = n / 2;
+    if (memcmp(src, src + h, (size_t)h * 8) != 0) return 0;
+    (void)N;                                                             // (the caller checks the ids' range: numpy's reductions are SIMD)
+    // the usual case first: K = the first run's length, every block of K constant in both halves (a branch-free pass again)
+    int64_t k0 = 1;
+    while (k0 < h && dst[k0] == dst[0]) ++k0;
+    if (k0 >= 2 && h % k0 == 0) {
+        uint64_t acc = 0;
+        for (int64_t j = 0; j < n; j += k0) {
+            const int64_t first = dst[j];
+            for (int64_t k = 1; k < k0; ++k) acc |= (uint64_t)(dst[j + k] ^ first);
+        }
+        if (acc == 0) return k0;
+    }
+    // runs of several lengths (two rows with the same anchor make a run of 2 K): K = gcd of the positions where dst changes
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t g = h;
+    for (int half = 0; half < 2; ++half) {
+        const int64_t* x = dst + half * h;
+        for (int64_t i = 1; i < h; ++i)
+            if (x[i] != x[i - 1]) { g = gcd(g, i); if (g < 2) return 0; }
+    }
+    return g;
+}
+
 }  // extern "C"

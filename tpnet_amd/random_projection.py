@@ -425,6 +425,38 @@ class RandomProjectionModule(nn.Module):
         slot[1].record(torch.cuda.current_stream(dev))
         return [out[i] if arrays[i].dtype == np.int64 else out[i].view(torch.float64) for i in range(k)]
 
+    def _to_device_multi(self, *arrays):
+        """_to_device for host arrays of DIFFERENT lengths (8-byte items): one pinned buffer, one asynchronous copy, a device view
+        per array."""
+        sizes = [int(a.size) for a in arrays]
+        tot = sum(sizes)
+        dev = self._dev()
+        ring = self.__dict__.setdefault("_pin_ring", {"bufs": [], "pos": 0})
+        if not ring["bufs"]:
+            ring["bufs"] = [[None, None] for _ in range(8)]
+        slot = ring["bufs"][ring["pos"]]
+        ring["pos"] = (ring["pos"] + 1) % len(ring["bufs"])
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < tot:
+            slot[0] = torch.empty(max(tot, 4096), dtype=torch.int64).pin_memory()
+        host = slot[0][:tot]
+        hv = host.numpy()
+        o = 0
+        for a, k in zip(arrays, sizes):
+            hv[o:o + k] = a.reshape(-1).view(np.int64)
+            o += k
+        out = host.to(dev, non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(dev))
+        res, o = [], 0
+        for a, k in zip(arrays, sizes):
+            v = out[o:o + k]
+            res.append(v if a.dtype == np.int64 else v.view(torch.float64))
+            o += k
+        return res
+
     def _ids_to_device(self, ids, what):
         return self._to_device(self._check_ids(ids, what))[0]
 
@@ -622,6 +654,13 @@ class RandomProjectionModule(nn.Module):
             fused = self._fused_feature(src, dst_node_ids, n)
             if fused is not None:
                 return fused
+        if n > 8192 and n % 2 == 0 and not self.fused_mlp and self._plist()[0].device.type == "cuda":
+            # the encoder's call as the reference issues it (models/TPNet.py:311-316: src = tile(neigh, 2), dst = concat(repeat(a1, K),
+            # repeat(a2, K)) on the host): recognised in one pass over the two arrays in C; n / 2 neighbour ids + 2 n / (2 K) anchors
+            # go up instead of 2 n ids, the anchored readout and the dense layers run as one call
+            feats = self._encoder_pattern_features(src, dst_node_ids, n)
+            if feats is not None:
+                return feats
         # (rows of <= 128 floats: the generic kernel's 16-lane geometry is as fast on long lists; measured)
         if self.dim > 128 and n >= 4 and n % 2 == 0 and n > 8192 and np.array_equal(src[: n // 2], src[n // 2:]):
             # the encoder's pattern: neighbours tiled twice, each half of dst a np.repeat of the row's anchor
@@ -643,6 +682,42 @@ class RandomProjectionModule(nn.Module):
             g1, g2 = self.pair_gram_shared(src[: n // 2], dst[: n // 2], dst[n // 2:])
             return self._apply_mlp(torch.cat([g1, g2], dim=0))
         return self._apply_mlp(self.pair_gram(src_node_ids, dst_node_ids))
+
+    def _encoder_pattern_features(self, src, dst, n):
+        """get_pair_wise_feature for the encoder's tile / repeat pattern on host arrays (None: not that pattern, or a shape the
+        one-call path does not serve)."""
+        if type(src) is not np.ndarray or type(dst) is not np.ndarray or len(dst) != n:
+            return None
+        if src.dtype != np.int64 or dst.dtype != np.int64 or not src.flags.c_contiguous or not dst.flags.c_contiguous \
+                or src.ndim != 1 or dst.ndim != 1:
+            return None
+        prep = self._overlapped_mlp()
+        if prep is None:
+            return None
+        self._ensure_engine()
+        lib = _lib.load()
+        if not lib.tpnet_pair_gram_anchored_supported(self._st_ref()):
+            return None
+        K = int(lib.tpnet_host_encoder_pattern(src.ctypes.data, dst.ctypes.data, n, self.node_num))
+        if K < 4:
+            return None
+        h = n // 2
+        if max(int(src[:h].view(np.uint64).max()), int(dst.view(np.uint64).max())) >= self.node_num:   # (negative: huge as unsigned)
+            return None                                 # (the general path reports the bad id)
+        m = h // K
+        wd, a1, a2 = self._to_device_multi(src[:h], np.ascontiguousarray(dst[:h:K]), np.ascontiguousarray(dst[h::K]))
+        NG = self.pair_wise_feature_dim
+        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+
+        def launch(gram):
+            out = torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"])
+            _lib.check(lib.tpnet_anchored_features(self._st_ref(), wd.data_ptr(), a1.data_ptr(), a2.data_ptr(), m, K, self._now_host,
+                                                   float(self.time_decay_weight), flags, prep[2], gram.data_ptr(), out.data_ptr(),
+                                                   _raw_stream(self._eng["dev_index"])), "anchored_features")
+            return out
+        if _ff.needs_grad(prep[4]):
+            return _ff.apply_with_grad(self.mlp, launch, n, NG)
+        return launch(torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"]))
 
     def pair_gram_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids):
         """The encoder's readout before self.mlp (models/TPNet.py:311-324): neighbor_ids [n, K] (the sampled neighbours of n
