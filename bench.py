@@ -79,7 +79,7 @@ def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3):
     and combined rates, with and without rp.mlp."""
     threads = min(os.cpu_count() or 1, 16)
     B = cfg["B"]
-    nb = max(3, min(len(src) // B - 2, max(3, 12000 // B)))      # ~12 000 edges per repetition
+    nb = max(3, min(len(src) // B - 2, max(3, 400000 // B)))     # ~400 000 edges per repetition: 9 repetitions = 10-15 s of CPU work
     med = lambda xs: float(np.median(xs))
     out = {}
     for name, th, mlp in (("all", threads, False), ("3thr", 3, False), ("all_mlp", threads, True)):
