@@ -176,12 +176,15 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
             timer->batches += nb;
             timer->edges += Ec;
         }
-        // (measured and not kept, round 3: the write-back as extra blocks of the chunk's last pipeline step -- readouts only, nothing
-        // it reads is written -- grew that step by what the write-back takes alone, leading the grid or not, and every other step
-        // by ~2 us: 634 against 635 us for the 158-batch epoch; a write-back driven by chain records that carry (last chain of the
-        // node, table copy, last clock) instead of a scan of the position flags: 30 against 26 us)
-        rc = launch_wwriteback(st, p, Ec, lid, s);
-        if (rc) return rc;
+        // the write-back: node by node where the hashed planner planned the chunk (wplan3.hip: 9 us for the 158-batch epoch), else
+        // the scan of the sorted positions for the last-run flag (wstep.hip: 25 us).  (Measured and not kept, round 3: the
+        // write-back as extra blocks of the chunk's last pipeline step -- readouts only, nothing it reads is written -- grew that
+        // step by what the write-back takes alone, leading the grid or not, and every other step by ~2 us: 634 against 635 us for
+        // the epoch; a write-back driven by chain records that carry (last chain of the node, table copy, last clock): 30 us.)
+        if (!(plan3 && wplan3_writeback(st, p, Ec, batch, lid, s))) {
+            rc = launch_wwriteback(st, p, Ec, lid, s);
+            if (rc) return rc;
+        }
     }
     return TPNET_OK;
 }

@@ -303,6 +303,8 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
                  double lambda, uint32_t flags, hipStream_t s);
 // end of the chunk: every touched node's last version -> the table's other copy, meta published under launch_id
 int launch_wwriteback(const tpnet_state& st, const WPlan& p, int64_t Ec, uint32_t launch_id, hipStream_t s);
+// the same for a chunk the hashed planner planned, node by node (false: not served, take launch_wwriteback)
+bool wplan3_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s);
 
 extern thread_local int g_last_hip_error;
 #define TPNET_HIP_TRY(expr)                                   \

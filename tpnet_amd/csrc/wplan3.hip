@@ -21,6 +21,7 @@
 // order here, node order there) and the order of the chains inside a length class -- the arithmetic of every run is
 // identical, so both planners give bit-identical results.
 #include "tpnet_common.h"
+#include "device_common.hpp"
 
 #include <rocprim/block/block_radix_sort.hpp>
 
@@ -764,6 +765,60 @@ __global__ __launch_bounds__(256) void k_wrefs(WPlan p, WTmp q, const int64_t* _
     }
 }
 
+// the planner's views of a chunk's workspace, as every stage (and the write-back) sees them
+static WTmp wtmp_full(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch) {
+    const int64_t nb = (Ec + batch - 1) / batch;
+    WTmp q = wtmp_of(p, (size_t)(2 * Ec));
+    q.bpb = wplan3_bpb(batch);
+    q.seg = wplan3_seg(batch);
+    const int64_t nw = (nb + p.K - 1) / p.K;
+    q.direct2 = (nw * st.N <= (int64_t)q.hcap) ? 1u : 0u;
+    q.n2 = (uint32_t)st.N;
+    q.blkcnt = p.wblk;
+    q.blkbase = p.wblk + (size_t)nb * q.bpb * 9;
+    return q;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// end of a chunk planned here: the last version of every touched node -> the other copy of its table bundle, meta published.
+// One lane group per NODE: the windows it is a target in (wmask) -> its chain in the last of them (chain table) -> the chain's last
+// position = the tail of its last run = the log slot to copy.  Four dependent round trips and N lane groups, where the scan of
+// every sorted position for the last-run flag (wstep.hip: k_wwriteback) is five and 2 E / 256 workgroups.
+// ---------------------------------------------------------------------------------------------------------------
+static constexpr int WBN_LANES = 32;
+__global__ __launch_bounds__(256) void k_wwriteback_nodes(tpnet_state S, WPlan p, WTmp q, int64_t Bfull, uint32_t bid) {
+    const int per = S.L * S.d;
+    const int pv = per / 4;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    const int gl = threadIdx.x % WBN_LANES, g = threadIdx.x / WBN_LANES;
+    constexpr int GPB = 256 / WBN_LANES;
+    for (int64_t n = (int64_t)blockIdx.x * GPB + g; n < S.N; n += (int64_t)gridDim.x * GPB) {
+        const unsigned long long wm = p.wmask[n];
+        if (!wm) continue;
+        const int64_t w = 63 - __clzll((long long)wm);
+        uint32_t base, cnt;
+        int64_t last_b;
+        chain_of(p, q, Bfull, (uint32_t)n, w, base, cnt, last_b);
+        const uint32_t pos = base + cnt - 1u;
+        const int c = (int)(meta[n].ver & 1u);
+        const float4* __restrict__ srow = reinterpret_cast<const float4*>(p.log + (int64_t)pos * per);
+        float4* __restrict__ drow = reinterpret_cast<float4*>(S.q + ((int64_t)(c ^ 1) * S.N + n) * (int64_t)per);
+        for (int x = gl; x < pv; x += WBN_LANES) drow[x] = srow[x];
+        if (gl == 0) publish_meta(meta + n, c ^ 1, p.base.desc[last_b].t_last, bid);
+    }
+}
+
+// (false: the caller takes the position scan -- rows that are not 16-byte vectors, or a table much larger than the chunk)
+bool wplan3_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s) {
+    static const int off = TPNET_DEV_INT(NO_WB_NODES, 0);
+    if (off || (st.L * st.d) % 4 != 0 || st.N > 8 * Ec) return false;
+    const WTmp q = wtmp_full(st, p, Ec, batch);
+    int64_t grid = (st.N + 7) / 8;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(k_wwriteback_nodes, dim3((unsigned)grid), dim3(256), 0, s, st, p, q, batch, launch_id);
+    return hipGetLastError() == hipSuccess;
+}
+
 bool wplan3_applies(const tpnet_state& st, int64_t Ec, int64_t batch, int K) {
     if (K < 1 || batch < 1 || batch > PLAN_ONE_MAX) return false;
     const int64_t nb = (Ec + batch - 1) / batch;
@@ -780,14 +835,8 @@ int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, cons
     if (!wplan3_applies(st, Ec, batch, p.K) || !p.wmask || !p.wcls || !p.wtab || !p.wblk) return TPNET_ERR_BAD_ARG;
     const int64_t nb = (Ec + batch - 1) / batch;
     const int64_t nc = 2 * Ec;
-    WTmp q = wtmp_of(p, (size_t)nc);
-    q.bpb = wplan3_bpb(batch);
-    q.seg = wplan3_seg(batch);
+    WTmp q = wtmp_full(st, p, Ec, batch);
     const int64_t nw = (nb + p.K - 1) / p.K;
-    q.direct2 = (nw * st.N <= (int64_t)q.hcap) ? 1u : 0u;
-    q.n2 = (uint32_t)st.N;
-    q.blkcnt = p.wblk;
-    q.blkbase = p.wblk + (size_t)nb * q.bpb * 9;
     int node_bits = 1;
     while (node_bits < 31 && (1ll << node_bits) < st.N) ++node_bits;
     const NodeMeta* meta = reinterpret_cast<const NodeMeta*>(st.meta);
