@@ -11,7 +11,10 @@ c = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C2"]; B = c["B"]
 src, dst, neg, t, N = bench.make_workload(c, 40, 0)
 rp = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=c["E"], dim_factor=10, num_layer=3, time_decay_weight=c["lam"],
         device="cuda:0", use_matrix=False, beginning_time=np.float64(0.0), not_scale=False, enforce_dim=c["d"]).to("cuda:0")
-names = ["start", "edges loaded, weights in LDS", "sorted", "sorted keys in LDS", "items written", "descriptor written"]
+names = (["start", "edges loaded, weights in LDS", "sorted", "sorted keys in LDS", "items written", "descriptor written"]
+         if os.environ.get("TPNET_DEV_PLAN_ONE_SORT") else
+         ["start", "edges loaded, weights in LDS", "grouped (hash table)", "spans scanned, members listed", "ranked, sorted arrays written",
+          "items written"])
 acc = []
 for b in range(30):
     s = slice(b * B, (b + 1) * B)

@@ -509,6 +509,278 @@ __global__ __launch_bounds__(BS) void k_plan_one(Plan p, const int64_t* __restri
     PSTAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same plan WITHOUT a sort, for batches of up to 1 024 edges (round 3): nothing downstream needs the batch's targets in
+// node order -- only every target's contributions side by side, in the reference's order (all src-side adds in edge order,
+// then the dst-side ones = ascending contribution number j).  So: an LDS hash table groups the 2B contributions by target
+// (compare-and-swap insert, one counter per slot), a scan of the counters gives every group its span, the members of a
+// group are listed in arrival order and then RANKED by j -- a group of up to 32 by counting the smaller members, a larger
+// one (a hub) by a wave with a bitmap over j and prefix pop-counts.  Six barriers, no radix pass: 14 -> ~8 us for a C2
+// batch, the first link of every per-batch call's chain.  The position of a group inside the sorted arrays (and of an item
+// inside its list) depends on the table's slot order, not the results: every sum has its terms in the same order as before.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BS, int IPT>
+__global__ __launch_bounds__(BS) void k_plan_one_h(Plan p, const int64_t* __restrict__ src_c, const int64_t* __restrict__ dst_c,
+                                                   const double* __restrict__ t_c, int64_t Ec, int32_t Bfull, int64_t N,
+                                                   double now_time, const double* __restrict__ t_prev, double lambda, int L,
+                                                   uint32_t heavy_threshold, uint32_t* err, int eager) {
+    constexpr int NC = BS * IPT;                         // contributions a workgroup can hold
+    constexpr int SLOTS = 2 * NC;                        // hash table: load <= 1/2
+    constexpr int SPT = SLOTS / BS;                      // slots per thread in the scan
+    constexpr int LOG_SLOTS = (SLOTS == 4096) ? 12 : (SLOTS == 2048) ? 11 : 10;
+    static_assert((1 << LOG_SLOTS) == SLOTS, "k_plan_one_h: table size");
+    constexpr int NW = BS / 64;
+    constexpr int BMW = NC / 32;                         // words of a hub's bitmap over j
+    constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+    constexpr uint32_t SMALL = 16;                       // groups up to this size are ranked by their own members
+    static_assert(NC <= 2048 && BMW <= 64, "k_plan_one_h: j fits 11 bits, a hub's bitmap one word per lane");
+    const int64_t bb = blockIdx.x;
+    const int64_t e0 = bb * Bfull;
+    const int32_t B = (int32_t)((Ec - e0 < Bfull) ? (Ec - e0) : Bfull);
+    const int64_t* __restrict__ src = src_c + e0;
+    const int64_t* __restrict__ dst = dst_c + e0;
+    const double* __restrict__ t = t_c + e0;
+    p.s_partner += 2 * e0;
+    p.s_coef += 2 * e0;
+    p.s_target += 2 * e0;
+    p.light += 2 * e0;
+    p.heavy += 2 * e0;
+    __shared__ uint32_t hkey[SLOTS];                     // the slot's node
+    __shared__ uint32_t hcb[SLOTS];                      // members counted so far; after the scan: span base << 16 | count
+    __shared__ uint16_t mem[NC];                         // members of the groups, span by span, in arrival order
+    __shared__ uint16_t sorted[NC];                      // position -> j (bit 15: the first of its group)
+    __shared__ uint16_t cnt_at[NC];                      // at a group's first position: its size
+    __shared__ uint32_t bm[NW][BMW];                     // a wave's bitmap over j for the hub it ranks
+    __shared__ uint32_t e_src[NC / 2], e_dst[NC / 2];    // endpoint (0 if out of range) | bit 31: the EDGE has a bad endpoint
+    __shared__ float e_w[NC / 2];
+    __shared__ uint32_t n_light, n_heavy, n_big, wsum[NW];
+    __shared__ uint16_t big[NC / SMALL];                 // slots of the groups larger than SMALL
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = 2 * B;
+    [[maybe_unused]] unsigned long long* dbg = p.dbg;
+    PSTAMP(0);
+    constexpr int EPT = IPT / 2;
+    int64_t rs[EPT], rd[EPT];
+    double rt[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {                      // (the loads are in flight while the table is cleared)
+        const int e = q * BS + tid;
+        const int ec = e < B ? e : B - 1;
+        rs[q] = src[ec];
+        rd[q] = dst[ec];
+        rt[q] = t[ec];
+    }
+    const double t_last = t[B - 1];                      // next_time = node_interact_times[-1]   (TPNet.py:76)
+    if (tid == 0) { n_light = 0; n_heavy = 0; n_big = 0; }
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        hkey[k * BS + tid] = EMPTY;
+        hcb[k * BS + tid] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = q * BS + tid;
+        if (e < B) {
+            const int64_t s = rs[q], dd = rd[q];
+            const bool oks = (uint64_t)s < (uint64_t)N, okd = (uint64_t)dd < (uint64_t)N;
+            const uint32_t bad = (oks && okd) ? 0u : 0x80000000u;
+            if (bad) atomicAdd(err, 1u);                 // once per bad edge
+            e_src[e] = (oks ? (uint32_t)s : 0u) | bad;
+            e_dst[e] = (okd ? (uint32_t)dd : 0u) | bad;
+            const float x = (float)t_last - (float)rt[q];   // the reference's casts (models/TPNet.py:77-78), as contribution()
+            e_w[e] = bad ? 0.0f : expf((float)(-lambda) * x);
+        }
+    }
+    __syncthreads();
+    PSTAMP(1);
+    auto target_of = [&](int j) -> uint32_t {            // first the src-side scatter-adds, then the dst-side ones (TPNet.py:93-96)
+        return ((j >= B) ? e_dst[j - B] : e_src[j]) & 0x7FFFFFFFu;
+    };
+    auto contrib = [&](int j, int32_t& partner, float& w) {
+        const bool side = j >= B;
+        const int e = side ? j - B : j;
+        const uint32_t es = e_src[e], ed = e_dst[e];
+        const bool ok = !(es & 0x80000000u);
+        partner = ok ? (int32_t)((side ? es : ed) & 0x7FFFFFFFu) : 0;
+        w = ok ? e_w[e] : 0.0f;
+    };
+    // group by target: slot and arrival number of every contribution
+    uint32_t slot[IPT], arr[IPT];
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int j = q * BS + tid;
+        slot[q] = 0;
+        arr[q] = 0;
+        if (j < nc) {
+            const uint32_t key = target_of(j);
+            uint32_t h = (key * 2654435761u) >> (32 - LOG_SLOTS);
+            for (;;) {                                   // (the table is never more than half full: the walk ends)
+                const uint32_t prev = atomicCAS(&hkey[h], EMPTY, key);
+                if (prev == EMPTY || prev == key) break;
+                h = (h + 1) & (uint32_t)(SLOTS - 1);
+            }
+            slot[q] = h;
+            arr[q] = atomicAdd(&hcb[h], 1u);
+        }
+    }
+    __syncthreads();
+    PSTAMP(2);
+    // spans: exclusive scan of the slots' counts
+    uint32_t c[SPT], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        c[k] = hcb[tid * SPT + k];
+        tsum += c[k];
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = inc - tsum;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        if (i < wave) base += wsum[i];
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        hcb[tid * SPT + k] = (base << 16) | c[k];
+        if (c[k] > SMALL) big[atomicAdd(&n_big, 1u)] = (uint16_t)(tid * SPT + k);
+        base += c[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int j = q * BS + tid;
+        if (j < nc) mem[(hcb[slot[q]] >> 16) + arr[q]] = (uint16_t)j;
+    }
+    __syncthreads();
+    PSTAMP(3);
+    // ranks and the sorted arrays
+    auto emit = [&](int j, uint32_t pos, bool first, uint32_t cnt) {    // (the arrays themselves are written by position below: coalesced)
+        sorted[pos] = (uint16_t)(j | (first ? 0x8000 : 0));
+        if (first) cnt_at[pos] = (uint16_t)cnt;
+    };
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+        const int j = q * BS + tid;
+        if (j < nc) {
+            const uint32_t cb = hcb[slot[q]];
+            const uint32_t gb = cb >> 16, cnt = cb & 0xFFFFu;
+            if (cnt <= SMALL) {
+                uint32_t rank = 0;
+                if (cnt > 1) {
+                    for (uint32_t m = 0; m < cnt; m += 4) {          // (four independent LDS reads per round; the span of the
+#pragma unroll                                                       //  last group ends inside mem[], a read past a span is masked)
+                        for (uint32_t k = 0; k < 4; ++k) {
+                            const uint32_t mm = m + k;
+                            const uint32_t o = mem[(gb + mm) < (uint32_t)NC ? gb + mm : 0u];
+                            rank += (mm < cnt && o < (uint32_t)j) ? 1u : 0u;
+                        }
+                    }
+                }
+                emit(j, gb + rank, rank == 0, cnt);
+            }
+        }
+    }
+    const uint32_t nbig = n_big;
+    for (uint32_t k = wave; k < nbig; k += NW) {         // a hub: one wave, a bitmap over j, prefix pop-counts
+        const uint32_t cb = hcb[big[k]];
+        const uint32_t gb = cb >> 16, cnt = cb & 0xFFFFu;
+        if (lane < BMW) bm[wave][lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t m = lane; m < cnt; m += 64) {
+            const uint32_t j = mem[gb + m];
+            atomicOr(&bm[wave][j >> 5], 1u << (j & 31u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t word = lane < BMW ? bm[wave][lane] : 0u;
+        uint32_t pre = (uint32_t)__popc(word);
+        const uint32_t own = pre;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)pre, o, 64);
+            if (lane >= o) pre += v;
+        }
+        pre -= own;
+        for (uint32_t m0 = 0; m0 < cnt; m0 += 64) {      // (uniform trip count: the shuffles are wave-wide)
+            const uint32_t m = m0 + lane;
+            const bool on = m < cnt;
+            const uint32_t j = on ? mem[gb + m] : 0u;
+            const uint32_t pw = (uint32_t)__shfl((int)pre, (int)(j >> 5), 64);
+            const uint32_t ww = (uint32_t)__shfl((int)word, (int)(j >> 5), 64);
+            const uint32_t rank = pw + (uint32_t)__popc(ww & ((1u << (j & 31u)) - 1u));
+            if (on) emit((int)j, gb + rank, rank == 0, cnt);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    PSTAMP(4);
+    // the items: one per group, at the group's first position
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {                      // (uniform trip count: the list appends are wave-wide)
+        const int pos = q * BS + tid;
+        Item it;
+        bool lead = false;
+        if (pos < nc) {
+            const uint32_t v = sorted[pos];
+            lead = (v & 0x8000u) != 0;
+            const int j = (int)(v & 0x7FFFu);
+            const int32_t tg = (int32_t)target_of(j);
+            contrib(j, it.p0, it.w0);
+            p.s_partner[pos] = it.p0;
+            p.s_coef[pos] = it.w0;
+            p.s_target[pos] = tg;
+            if (lead) {
+                it.j0 = (uint32_t)(2 * e0 + pos);                  // chunk-relative position in the sorted arrays
+                it.cnt = cnt_at[pos];
+                it.target = tg;
+                it.p1 = 0;
+                it.w1 = 0.0f;
+                it.pad = 0;
+                if (it.cnt >= 2) contrib((int)(sorted[pos + 1] & 0x7FFFu), it.p1, it.w1);
+            }
+        }
+        const bool hv = lead && it.cnt > heavy_threshold, lt = lead && !hv;
+        const unsigned long long ml = __ballot(lt), mh = __ballot(hv);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (ml) {
+            const int first = __ffsll((long long)ml) - 1;
+            uint32_t lb = 0;
+            if (lane == first) lb = atomicAdd(&n_light, (uint32_t)__popcll(ml));
+            lb = __shfl(lb, first);
+            if (lt) p.light[lb + (uint32_t)__popcll(ml & below)] = it;
+        }
+        if (mh) {
+            const int first = __ffsll((long long)mh) - 1;
+            uint32_t hb = 0;
+            if (lane == first) hb = atomicAdd(&n_heavy, (uint32_t)__popcll(mh));
+            hb = __shfl(hb, first);
+            if (hv) p.heavy[hb + (uint32_t)__popcll(mh & below)] = it;
+        }
+    }
+    __syncthreads();
+    PSTAMP(5);
+    if (tid == 0) {
+        BatchDesc D;
+        D.e0 = e0;
+        D.ne = B;
+        D.pad = 0;
+        D.t_last = t_last;
+        D.now = (bb == 0) ? (t_prev ? *t_prev : now_time) : t_c[e0 - 1];   // clock left by the previous batch (TPNet.py:99)
+        D.n_light = n_light;
+        D.n_heavy = n_heavy;
+        const double g = eager ? exp(-lambda * (t_last - D.now)) : 1.0;    // (as k_plan_one)
+        for (int i = 0; i < TPNET_MAX_LAYERS; ++i)
+            D.decay[i] = (eager && i < L) ? (float)pow(g, (double)(i + 1)) : 1.0f;
+        p.desc[bb] = D;
+    }
+}
+
 int64_t plan_one_max_batch() {
     static const int off = TPNET_DEV_STR(NO_PLAN_ONE) ? 1 : 0;     // developer override: always the chunk planner
     return off ? 0 : PLAN_ONE_MAX;
@@ -533,6 +805,18 @@ int plan_blocks(const tpnet_state& st, const Plan& p, const int64_t* src, const 
     hipLaunchKernelGGL((k_plan_one<BS_, IPT_>), dim3((unsigned)nbl), dim3(BS_), 0, s, p, src, dst, t, Ec, (int32_t)B, st.N,   \
                        node_bits, now_time, t_prev_dev, lambda, (int)st.L, thr, st.err, (flags & TPNET_FLAG_EAGER_DECAY) ? 1 : 0)
     const int64_t nc = 2 * B;
+    static const int sort_env = TPNET_DEV_INT(PLAN_ONE_SORT, 0);   // developer override: the sorting planner for every size
+#define TPNET_PLAN_ONE_H(BS_, IPT_)                                                                                         \
+    hipLaunchKernelGGL((k_plan_one_h<BS_, IPT_>), dim3((unsigned)nbl), dim3(BS_), 0, s, p, src, dst, t, Ec, (int32_t)B, st.N, \
+                       now_time, t_prev_dev, lambda, (int)st.L, thr, st.err, (flags & TPNET_FLAG_EAGER_DECAY) ? 1 : 0)
+    if (nc <= 2048 && !sort_env) {
+        if (nc <= 512) TPNET_PLAN_ONE_H(256, 2);
+        else if (nc <= 1024) TPNET_PLAN_ONE_H(512, 2);
+        else TPNET_PLAN_ONE_H(1024, 2);
+        TPNET_HIP_TRY(hipGetLastError());
+        return TPNET_OK;
+    }
+#undef TPNET_PLAN_ONE_H
     if (nc <= 512) {
         if (bs_env == 512) TPNET_PLAN_ONE(256, 2); else TPNET_PLAN_ONE(256, 2);
     } else if (nc <= 1024) {
