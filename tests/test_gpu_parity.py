@@ -219,6 +219,47 @@ def test_exact_mode_is_bit_exact_when_times_are_batch_constant():
         np.testing.assert_array_equal(_layers(rp), np.stack(st.P[1:]))
 
 
+@pytest.mark.parametrize("B", [1, 2, 33, 255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025])
+@pytest.mark.parametrize("law", ["one-node", "two-nodes", "groups-of-16-17", "distinct", "mixed"])
+def test_single_batch_planner_group_shapes_bit_for_bit(B, law):
+    """The per-batch planner groups a batch's contributions by target without a sort (k_plan_one_h, B <= 1 024: hash table,
+    rank by contribution number -- small groups by counting, hubs by a bitmap; B = 1 025: the sorting planner).  Whatever
+    the shape of the groups -- every contribution on ONE target, groups on both sides of the small / hub limit, all distinct
+    -- each target's sum must keep the reference's order: with batch-constant times the exact mode is bit for bit the oracle
+    (order-sensitive f32 sums), and the default mode (hubs summed by workgroups) is the oracle within the stream tolerance."""
+    _need_gpu()
+    rng = np.random.RandomState(B * 5 + len(law))
+    N, d, L, nb = 2100, 64, 2, 2
+    E = B * nb
+    if law == "one-node":
+        src = np.full(E, 5, np.int64); dst = np.full(E, 5, np.int64)
+        dst[1::2] = rng.randint(1, N, len(dst[1::2]))               # (half of the dst side elsewhere: the hub keeps ~1.5 B terms)
+    elif law == "two-nodes":
+        src = np.where(rng.rand(E) < 0.5, 3, 4).astype(np.int64); dst = np.where(rng.rand(E) < 0.5, 3, 4).astype(np.int64)
+    elif law == "groups-of-16-17":
+        src = (1 + (np.arange(E) % B) // 16).astype(np.int64)       # 16 src-side terms per node ...
+        dst = (1 + N // 2 + (np.arange(E) % B) // 17).astype(np.int64)   # ... 17 dst-side terms per node of another range
+        dst[::40] = src[::40]                                       # (and a seventeenth / eighteenth for some)
+    elif law == "distinct":
+        src = (1 + np.arange(E) % B).astype(np.int64); dst = (1 + B + np.arange(E) % B).astype(np.int64)
+    else:
+        src, dst, _, _ = _random_stream(rng, N, E, 1.0, hub_frac=0.5)
+    t = np.repeat(1000.0 * np.arange(1, nb + 1), B)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    for exact in (True, False):
+        rp = _module(N, d, L, 1e-4, 0.0, P0=P0, exact=exact)
+        st = O.OracleState(P0, L, 1e-4, 0.0)
+        for b in range(nb):
+            s = slice(b * B, (b + 1) * B)
+            rp.update(src[s], dst[s], t[s])
+            O.update(st, src[s], dst[s], t[s])
+            if exact:
+                np.testing.assert_array_equal(_layers(rp), np.stack(st.P[1:]), err_msg=f"batch {b}")
+            else:
+                _assert_state(_layers(rp), np.stack(st.P[1:]), 1e-4, f"batch {b}")
+        rp.check_device_errors()
+
+
 def test_module_calls_interleave_like_the_training_loop():
     """Caller order of train_link_prediction.py:325-373: readouts (big and small), then update, per batch; plus
     encoder-style index patterns (np.tile / np.repeat, padding id 0: models/TPNet.py:313-316)."""
