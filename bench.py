@@ -388,10 +388,10 @@ def main():
         gc.collect()
         gc.disable()                              # (no collector pause inside the timed region; re-enabled behind it)
 
-        # the warm-up steps run the schedule the timed steps will run ("auto" picks the windowed pipeline from 28 batches of
+        # the warm-up steps run the schedule the timed steps will run ("auto" picks the windowed pipeline from 24 batches of
         # <= 2048 edges, 56 larger ones; a warm-up call shorter than that would otherwise leave the pipeline's kernels to be
         # loaded inside the timed region: HIP resolves every kernel at its first launch, ~0.3 ms each)
-        timed_windowed = d % 4 == 0 and ((K >= 28 and Bg <= 2048) or (K >= 56 and Bg <= 4096))
+        timed_windowed = d % 4 == 0 and ((K >= 24 and Bg <= 2048) or (K >= 56 and Bg <= 4096))
 
         def prep(a, b_):
             sl_ = slice(a * Bg, b_ * Bg)
@@ -466,7 +466,7 @@ def main():
 
     # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side, tpnet_time_stream)
     # around the loop of launches of the dominant kernel, in an extra pass over the SAME batches [W, W + K) as the timed
-    # region -- so `roofline` describes the kernel `value` was produced by (k_step below ~28 batches, k_wpipe from there).
+    # region -- so `roofline` describes the kernel `value` was produced by (k_step below 24 batches, k_wpipe from there).
     roof = None
     extra = {}
 

@@ -1055,9 +1055,9 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     np.testing.assert_array_equal(e4[2], c1[2])
 
 
-@pytest.mark.parametrize("nb", [27, 28, 60])
+@pytest.mark.parametrize("nb", [23, 24, 60])
 def test_auto_schedule_on_both_sides_of_its_threshold(nb):
-    """The shipped default ("auto") takes the per-batch kernels below 28 batches and the windowed pipeline from there
+    """The shipped default ("auto") takes the per-batch kernels below 24 batches and the windowed pipeline from there
     (tpnet_amd/csrc/api.hip, window_chunk): both sides against the oracle, and the choice itself (a windowed run leaves a
     plan that the next epoch replays; a per-batch run does not)."""
     _need_gpu()
@@ -1081,7 +1081,7 @@ def test_auto_schedule_on_both_sides_of_its_threshold(nb):
     rp.reset_random_projections()
     rp.random_projections[0].data.copy_(torch.from_numpy(P0))
     rp.run_stream(ds, dd, dn, dt, B, schedule="auto")
-    assert rp.last_stream_replayed == (nb >= 28)
+    assert rp.last_stream_replayed == (nb >= 24)
 
 
 def test_multi_chunk_packed_rows_with_odd_row_length():

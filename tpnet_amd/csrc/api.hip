@@ -52,8 +52,9 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     const int64_t nb = (E + batch - 1) / batch;
     // short streams: with the three-launch planner (wplan3.hip; batches of <= 2 048 edges) the pipeline pays ~70 us of planning
     // and L + 1 dependent launches up front, the per-batch schedule ~20 us and ~6.6 us per batch (C2): the pipeline wins from
-    // about 28 batches (tools/short_sweep.py: 20 batches 210 against 180 us, 40 batches 277 against 312 us).  Larger batches keep the chunk planner's crossover (two device-wide sorts).
-    static const int min_nb3 = TPNET_DEV_INT(WIN_MIN_BATCHES, 28);
+    // 24 batches (tools/short_sweep.py, end of round 3: 20 batches 186 against 170 us, 24: 194 against 196, 28: 202 against 221,
+    // 40: 236 against 295).  Larger batches keep the chunk planner's crossover (two device-wide sorts).
+    static const int min_nb3 = TPNET_DEV_INT(WIN_MIN_BATCHES, 24);
     const int min_nb = batch <= PLAN_ONE_MAX ? min_nb3 : 56;
     if (K == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
     *K_out = K;
