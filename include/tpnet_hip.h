@@ -383,7 +383,7 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
  * recent neighbours from the device sampler, and every neighbour is paired with the edge's two endpoints: out[0][(i*K + k)] =
  * G(neigh[i][k], src[i % B]), out[1][...] = G(neigh[i][k], other[i % B]), i in [0, 2B) -- the reference's
  * get_pair_wise_feature(tile(neigh, 2), concat(repeat(tile(src,2),K), repeat(tile(other,2),K))) before self.mlp, without any index
- * array and without the neighbour ids visiting the host.  One call, three launches.  scratch: tpnet_encoder_scratch_bytes(B, K)
+ * array and without the neighbour ids visiting the host.  One call, two launches (rows + sampler, readout).  scratch: tpnet_encoder_scratch_bytes(B, K)
  * device bytes; the sampled neighbour ids [2B][K] (int64) are left at (scratch rounded up to 256) + 64 B bytes for the caller's
  * other neighbour features.  Needs tpnet_pair_gram_anchored_supported(st).  src / other / t: device arrays of B. */
 size_t tpnet_encoder_scratch_bytes(int64_t B, int32_t K);

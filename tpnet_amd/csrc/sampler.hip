@@ -117,6 +117,43 @@ __global__ void k_encoder_rows(const int64_t* __restrict__ src, const int64_t* _
     }
 }
 
+// the two kernels above in ONE launch for the encoder's call (round 3): thread (row i, slot k) derives the row's node and time
+// from the batch itself (three loads that a wave shares: its 64 threads span 3-4 rows), slot 0 also writes the row's record
+// (node, time, anchors); then the sampler's cut and window as in k_sample_recent.  One launch less per encoder call (~5 us each).
+__global__ void k_encoder_sample(const int64_t* __restrict__ row_start, const int32_t* __restrict__ nbr,
+                                 const double* __restrict__ nbr_t, int64_t num_nodes, const int64_t* __restrict__ src,
+                                 const int64_t* __restrict__ other, const double* __restrict__ t, int64_t B, int K,
+                                 int64_t* __restrict__ nodes, double* __restrict__ t2, int64_t* __restrict__ a1,
+                                 int64_t* __restrict__ a2, int64_t* __restrict__ out_ids) {
+    const int64_t tot = 2 * B * K;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = x / K;
+        const int k = (int)(x - i * K);
+        const int64_t e = i < B ? i : i - B;
+        const int64_t sn = src[e], on = other[e];
+        const double q = t[e];
+        const int64_t nid = i < B ? sn : on;
+        if (k == 0) {
+            nodes[i] = nid;
+            t2[i] = q;
+            a1[i] = sn;
+            a2[i] = on;
+        }
+        int64_t id = 0;
+        if ((uint64_t)nid < (uint64_t)num_nodes) {
+            const int64_t lo0 = row_start[nid], hi0 = row_start[nid + 1];
+            int64_t lo = lo0, hi = hi0;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (nbr_t[mid] < q) lo = mid + 1; else hi = mid;
+            }
+            const int64_t pos = lo - K + k;           // slot k of the K-wide window ending at the cut
+            if (pos >= lo0) id = nbr[pos];
+        }
+        out_ids[x] = id;
+    }
+}
+
 }  // namespace tpnet
 
 using namespace tpnet;
@@ -224,10 +261,21 @@ int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, in
     int64_t* a1 = (int64_t*)(t2 + 2 * B);
     int64_t* a2 = a1 + 2 * B;
     int64_t* neigh = a2 + 2 * B;
-    int g0 = (int)((2 * B + 255) / 256);
-    if (g0 > 1024) g0 = 1024;
-    hipLaunchKernelGGL(k_encoder_rows, dim3(g0), dim3(256), 0, s, src, other, t, B, nodes, t2, a1, a2);
-    return tpnet_sample_recent(sampler, E, num_nodes, nodes, t2, 2 * B, K, neigh, nullptr, nullptr, stream);
+    static const int two = TPNET_DEV_INT(ENCODER_TWO_LAUNCHES, 0);     // developer override: row set-up and sampler apart
+    if (two) {
+        int g0 = (int)((2 * B + 255) / 256);
+        if (g0 > 1024) g0 = 1024;
+        hipLaunchKernelGGL(k_encoder_rows, dim3(g0), dim3(256), 0, s, src, other, t, B, nodes, t2, a1, a2);
+        return tpnet_sample_recent(sampler, E, num_nodes, nodes, t2, 2 * B, K, neigh, nullptr, nullptr, stream);
+    }
+    SamplerView v = carve(const_cast<void*>(sampler), E, num_nodes);
+    const int64_t tot = 2 * B * (int64_t)K;
+    int grid = (int)((tot + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_encoder_sample, dim3(grid), dim3(256), 0, s, v.row_start, v.nbr, v.nbr_t, num_nodes, src, other, t, B, (int)K,
+                       nodes, t2, a1, a2, neigh);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
 }
 
 int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
