@@ -111,7 +111,10 @@ def prepared(mlp, F):
     .to()): keyed on (data_ptr, _version) of the four tensors."""
     try:
         l1, l2 = mlp._modules["0"], mlp._modules["2"]
-        w1, b1, w2, b2 = l1.weight, l1.bias, l2.weight, l2.bias
+        p1, p2 = l1._parameters, l2._parameters      # (the dicts behind l1.weight ...: nn.Module.__getattr__ is ~0.4 us per read,
+        w1, b1, w2, b2 = p1["weight"], p1["bias"], p2["weight"], p2["bias"]   #  and this runs on every call)
+        if w1 is None or b1 is None or w2 is None or b2 is None:
+            return None
     except (KeyError, AttributeError):
         return None
     key = (w1.data_ptr(), w1._version, b1.data_ptr(), b1._version, w2.data_ptr(), w2._version, b2.data_ptr(), b2._version)

@@ -886,7 +886,9 @@ class RandomProjectionModule(nn.Module):
     def _fused_feature(self, src, dst, n):
         """tpnet_host_pair_feature with self.mlp (None if self.mlp is not the reference's Linear-ReLU-Linear on this GPU)."""
         NG = self.pair_wise_feature_dim
-        mlp = self.mlp
+        mlp = self._modules.get("mlp")              # (self.mlp without nn.Module.__getattr__)
+        if mlp is None:
+            mlp = self.mlp
         if len(dst) != n:
             raise ValueError("src_node_ids and dst_node_ids must have the same length")
         if self._plist()[0].device.type != "cuda":
