@@ -392,7 +392,8 @@ int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, in
                        uint32_t flags, void* scratch, size_t scratch_bytes, float* out, void* stream);
 
 /* The first half of tpnet_encoder_gram alone: the rows [src; other] at tile(t, 2), their anchors and their K sampled neighbours,
- * laid out in `scratch` (rounded up to 256): nodes int64[2B] | times double[2B] | a1 int64[2B] | a2 int64[2B] | neigh int64[2B][K]. */
+ * laid out in `scratch` (rounded up to 256): nodes int64[2B] | times double[2B] | a1 int64[2B] | a2 int64[2B] | neigh int64[2B][K]
+ * | (rows of <= 128 floats: the call's pairs spelled out for the generic readout) u int64[4BK] | v int64[4BK]. */
 int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
                        const int64_t* other, const double* t, int64_t B, int32_t K, void* scratch, size_t scratch_bytes,
                        void* stream);

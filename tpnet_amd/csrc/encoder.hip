@@ -61,6 +61,14 @@ int tpnet_encoder_features(const tpnet_state* st, const void* sampler, int64_t E
     int64_t* a1 = nodes + 4 * B;
     int64_t* a2 = a1 + 2 * B;
     int64_t* neigh = a2 + 2 * B;
+    if (encoder_generic_readout(*st) && st->L == 3 && !(flags & TPNET_FLAG_PACKED) && mlp->F == 64 && mlp->H == 256 && mlp->w1 &&
+        mlp->w2f && mlp->b1 && mlp->b2 && !((reinterpret_cast<uintptr_t>(gram) | reinterpret_cast<uintptr_t>(out)) & 15)) {
+        // narrow rows: the generic readout on the pair lists the sampler kernel wrote behind the neighbour ids, then the dense layers
+        const int64_t half = 2 * B * (int64_t)K;
+        rc = tpnet_pair_gram(st, neigh + half, neigh + 3 * half, 2 * half, now_time, lambda, flags, gram, stream);
+        if (rc) return rc;
+        return mlp_rows(mlp, gram, 2 * half, out, (hipStream_t)stream);
+    }
     return tpnet_anchored_features(st, neigh, a1, a2, 2 * B, K, now_time, lambda, flags, mlp, gram, out, stream);
 }
 

@@ -124,7 +124,8 @@ __global__ void k_encoder_sample(const int64_t* __restrict__ row_start, const in
                                  const double* __restrict__ nbr_t, int64_t num_nodes, const int64_t* __restrict__ src,
                                  const int64_t* __restrict__ other, const double* __restrict__ t, int64_t B, int K,
                                  int64_t* __restrict__ nodes, double* __restrict__ t2, int64_t* __restrict__ a1,
-                                 int64_t* __restrict__ a2, int64_t* __restrict__ out_ids) {
+                                 int64_t* __restrict__ a2, int64_t* __restrict__ out_ids, int64_t* __restrict__ pu,
+                                 int64_t* __restrict__ pv) {
     const int64_t tot = 2 * B * K;
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < tot; x += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = x / K;
@@ -151,12 +152,28 @@ __global__ void k_encoder_sample(const int64_t* __restrict__ row_start, const in
             if (pos >= lo0) id = nbr[pos];
         }
         out_ids[x] = id;
+        if (pu) {
+            // narrow rows: the call's pairs spelled out, (neighbour, src) then (neighbour, other) -- get_pair_wise_feature's own
+            // order (models/TPNet.py:311-316) -- for the generic readout, which beats the anchored walk on rows of <= 128 floats
+            pu[x] = id;
+            pu[tot + x] = id;
+            pv[x] = sn;
+            pv[tot + x] = on;
+        }
     }
 }
 
 }  // namespace tpnet
 
 using namespace tpnet;
+
+// rows of <= 128 floats: the generic pair kernel's 16-lane geometry reads an encoder-style list faster than the anchored walk
+// (tools/encoder_readout.py, 80 000 pairs at d=128: 27.1 against 31.3 us; 16 000 at d=64: 7.1 against 13.2) -- the encoder's calls
+// take it there, from pair lists the sampler kernel writes beside the neighbour ids
+bool tpnet::encoder_generic_readout(const tpnet_state& st) {
+    static const int off = TPNET_DEV_INT(ENCODER_ANCHORED_ONLY, 0);
+    return !off && st.d <= 128;
+}
 
 extern "C" {
 
@@ -246,7 +263,7 @@ int tpnet_sample_recent(const void* sampler, int64_t E, int64_t num_nodes, const
 size_t tpnet_encoder_scratch_bytes(int64_t B, int32_t K) {
     if (B < 0) B = 0;
     if (K < 1) K = 1;
-    return (size_t)(8 * B + 2 * B * (int64_t)K) * 8 + 256;
+    return (size_t)(8 * B + 10 * B * (int64_t)K) * 8 + 256;       // (+ the spelled-out pair lists of narrow rows: 2 x 4 B K ids)
 }
 
 int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, int64_t num_nodes, const int64_t* src,
@@ -272,8 +289,9 @@ int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, in
     const int64_t tot = 2 * B * (int64_t)K;
     int grid = (int)((tot + 255) / 256);
     if (grid > 8192) grid = 8192;
+    int64_t* pu = encoder_generic_readout(*st) ? neigh + 2 * B * (int64_t)K : nullptr;
     hipLaunchKernelGGL(k_encoder_sample, dim3(grid), dim3(256), 0, s, v.row_start, v.nbr, v.nbr_t, num_nodes, src, other, t, B, (int)K,
-                       nodes, t2, a1, a2, neigh);
+                       nodes, t2, a1, a2, neigh, pu, pu ? pu + 4 * B * (int64_t)K : nullptr);
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }
@@ -292,6 +310,10 @@ int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, in
     int64_t* a2 = a1 + 2 * B;
     int64_t* neigh = a2 + 2 * B;
     const int NN = 2 * st->L + 2;
+    if (encoder_generic_readout(*st)) {
+        const int64_t half = 2 * B * (int64_t)K;
+        return tpnet_pair_gram(st, neigh + half, neigh + 3 * half, 2 * half, now_time, lambda, flags, out, stream);
+    }
     return tpnet_pair_gram_anchored(st, neigh, a1, a2, 2 * B, K, now_time, lambda, flags, out,
                                     out + (size_t)(2 * B) * (size_t)K * (size_t)(NN * NN), stream);
 }

@@ -178,6 +178,7 @@ int mlp_f32_mode();
 
 // the plan of ONE batch by one workgroup (plan.hip, k_plan_one): same Plan contents as plan_build for batch 0 of a chunk
 static constexpr int64_t PLAN_ONE_MAX = 2048;
+bool encoder_generic_readout(const tpnet_state& st);   // sampler.hip: the encoder's calls on rows of <= 128 floats
 int64_t plan_one_max_batch();      // PLAN_ONE_MAX (0 with the developer override TPNET_DEV_NO_PLAN_ONE)
 int plan_one(const tpnet_state& st, const Plan& p, const int64_t* src, const int64_t* dst, const double* t, int64_t B,
              double now_time, double lambda, uint32_t flags, hipStream_t s);
