@@ -88,6 +88,9 @@ typedef struct tpnet_state {
 #define TPNET_FLAG_PLAN_SORTED 64u    /* tpnet_run_stream, windowed schedule: plan every chunk with the chunk planner (two device-wide
                                        radix sorts) even where the three-launch planner applies (batches of <= 2048 edges, <= 64
                                        windows per chunk).  Both give the same bits; this one is the slower start-up */
+#define TPNET_FLAG_PLAN_HASHED 128u   /* tpnet_run_stream, windowed schedule: plan with the hashed planner (a fill + four kernels, <= 64
+                                       windows per chunk) even where the one-launch dense planner applies (table small against the
+                                       stream: N * 12 bytes <= batch * L * d * 4).  Same bits again */
 
 const char* tpnet_strerror(int status);
 int tpnet_abi_version(void);

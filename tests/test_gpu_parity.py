@@ -978,8 +978,9 @@ def test_version_protocol_under_multi_pass_grids(d, B, N):
                                         (120, 3, 260, 40, 200), (128, 3, 50, 1000, 12),
                                         (16, 3, 60000, 100, 40)])      # (many nodes, few edges: the chain table is hashed)
 def test_three_launch_planner_equals_chunk_planner(d, L, N, B, nb):
-    """Both planners of the windowed schedule describe the same runs (blocks of 8 contributions in index order, the same
-    versions read): features and state are equal bit for bit, whatever the window length each picks."""
+    """All three planners of the windowed schedule (the one-launch dense planner where the table is small against the stream --
+    every case but the last --, the hashed planner, the sorted chunk planner) describe the same runs (blocks of 8 contributions
+    in index order, the same versions read): features and state are equal bit for bit, whatever the window length each picks."""
     _need_gpu()
     rng = np.random.RandomState(d + B + nb)
     E = nb * B - B // 3
@@ -996,11 +997,14 @@ def test_three_launch_planner_equals_chunk_planner(d, L, N, B, nb):
     fb, nb_ = b.run_stream(ds, dd, dn, dt, B, schedule="windowed-sorted")
     ok = torch.ones(E, dtype=torch.bool, device=DEV)
     ok[5] = False                                                # (rows of a bad id are not defined)
-    assert torch.equal(fa[ok], fb[ok])
+    c = _module(N, d, L, lam, t[0], P0=P0)
+    fc, nc_ = c.run_stream(ds, dd, dn, dt, B, schedule="windowed-hashed")
+    assert torch.equal(fa[ok], fb[ok]) and torch.equal(fc[ok], fb[ok])
     ok[7] = False
-    assert torch.equal(na[ok], nb_[ok])
+    assert torch.equal(na[ok], nb_[ok]) and torch.equal(nc_[ok], nb_[ok])
     np.testing.assert_array_equal(_layers(a), _layers(b))
-    for m in (a, b):
+    np.testing.assert_array_equal(_layers(c), _layers(b))
+    for m in (a, b, c):
         with pytest.raises(IndexError):
             m.check_device_errors()
 

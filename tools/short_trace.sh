@@ -13,8 +13,8 @@ for s in $1; do
 import csv,glob
 import os; f=max(glob.glob("$R/gpurun_out/st_trace/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows=sorted(csv.DictReader(open(f)), key=lambda r:int(r['Start_Timestamp']))
-starts=[i for i,r in enumerate(rows) if 'k_wsort' in r['Kernel_Name'] or 'k_make_keys_w' in r['Kernel_Name']]
-a=starts[-1]-1 if 'fillBuffer' in rows[starts[-1]-1]['Kernel_Name'] else starts[-1]
+starts=[i for i,r in enumerate(rows) if 'k_wsort' in r['Kernel_Name'] or 'k_make_keys_w' in r['Kernel_Name'] or 'k_dense_sort<' in r['Kernel_Name']]
+a=starts[-1]-1 if ('fillBuffer' in rows[starts[-1]-1]['Kernel_Name'] and 'k_dense_sort<' not in rows[starts[-1]]['Kernel_Name']) else starts[-1]
 b=a
 while b < len(rows) and not ('k_wpipe' in rows[b]['Kernel_Name']): b+=1
 while b < len(rows) and ('k_wpipe' in rows[b]['Kernel_Name'] or 'k_wwriteback' in rows[b]['Kernel_Name']): b+=1

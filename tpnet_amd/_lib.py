@@ -17,6 +17,7 @@ FLAG_PACKED = 8
 FLAG_SCHED_WINDOWED = 16
 FLAG_SCHED_BATCH = 32
 FLAG_PLAN_SORTED = 64
+FLAG_PLAN_HASHED = 128
 
 ERR_INDEX = -4
 

@@ -66,8 +66,10 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     // batches that fit one workgroup's LDS: chunks of at most 64 windows, which the hashed planner serves (wplan3.hip) -- ONE set
     // of plan kernels whatever the stream's length (a chunk that falls to the sorted planner meets rocPRIM's large-size sort
     // kernels for the first time in the middle of a long call: HIP resolves a kernel at its first launch, ~0.3 ms each)
-    if (batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED) && cap > (int64_t)WIN_MAX_WINDOWS * Ew)
-        cap = (int64_t)WIN_MAX_WINDOWS * Ew;
+    // (the dense planner, wplan_dense.hip: one launch, up to 256 windows)
+    const bool dense = !(flags & (TPNET_FLAG_PLAN_SORTED | TPNET_FLAG_PLAN_HASHED)) && wplan_dense_eligible(st.N, st.d, st.L, batch);
+    const int64_t maxw = dense ? 256 : WIN_MAX_WINDOWS;
+    if (batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED) && cap > maxw * Ew) cap = maxw * Ew;
     const int64_t hard = cap / Ew * Ew;
     const int64_t lim = (E <= cap) ? E : hard;
     if ((lim + batch - 1) / batch < 4) return 0;
@@ -129,12 +131,13 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
         // the hashed planner costs ~45 us + 0.76 us per batch, the sorted one ~200 us + 0.63 us per batch (C2, profiles/r03_C2.md):
         // 4 % of a long stream's time, paid for having one set of plan kernels (see window_chunk)
         static const int max3 = TPNET_DEV_INT(PLAN3_MAX_BATCHES, 1 << 30);
-        const bool plan3 = !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && nb <= max3 && wplan3_applies(st, Ec, batch, K);
+        const bool dense = !(flags & (TPNET_FLAG_PLAN_SORTED | TPNET_FLAG_PLAN_HASHED)) && wplan_dense_applies(st, p, Ec, batch, K);
+        const bool plan3 = !dense && !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && nb <= max3 && wplan3_applies(st, Ec, batch, K);
         // a plan may be replayed when the whole stream is ONE chunk and the caller vouches (tag) that the stream arrays and
         // the table's per-node state are what the plan in this workspace was built for
         PlanBuilt now{};
         bool replay = false;
-        if (tag && plan3 && Ec == E && tag->table_sig && tag->stream_sig) {
+        if (tag && (plan3 || dense) && Ec == E && tag->table_sig && tag->stream_sig) {
             now.valid = 1; now.src = src; now.dst = dst; now.t = t; now.ws = ws; now.E = E; now.batch = batch; now.N = st.N;
             now.ws_bytes = ws_bytes; now.now_time = now_time; now.lambda = lambda; now.d = st.d; now.L = st.L; now.K = K;
             now.flags = flags & ~(uint32_t)TPNET_FLAG_SCHED_WINDOWED;
@@ -145,7 +148,10 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
             memset(tag->built, 0, sizeof(tag->built));                  // (invalid unless this call completes its plan)
             tag->replayed = replay ? 1 : 0;
         }
-        if (plan3)
+        if (dense)
+            rc = wplan_dense_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
+                                   c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, replay, s);
+        else if (plan3)
             rc = wplan3_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
                               c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, replay, s);
         else
@@ -182,7 +188,7 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
         // write-back as extra blocks of the chunk's last pipeline step -- readouts only, nothing it reads is written -- grew that
         // step by what the write-back takes alone, leading the grid or not, and every other step by ~2 us: 634 against 635 us for
         // the epoch; a write-back driven by chain records that carry (last chain of the node, table copy, last clock): 30 us.)
-        if (!(plan3 && wplan3_writeback(st, p, Ec, batch, lid, s))) {
+        if (!(dense ? wplan_dense_writeback(st, p, Ec, batch, lid, s) : (plan3 && wplan3_writeback(st, p, Ec, batch, lid, s)))) {
             rc = launch_wwriteback(st, p, Ec, lid, s);
             if (rc) return rc;
         }

@@ -954,6 +954,7 @@ static size_t wplan_extra_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int
     tot += align_up(nc * 4, 256) * 2;                           // inv, rhead
     tot += align_up((size_t)N * 8, 256) + align_up((2 * WIN_MAX_WINDOWS * 8 + WIN_MAX_WINDOWS) * 4, 256) +
            align_up(wplan3_table_bytes(Ec, batch), 256) + align_up(wplan3_blk_bytes(Ec, batch), 256);   // wmask, wcls, wtab, wblk (hashed planner, wplan3.hip)
+    tot += align_up(wplan_dense_bytes(Ec, batch, N, d, L), 256);       // the dense planner's matrices (wplan_dense.hip; 0: not eligible)
     return tot + 256;
 }
 
@@ -1000,6 +1001,10 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
     out->wzero_bytes = (size_t)(p - reinterpret_cast<char*>(out->wmask));      // (+ the chain table's share of wtab: wplan3_build)
     out->wtab = take(wplan3_table_bytes(Ec, batch));
     out->wblk = (uint32_t*)take(wplan3_blk_bytes(Ec, batch));
+    {
+        const size_t db = wplan_dense_bytes(Ec, batch, N, d, L);
+        out->dense = db ? take(db) : nullptr;
+    }
     out->heavy_thr = wplan_heavy_threshold(K, batch, d);
     out->chains = reinterpret_cast<Chain*>(out->base.light);
     out->chains_sparse = reinterpret_cast<Chain*>(out->base.heavy);

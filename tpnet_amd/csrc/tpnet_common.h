@@ -276,6 +276,7 @@ struct WPlan {
     void* wtab;           // the chain table, then the runs' per-batch segments: wplan3_table_bytes(Ec, batch) bytes in all
     size_t wzero_bytes;   // wmask, wcls and wtab are contiguous: what one fill has to zero before a plan
     uint32_t* wblk;       // per-workgroup counts / bases of the hashed planner (wplan3_blk_bytes)
+    void* dense;          // the dense planner's matrices (wplan_dense.hip: wplan_dense_bytes; nullptr: not eligible)
     uint32_t heavy_thr;   // contributions per (node, window) above which a workgroup per column part walks the chain
     int32_t K;            // batches per window
     int64_t Ew;           // edges per full window = K * batch
@@ -297,6 +298,15 @@ size_t wplan3_blk_bytes(int64_t Ec, int64_t batch);
 int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                  const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
                  bool want_readout, bool replay, hipStream_t s);
+// the same plan in ONE launch through a dense (batch x node) matrix of run lengths (wplan_dense.hip), where the table is small
+// against the stream (wplan_dense_eligible: every dataset of the reference); any number of windows up to 256
+bool wplan_dense_eligible(int64_t N, int d, int L, int64_t batch);
+size_t wplan_dense_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int L);          // 0: not eligible
+bool wplan_dense_applies(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, int K);
+int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                      const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
+                      bool want_readout, bool replay, hipStream_t s);
+bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s);
 uint32_t wplan_heavy_threshold(int K, int64_t batch, int d);
 // pipeline step j of a chunk of nw windows: layer i of window j-i+1 (i = 1..L) and the readout of window j-L, whichever
 // exist, in ONE launch; j = 0 .. nw+L-1.

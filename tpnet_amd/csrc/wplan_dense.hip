@@ -1,0 +1,520 @@
+// Plan of a windowed chunk through a DENSE (batch x node) matrix of run lengths (tpnet_common.h: WPlan; consumers: wstep.hip).
+//
+// The hashed planner (wplan3.hip) finds a node's runs through two hash tables: a fill and four kernels, each a handful of
+// dependent probes deep.  Where the table is small against the stream (N * 12 bytes <= half the version-log bytes of one batch:
+// every real dataset of the reference), the runs fit a dense matrix, one row per batch, and everything the pipeline needs
+// becomes a direct lookup -- four launches, no fill, no hash table, any number of windows up to 256:
+//   k_dense_sort   a workgroup per batch sorts the batch's 2B contributions by target in LDS (wplan_common.hpp: the same sort as
+//                  the hashed planner's) and writes the batch's row len[b][n] = contributions to node n in batch b (every
+//                  entry: nothing to zero);
+//   k_dense_win    a thread per (node, window): the node's contributions in the window and its last run there; its chain in the
+//                  window counted and ranked per (chunk of 256 nodes, window, length class);
+//   k_dense_pre    a thread per (node, window): m[b][n] = {contributions of n in batches < b, len, batch of n's previous run}
+//                  for the window's batches; node totals; chains of every (window, class) in the earlier chunks of nodes;
+//   k_dense_place  a thread per contribution: position = first position of n (positions are node-major, a node's contributions
+//                  in batch order: the sorted planner's order) + m[b][n].pre + rank in its run; the version of ANY node before
+//                  batch b is the position base[v] + m[b][v].pre - 1 (the tail of its previous run) or, when pre = 0, the table
+//                  row -- so the partner's version, the node's own previous run, the readout references of src / dst / neg are
+//                  one lookup each; chain heads write their chain record into the window's list.
+// (Built first as ONE persistent launch with grid barriers between the phases -- measured slower: a barrier with its release /
+// acquire of the XCD's L2 cost 4-5 us against ~1.7 us for a kernel boundary, and every phase ran on the sort's few workgroups.)
+// Same WPlan contents as the sorted planner up to the order of the chains inside a length class; the arithmetic of every run is
+// identical, so all three planners give bit-identical results (tests/test_gpu_parity.py::test_three_launch_planner_equals_chunk_planner).
+#include "wplan_common.hpp"
+
+namespace tpnet {
+
+static constexpr int DCH = 256;                     // nodes per chunk = threads per workgroup of every kernel but the sort
+static constexpr int DENSE_MAX_WINDOWS = 256;       // (window, class) counters live in LDS: 8 KB
+static constexpr int DENSE_MAX_CHUNKS = 2048;       // chunks of 256 nodes (a thread per node in phase B): N <= 524 288
+
+struct DView {                 // the dense planner's arrays (WPlan::dense, carved by wplan_carve)
+    uint16_t* len;             // [nb][Ns]
+    uint2* m;                  // [nb][Ns] {pre, len | prevb << 16}; prevb = 0xFFFF: no run before batch b
+    uint32_t* crank;           // [nw][Ns] B1: rank of the chain (n, w) among the chains of its (chunk of nodes, window, class)
+    uint2* wsl;                // [nw][Ns] B1a: {contributions of n in window w, batch of its last run there (0xFFFF: none)}
+    uint32_t* tot;             // [Ns] contributions of node n in the chunk
+    uint32_t* lastb;           // [Ns] batch of its last run (0xFFFF: none)
+    uint32_t* base;            // [Ns] B1: exclusive prefix of tot inside the node's chunk of BS nodes
+    uint32_t* basef;           // [Ns] C: first position of node n (base + the chunk's base): what the write-back and a replay read
+    uint32_t* ctot;            // [nchunks] B1: contributions per chunk of nodes
+    uint32_t* ccnt;            // [nchunks][nw * 8] B1: chains per (chunk, window, class)
+    uint32_t* cpre;            // [nchunks][nw * 8] B2: the same, summed over the earlier chunks
+    uint32_t* ptot;            // [nw * 8] B2: chains per (window, class)
+    int64_t Ns;                // row stride (N rounded up to 64)
+};
+
+static inline int64_t dense_ns(int64_t N) { return (N + 63) / 64 * 64; }
+
+bool wplan_dense_eligible(int64_t N, int d, int L, int64_t batch) {
+    static const int off = TPNET_DEV_INT(NO_PLAN_DENSE, 0);
+    if (off || batch < 1 || batch > PLAN_ONE_MAX || N > (int64_t)DENSE_MAX_CHUNKS * 256) return false;
+    return (int64_t)N * 12 <= batch * (int64_t)L * d * 4;     // half the version-log bytes of one batch
+}
+
+size_t wplan_dense_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int L) {
+    if (!wplan_dense_eligible(N, d, L, batch)) return 0;
+    const size_t nb = (size_t)((Ec + batch - 1) / batch);
+    const size_t Ns = (size_t)dense_ns(N);
+    size_t nw = (nb + 1) / 2 + 1;
+    if (nw > (size_t)DENSE_MAX_WINDOWS) nw = DENSE_MAX_WINDOWS;
+    const size_t nchunks = (Ns + 255) / 256;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    return al(nb * Ns * 2) + al(nb * Ns * 8) + al(nw * Ns * 4) + al(nw * Ns * 8) + 4 * al(Ns * 4) + al(nchunks * 4) +
+           2 * al(nchunks * nw * 8 * 4) + al(nw * 8 * 4) + 256;
+}
+
+static DView dview_of(const WPlan& p, int64_t Ec, int64_t batch, int64_t N) {
+    DView v;
+    const size_t nb = (size_t)((Ec + batch - 1) / batch);
+    const size_t Ns = (size_t)dense_ns(N);
+    size_t nw = (nb + 1) / 2 + 1;
+    if (nw > (size_t)DENSE_MAX_WINDOWS) nw = DENSE_MAX_WINDOWS;
+    const size_t nchunks = (Ns + 255) / 256;
+    char* c = reinterpret_cast<char*>(p.dense);
+    auto take = [&](size_t bytes) { void* r = c; c += (bytes + 255) / 256 * 256; return r; };
+    v.len = (uint16_t*)take(nb * Ns * 2);
+    v.m = (uint2*)take(nb * Ns * 8);
+    v.crank = (uint32_t*)take(nw * Ns * 4);
+    v.wsl = (uint2*)take(nw * Ns * 8);
+    v.tot = (uint32_t*)take(Ns * 4);
+    v.lastb = (uint32_t*)take(Ns * 4);
+    v.base = (uint32_t*)take(Ns * 4);
+    v.basef = (uint32_t*)take(Ns * 4);
+    v.ctot = (uint32_t*)take(nchunks * 4);
+    v.ccnt = (uint32_t*)take(nchunks * nw * 8 * 4);
+    v.cpre = (uint32_t*)take(nchunks * nw * 8 * 4);
+    v.ptot = (uint32_t*)take(nw * 8 * 4);
+    v.Ns = (int64_t)Ns;
+    return v;
+}
+
+// exclusive scan of one value per thread over the workgroup (wave shuffles + one LDS word per wave); total = the sum
+template <int BS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* [BS / 64] */, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();                                        // (wsum may still be read from an earlier scan)
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) {
+        const uint32_t s = wsum[i];
+        if (i < wave) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+struct DVRef { uint32_t ref; double t_src; };
+
+// the version of node v before batch b, given m[b][v] (and, speculatively loaded, base[v] and the node's meta record)
+__device__ __forceinline__ DVRef dense_version(const BatchDesc* __restrict__ desc, uint2 m, uint32_t basev, uint4 m0, uint4 m1) {
+    DVRef r;
+    if (m.x > 0u) {
+        r.ref = basev + m.x - 1u;                           // the tail of its previous run
+        r.t_src = desc[m.y >> 16].t_last;
+    } else {
+        const uint32_t c = m0.x & 1u;
+        r.ref = WREF_TABLE | c;
+        r.t_src = c ? __hiloint2double((int)m1.y, (int)m1.x) : __hiloint2double((int)m0.w, (int)m0.z);
+    }
+    return r;
+}
+
+struct DArgs {
+    const int64_t* src;
+    const int64_t* dst;
+    const int64_t* neg;
+    const double* t;
+    const double* t_prev;
+    const NodeMeta* meta;
+    uint32_t* err;             // tpnet_state::err: [0] bad ids
+    int64_t Ec, Bfull, N, nb, nw;
+    double now_time, lambda;
+    int32_t node_bits, L, nwhich /* 0: no readout, 2: src / dst, 3: + neg */, nchunks;
+};
+
+// phase C, contributions: batch-sorted position x
+__device__ __forceinline__ void dense_place(const WPlan& p, const WTmp& q, const DView& D, const DArgs& a,
+                                            const uint32_t* __restrict__ lstart, const uint32_t* __restrict__ cbase, int64_t x) {
+    const BatchDesc* __restrict__ desc = p.base.desc;
+    const int KW = p.K;
+    const int64_t b = x / (2 * a.Bfull);
+    const int64_t e0b = b * a.Bfull;
+    const int64_t neb = (a.Ec - e0b < a.Bfull) ? (a.Ec - e0b) : a.Bfull;
+    const uint32_t node = q.bkey[x];
+    const int32_t partner = q.bpart[x];
+    const float coef = q.bcoef[x];
+    const uint32_t ri = q.bri[x];
+    const uint32_t fl = q.bflags[x] & WT_STRUCT_MASK;
+    const uint32_t val = q.bval[x];
+    // everything that depends on the ids alone is issued together: one round trip
+    const uint2 mo = D.m[b * D.Ns + node];
+    const uint2 mp = D.m[b * D.Ns + (uint32_t)partner];
+    const uint32_t bo = D.base[node] + cbase[node / (uint32_t)DCH];
+    const uint32_t bp = D.base[(uint32_t)partner] + cbase[(uint32_t)partner / (uint32_t)DCH];
+    const uint4 o0 = reinterpret_cast<const uint4*>(a.meta + node)[0], o1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
+    const uint4 p0 = reinterpret_cast<const uint4*>(a.meta + partner)[0], p1 = reinterpret_cast<const uint4*>(a.meta + partner)[1];
+    const double Tb = desc[b].t_last, Tnow = desc[b].now;
+    const DVRef own = dense_version(desc, mo, bo, o0, o1);
+    const DVRef pr = dense_version(desc, mp, bp, p0, p1);
+    const uint32_t f = bo + mo.x + ri;
+    p.base.s_partner[f] = partner;
+    p.base.s_coef[f] = coef;
+    p.base.s_target[f] = (int32_t)node;
+    p.s_bc[f] = (uint16_t)b;
+    uint32_t out = fl | pr.ref;
+    float dec = 1.0f;
+    if (fl & WREF_RUN_HEAD) {
+        const int64_t w = b / KW;
+        const uint32_t prevb = mo.y >> 16;
+        const bool chain_head = mo.x == 0u || (int64_t)prevb < w * KW;
+        if (chain_head) {
+            float g_first = 1.0f;
+            if (own.ref & WREF_TABLE) g_first = decay3_f32(a.lambda, Tb - own.t_src);
+            else dec = decay3_f32(a.lambda, Tb - own.t_src);    // (a log row's decay comes with the run: s_dec)
+            const int64_t bn = (w + 1) * KW;
+            const uint32_t pre_next = bn < a.nb ? D.m[bn * D.Ns + node].x : D.tot[node];
+            const uint32_t cnt = pre_next - mo.x;
+            const int c = wchain_class(cnt, p.heavy_thr);
+            const uint32_t pair = (uint32_t)w * 8u + (uint32_t)c;
+            const uint32_t chunk = node / (uint32_t)DCH;
+            const uint32_t at = lstart[pair] + D.cpre[(size_t)chunk * (size_t)(a.nw * 8) + pair] + D.crank[w * D.Ns + node];
+            uint4* rec = reinterpret_cast<uint4*>(p.chains + at);
+            rec[0] = make_uint4(f, cnt, node, own.ref);                          // Chain {j0, cnt, target, prev_ref,
+            rec[1] = make_uint4(__float_as_uint(g_first), 0u, 0u, 0u);           //        g_first, pad}
+        } else {
+            dec = decay3_f32(a.lambda, Tb - own.t_src);
+        }
+    }
+    if ((fl & WREF_RUN_TAIL) && D.lastb[node] == (uint32_t)b) out |= WREF_LAST_RUN;
+    p.s_ref[f] = out;
+    p.s_g[f] = decay3_f32(a.lambda, Tb - pr.t_src);
+    p.s_dec[f] = dec;
+    if (a.nwhich >= 2) {
+        const bool side = val >= (uint32_t)neb;
+        const int64_t e = e0b + (side ? (int64_t)val - neb : (int64_t)val);
+        p.e_ref[(side ? a.Ec : 0) + e] = own.ref;
+        p.e_g[(side ? a.Ec : 0) + e] = decay3_f32(a.lambda, Tnow - own.t_src);
+    }
+}
+
+// phase C, negatives: the version of neg[e] before the batch of edge e
+__device__ __forceinline__ void dense_neg(const WPlan& p, const DView& D, const DArgs& a, const uint32_t* __restrict__ basef,
+                                          int64_t e) {
+    const BatchDesc* __restrict__ desc = p.base.desc;
+    int64_t node = a.neg[e];
+    if ((uint64_t)node >= (uint64_t)a.N) node = 0;               // the readout reports the bad id itself
+    const int64_t b = e / a.Bfull;
+    const uint2 m = D.m[b * D.Ns + node];
+    const uint32_t bs = basef[node];
+    const uint4 m0 = reinterpret_cast<const uint4*>(a.meta + node)[0], m1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
+    const DVRef r = dense_version(desc, m, bs, m0, m1);
+    p.e_ref[2 * a.Ec + e] = r.ref;
+    p.e_g[2 * a.Ec + e] = decay3_f32(a.lambda, desc[b].now - r.t_src);
+}
+
+// the same inside phase C: the node's first position = its chunk's base (LDS) + its place in the chunk
+__device__ __forceinline__ void dense_neg_c(const WPlan& p, const DView& D, const DArgs& a, const uint32_t* __restrict__ cbase,
+                                            int64_t e) {
+    const BatchDesc* __restrict__ desc = p.base.desc;
+    int64_t node = a.neg[e];
+    if ((uint64_t)node >= (uint64_t)a.N) node = 0;
+    const int64_t b = e / a.Bfull;
+    const uint2 m = D.m[b * D.Ns + node];
+    const uint32_t bs = D.base[node] + cbase[(uint32_t)node / (uint32_t)DCH];
+    const uint4 m0 = reinterpret_cast<const uint4*>(a.meta + node)[0], m1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
+    const DVRef r = dense_version(desc, m, bs, m0, m1);
+    p.e_ref[2 * a.Ec + e] = r.ref;
+    p.e_g[2 * a.Ec + e] = decay3_f32(a.lambda, desc[b].now - r.t_src);
+}
+
+// ---- A: a workgroup per batch (wplan_common.hpp: wsort_batch): the batch's contributions sorted by target, its row of len
+template <int BS, int IPT>
+__global__ __launch_bounds__(BS) void k_dense_sort(WPlan p, WTmp q, DView D, DArgs a) {
+    __shared__ WSortShared<BS, IPT> sh;
+    const int64_t bb = blockIdx.x;
+    wsort_batch<BS, IPT, true>(sh, q, p.base.desc, a.src, a.dst, a.t, a.Ec, (int32_t)a.Bfull, a.N, a.node_bits, a.now_time,
+                               a.t_prev, a.lambda, a.L, a.err, p.K, bb, D.len + bb * D.Ns);
+}
+
+
+// ---- B1: a workgroup per (chunk of DCH nodes, window), a thread per node: the node's contributions in the window and the
+// batch of its last run there; its chain in the window (that many contributions) ranked among the chunk's chains of the same
+// (window, class) in node order -- ballots inside a wave, the waves' counts through LDS.  (A thread per node that walked its
+// whole column was one dependent round trip per 16 batches with the stores of m in between: 15 us for 20 batches, 57 us for a
+// Wikipedia epoch.)
+__global__ __launch_bounds__(DCH) void k_dense_win(WPlan p, DView D, DArgs a) {
+    __shared__ uint32_t wcnt[(DCH / 64) * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KW = p.K;
+    const int64_t c = blockIdx.x / a.nw, w = blockIdx.x - c * a.nw;
+    const int64_t n = c * DCH + tid;
+    const bool live = n < a.N;
+    const int64_t nld = live ? n : 0;                            // (dead threads load node 0's column and store nothing)
+    const int64_t bw0 = w * KW, bw1 = (bw0 + KW < a.nb) ? bw0 + KW : a.nb;
+    uint32_t sum = 0, last = 0xFFFFu;
+    constexpr int UB = 16;
+    for (int64_t b0 = bw0; b0 < bw1; b0 += UB) {
+        uint32_t l[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int64_t b = (b0 + k < bw1) ? b0 + k : bw1 - 1;          // no branch around a load: rows past the end are clamped
+            l[k] = (uint32_t)D.len[b * D.Ns + nld];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (b0 + k < bw1) {
+                sum += l[k];
+                last = l[k] ? (uint32_t)(b0 + k) : last;
+            }
+        }
+    }
+    if (!live) sum = 0;
+    if (live) D.wsl[w * D.Ns + n] = make_uint2(sum, last);
+    const int cl = sum ? wchain_class(sum, p.heavy_thr) : -1;
+    uint32_t myrank = 0;
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const unsigned long long mk = __ballot(cl == c8);
+        if (cl == c8) myrank = (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave * 8 + c8] = (uint32_t)__popcll(mk);
+    }
+    __syncthreads();
+    if (cl >= 0) {
+        for (int wv = 0; wv < wave; ++wv) myrank += wcnt[wv * 8 + cl];
+        D.crank[w * D.Ns + n] = myrank;
+    }
+    if (tid < 8) {
+        uint32_t tsum = 0;
+        for (int wv = 0; wv < DCH / 64; ++wv) tsum += wcnt[wv * 8 + tid];
+        D.ccnt[(size_t)c * (size_t)(a.nw * 8) + w * 8 + tid] = tsum;
+    }
+}
+
+// ---- B2: the same items: the node's contributions and last run BEFORE the window (from the windows' sums), then m for the
+// window's batches; chains of every class in the earlier chunks of nodes; the chunk's last window: node totals
+__global__ __launch_bounds__(DCH) void k_dense_pre(WPlan p, DView D, DArgs a) {
+    __shared__ uint32_t wsum[DCH / 64];
+    __shared__ uint32_t part[DCH];
+    const int tid = threadIdx.x;
+    const int KW = p.K;
+    const int64_t c = blockIdx.x / a.nw, w = blockIdx.x - c * a.nw;
+    const int64_t n = c * DCH + tid;
+    const bool live = n < a.N;
+    const int64_t nld = live ? n : 0;
+    const int64_t bw0 = w * KW, bw1 = (bw0 + KW < a.nb) ? bw0 + KW : a.nb;
+    const size_t npair = (size_t)(a.nw * 8);
+    constexpr int UB = 16;
+    // chains of (window, class tid % 8) in the chunks before this one: 32 strided partial sums per class, added in LDS
+    {
+        uint32_t ps = 0;
+        for (int64_t cq = tid >> 3; cq < c; cq += DCH / 8) ps += D.ccnt[(size_t)cq * npair + w * 8 + (tid & 7)];
+        part[tid] = ps;
+    }
+    uint32_t run = 0, prevb = 0xFFFFu;
+    for (int64_t w0 = 0; w0 < w; w0 += UB) {
+        uint2 v[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int64_t wq = (w0 + k < w) ? w0 + k : w - 1;
+            v[k] = D.wsl[wq * D.Ns + nld];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            if (w0 + k < w) {
+                run += v[k].x;
+                prevb = v[k].x ? v[k].y : prevb;
+            }
+        }
+    }
+    for (int64_t b0 = bw0; b0 < bw1; b0 += UB) {
+        uint32_t l[UB];
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int64_t b = (b0 + k < bw1) ? b0 + k : bw1 - 1;
+            l[k] = (uint32_t)D.len[b * D.Ns + nld];
+        }
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+            const int64_t b = b0 + k;
+            if (b < bw1) {                                       // (uniform)
+                if (live) D.m[b * D.Ns + n] = make_uint2(run, l[k] | (prevb << 16));
+                run += l[k];
+                prevb = l[k] ? (uint32_t)b : prevb;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 8) {
+        uint32_t before = 0;
+        for (int k = 0; k < DCH / 8; ++k) before += part[k * 8 + tid];
+        D.cpre[(size_t)c * npair + w * 8 + tid] = before;
+        if (c == a.nchunks - 1) D.ptot[w * 8 + tid] = before + D.ccnt[(size_t)c * npair + w * 8 + tid];
+    }
+    if (w == a.nw - 1) {                                         // (uniform) the chunk's last window: node totals
+        if (!live) run = 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<DCH>(run, wsum, total);
+        if (live) { D.tot[n] = run; D.lastb[n] = prevb; D.base[n] = ex; }
+        if (tid == 0) D.ctot[c] = total;
+    }
+}
+
+// ---- C: positions and references.  Every workgroup scans the chunks' totals (first position of every chunk of nodes) and the
+// (window, class) totals (the lists' starts) for itself: <= 2 048 values each
+__global__ __launch_bounds__(DCH) void k_dense_place(WPlan p, WTmp q, DView D, DArgs a) {
+    __shared__ uint32_t wsum[DCH / 64];
+    __shared__ uint32_t cbase[DENSE_MAX_CHUNKS];
+    __shared__ uint32_t lstart[DENSE_MAX_WINDOWS * 8];
+    const int tid = threadIdx.x;
+    const int npair = (int)a.nw * 8;
+    {
+        uint32_t carry = 0;
+        for (int64_t c0 = 0; c0 < a.nchunks; c0 += DCH) {
+            const int64_t c = c0 + tid;
+            const uint32_t v = c < a.nchunks ? D.ctot[c] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<DCH>(v, wsum, tot);
+            if (c < a.nchunks) cbase[c] = carry + ex;
+            carry += tot;
+        }
+        carry = 0;
+        for (int i0 = 0; i0 < npair; i0 += DCH) {
+            const int i = i0 + tid;
+            const uint32_t v = i < npair ? D.ptot[i] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan<DCH>(v, wsum, tot);
+            if (i < npair) lstart[i] = carry + ex;
+            carry += tot;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t w = tid; w < a.nw; w += DCH) {
+            uint32_t t8[8], n = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { t8[k] = D.ptot[w * 8 + k]; n += t8[k]; }
+            WinDesc W;
+            W.start = lstart[w * 8];
+            W.n_heavy = t8[0];
+            W.n_chains = n;
+            W.n_ext = t8[0] + t8[1] + t8[2];
+            W.n_ext1 = t8[0] + t8[1];
+            W.pad0 = W.pad1 = W.pad2 = 0;
+            p.wdesc[w] = W;
+        }
+    }
+    const int64_t gid = (int64_t)blockIdx.x * DCH + tid, gsz = (int64_t)gridDim.x * DCH;
+    for (int64_t n = gid; n < a.N; n += gsz) D.basef[n] = D.base[n] + cbase[n / DCH];   // (for the write-back and a replay)
+    const int64_t nc = 2 * a.Ec;
+    const int64_t items = nc + (a.nwhich == 3 ? a.Ec : 0);
+    for (int64_t x = gid; x < items; x += gsz) {
+        if (x < nc) dense_place(p, q, D, a, lstart, cbase, x);
+        else dense_neg_c(p, D, a, cbase, x - nc);
+    }
+}
+
+// a replayed plan (same stream, same table state): only the negatives change between epochs
+__global__ __launch_bounds__(256) void k_wplan_dense_negs(WPlan p, DView D, DArgs a) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.Ec; e += (int64_t)gridDim.x * blockDim.x)
+        dense_neg(p, D, a, D.basef, e);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// end of a chunk planned here: the last version of every touched node -> the other copy of its table bundle, meta published.
+// One lane group per node: {tot, base, lastb} -> the log row -> the table (three dependent round trips).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wwriteback_dense(tpnet_state S, WPlan p, DView D, uint32_t bid) {
+    constexpr int LANES = 32;
+    const int per = S.L * S.d;
+    const int pv = per / 4;
+    NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
+    const int gl = threadIdx.x % LANES, g = threadIdx.x / LANES;
+    constexpr int GPB = 256 / LANES;
+    for (int64_t n = (int64_t)blockIdx.x * GPB + g; n < S.N; n += (int64_t)gridDim.x * GPB) {
+        const uint32_t tot = D.tot[n];
+        const uint32_t bs = D.basef[n], lb = D.lastb[n];
+        const uint32_t ver = meta[n].ver;
+        if (!tot) continue;
+        const uint32_t pos = bs + tot - 1u;
+        const int c = (int)(ver & 1u);
+        const float4* __restrict__ srow = reinterpret_cast<const float4*>(p.log + (int64_t)pos * per);
+        float4* __restrict__ drow = reinterpret_cast<float4*>(S.q + ((int64_t)(c ^ 1) * S.N + n) * (int64_t)per);
+        for (int x = gl; x < pv; x += LANES) drow[x] = srow[x];
+        if (gl == 0) publish_meta(meta + n, c ^ 1, p.base.desc[lb].t_last, bid);
+    }
+}
+
+bool wplan_dense_applies(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, int K) {
+    if (!p.dense || K < 1 || !wplan_dense_eligible(st.N, st.d, st.L, batch)) return false;
+    const int64_t nb = (Ec + batch - 1) / batch;
+    const int64_t nw = (nb + K - 1) / K;
+    int node_bits = 1;
+    while (node_bits < 63 && (1ll << node_bits) < st.N) ++node_bits;
+    return nw <= DENSE_MAX_WINDOWS && nw <= (nb + 1) / 2 + 1 && nb < 65535 && node_bits <= 31 && 2 * Ec < (int64_t)WREF_SLOT_MASK;
+}
+
+int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
+                      const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
+                      bool want_readout, bool replay, hipStream_t s) {
+    if (!wplan_dense_applies(st, p, Ec, batch, p.K)) return TPNET_ERR_BAD_ARG;
+    const int64_t nb = (Ec + batch - 1) / batch;
+    const WTmp q = wtmp_of(p, (size_t)(2 * Ec));
+    const DView D = dview_of(p, Ec, batch, st.N);
+    DArgs a;
+    a.src = src; a.dst = dst; a.neg = neg; a.t = t; a.t_prev = t_prev_dev;
+    a.meta = reinterpret_cast<const NodeMeta*>(st.meta);
+    a.err = st.err;
+    a.Ec = Ec; a.Bfull = batch; a.N = st.N; a.nb = nb; a.nw = (nb + p.K - 1) / p.K;
+    a.now_time = now_time; a.lambda = lambda;
+    int node_bits = 1;
+    while (node_bits < 31 && (1ll << node_bits) < st.N) ++node_bits;
+    a.node_bits = node_bits;
+    a.L = st.L;
+    a.nwhich = want_readout ? (neg ? 3 : 2) : 0;
+    a.nchunks = (int32_t)((st.N + DCH - 1) / DCH);
+    if (replay) {
+        if (a.nwhich == 3) {
+            int g = (int)((Ec + 255) / 256);
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(k_wplan_dense_negs, dim3(g), dim3(256), 0, s, p, D, a);
+            TPNET_HIP_TRY(hipGetLastError());
+        }
+        return TPNET_OK;
+    }
+#define TPNET_WDENSE(BS_, IPT_) hipLaunchKernelGGL((k_dense_sort<BS_, IPT_>), dim3((unsigned)nb), dim3(BS_), 0, s, p, q, D, a)
+    const int64_t n2 = 2 * batch;
+    if (n2 <= 512) TPNET_WDENSE(256, 2);
+    else if (n2 <= 1024) TPNET_WDENSE(512, 2);
+    else if (n2 <= 2048) TPNET_WDENSE(1024, 2);
+    else TPNET_WDENSE(1024, 4);
+#undef TPNET_WDENSE
+    const unsigned bgrid = (unsigned)((int64_t)a.nchunks * a.nw);
+    hipLaunchKernelGGL(k_dense_win, dim3(bgrid), dim3(DCH), 0, s, p, D, a);
+    hipLaunchKernelGGL(k_dense_pre, dim3(bgrid), dim3(DCH), 0, s, p, D, a);
+    int64_t cgrid = (3 * Ec + DCH - 1) / DCH;
+    if (cgrid > 4096) cgrid = 4096;
+    hipLaunchKernelGGL(k_dense_place, dim3((unsigned)cgrid), dim3(DCH), 0, s, p, q, D, a);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s) {
+    if ((st.L * st.d) % 4 != 0) return false;
+    const DView D = dview_of(p, Ec, batch, st.N);
+    int64_t grid = (st.N + 7) / 8;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(k_wwriteback_dense, dim3((unsigned)grid), dim3(256), 0, s, st, p, D, launch_id);
+    return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace tpnet

@@ -1017,10 +1017,11 @@ class RandomProjectionModule(nn.Module):
         if self.exact:
             flags |= _lib.FLAG_EAGER_DECAY | _lib.FLAG_SEQUENTIAL
         schedule = schedule or self.default_schedule
-        if schedule not in ("auto", "windowed", "batch", "windowed-sorted"):
-            raise ValueError("schedule must be 'auto', 'windowed', 'windowed-sorted' or 'batch'")
+        if schedule not in ("auto", "windowed", "batch", "windowed-sorted", "windowed-hashed"):
+            raise ValueError("schedule must be 'auto', 'windowed', 'windowed-sorted', 'windowed-hashed' or 'batch'")
         flags |= {"auto": 0, "windowed": _lib.FLAG_SCHED_WINDOWED, "batch": _lib.FLAG_SCHED_BATCH,
-                  "windowed-sorted": _lib.FLAG_SCHED_WINDOWED | _lib.FLAG_PLAN_SORTED}[schedule]
+                  "windowed-sorted": _lib.FLAG_SCHED_WINDOWED | _lib.FLAG_PLAN_SORTED,
+                  "windowed-hashed": _lib.FLAG_SCHED_WINDOWED | _lib.FLAG_PLAN_HASHED}[schedule]
         t_out = C.c_double(0.0)
         # a stream that is run again on the same table state (every epoch of train_link_prediction.py:234-253: reset, then the
         # same chronological batches) replays its plan: the tag tells the C side that src / dst / t hold what they held when
