@@ -922,9 +922,19 @@ int wplan_window_batches(int64_t batch, int d, int L) {
 // length).  Measured (tools/short_trace.sh, tools/sweep_c1c5.sh): C2 (d=128) 20 batches in 2 windows: 127 us at 96, 85 us at 32;
 // C1 (d=64, B=200, windows of 64 batches): 198 M edges/s at 96, 281 M at 32; rows of 256 / 512 floats and the 24-batch
 // windows of long C2 streams: 96 (128: -0..10 %).
+bool wplan_medium_chains(int d) {
+    static const int off = TPNET_DEV_INT(NO_MEDIUM, 0);
+    if (off || d % 4 != 0) return false;
+    const Geom g = pick_geom(d);
+    return g.w == 4 && d == g.lpp * g.vpl * 4;
+}
+
 uint32_t wplan_heavy_threshold(int K, int64_t batch, int d) {
     static const int env = TPNET_DEV_INT(WIN_HEAVY, 0);
     if (env > 0) return (uint32_t)env;
+    // chains of WIN_MED_MIN .. 128 contributions get a workgroup each (chain_medium: one segment of 128 positions at d = 128);
+    // beyond that a workgroup per column part
+    if (wplan_medium_chains(d)) return 128u;
     const int64_t t = (int64_t)K * batch * d / 24576;
     return (uint32_t)(t < 16 ? 16 : (t > 96 ? 96 : t));
 }
@@ -1280,7 +1290,11 @@ __global__ void k_gather_chains(WPlan p, const uint32_t* __restrict__ lk, const 
             D.n_chains = (uint32_t)(z - a);
             D.n_ext = D.n_heavy;
             D.n_ext1 = D.n_heavy;
-            D.pad0 = D.pad1 = D.pad2 = 0;
+            {
+                const int64_t m = lb(((uint32_t)w << 8) | (255u - (WIN_MED_MIN - 1u)));     // lengths >= WIN_MED_MIN sort before this key
+                D.n_med = (uint32_t)((m > h ? m : h) - a);
+            }
+            D.pad1 = D.pad2 = 0;
             p.wdesc[w] = D;
         }
         return;

@@ -223,6 +223,14 @@ static constexpr int WIN_MAX_WINDOWS = 64;          // windows per chunk of the 
 static constexpr int WIN_BLOCK = 8;                 // contributions summed on their own before they join the row (fixed
                                                     // association: the result of a run does not depend on who sums it)
 
+static constexpr uint32_t WIN_MED_MIN = 16;         // contributions from which a chain gets a workgroup of its own (two rounds of
+                                                    // WIN_BLOCK rows are what one lane group walks without a tail)
+// length classes 0..wchain_med_classes(thr) hold exactly the chains of >= WIN_MED_MIN contributions (class k >= 1 of wchain_class
+// holds the lengths of bit length bitlen(thr) - k + 1)
+__host__ __device__ inline int wchain_med_classes(uint32_t thr) {
+    const int c = (32 - __builtin_clz(thr | 1u)) - 4;
+    return c < 0 ? 0 : (c > 6 ? 6 : c);       // (class 7 also holds everything shorter)
+}
 // length class of a chain inside its window's list (wplan3.hip): 0 = walked by a workgroup per column part (more than
 // `thr` contributions), then classes of halving length -- a block's chains are alike, the long ones lead
 __host__ __device__ inline int wchain_class(uint32_t cnt, uint32_t thr) {
@@ -238,7 +246,9 @@ struct WinDesc {          // per window: its slice of the chain list (sorted by 
     uint32_t n_ext;       // chains of length classes 0..2 (more than ~thr / 4 contributions): what a step with spare workgroups
                           // walks by workgroups (>= n_heavy; the sorted planner: = n_heavy)
     uint32_t n_ext1;      // chains of length classes 0..1 (more than ~thr / 2)
-    uint32_t pad0, pad1, pad2;
+    uint32_t n_med;       // chains of at least WIN_MED_MIN contributions (>= n_heavy): beyond the heavy ones, each is walked by ONE
+                          // workgroup, its blocks of WIN_BLOCK dealt to the lane groups (wstep.hip: chain_medium)
+    uint32_t pad1, pad2;
 };
 
 struct Chain {            // all contributions of ONE node inside ONE window: sorted positions [j0, j0 + cnt)
@@ -308,6 +318,7 @@ int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src,
                       bool want_readout, bool replay, hipStream_t s);
 bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s);
 uint32_t wplan_heavy_threshold(int K, int64_t batch, int d);
+bool wplan_medium_chains(int d);          // rows that are exactly one chunk of their geometry: chain_medium serves (wstep.hip)
 // pipeline step j of a chunk of nw windows: layer i of window j-i+1 (i = 1..L) and the readout of window j-L, whichever
 // exist, in ONE launch; j = 0 .. nw+L-1.
 int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int64_t j, int64_t Ec, int64_t batch,

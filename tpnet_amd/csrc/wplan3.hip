@@ -349,7 +349,9 @@ __global__ __launch_bounds__(256) void k_wrefs(WPlan p, WTmp q, const int64_t* _
             D.n_chains = n;
             D.n_ext = t8[0] + t8[1] + t8[2];
             D.n_ext1 = t8[0] + t8[1];
-            D.pad0 = D.pad1 = D.pad2 = 0;
+            D.n_med = 0;
+            for (int k = 0; k <= wchain_med_classes(p.heavy_thr); ++k) D.n_med += t8[k];
+            D.pad1 = D.pad2 = 0;
             p.wdesc[wv] = D;
         }
 #pragma unroll

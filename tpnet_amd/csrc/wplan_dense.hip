@@ -409,7 +409,9 @@ __global__ __launch_bounds__(DCH) void k_dense_place(WPlan p, WTmp q, DView D, D
             W.n_chains = n;
             W.n_ext = t8[0] + t8[1] + t8[2];
             W.n_ext1 = t8[0] + t8[1];
-            W.pad0 = W.pad1 = W.pad2 = 0;
+            W.n_med = 0;
+            for (int k = 0; k <= wchain_med_classes(p.heavy_thr); ++k) W.n_med += t8[k];
+            W.pad1 = W.pad2 = 0;
             p.wdesc[w] = W;
         }
     }

@@ -460,6 +460,189 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// a chain walked by ONE workgroup, whole rows: the middle of the length distribution (WIN_MED_MIN contributions up to the heavy
+// threshold).  One lane group walking such a chain is n / 8 dependent rounds of row fetches -- the tail of every pipeline step of
+// a short stream; a workgroup per column part (chain_heavy) is eight workgroups per chain, mostly idle.  Here:
+//   1. a thread per position of a segment (<= SEGP positions, <= BCAP blocks of WIN_BLOCK) resolves its contribution (partner row,
+//      weight, pending decay, structure bits) and parks it in LDS; blocks are numbered by ballots;
+//   2. lane group g owns the blocks whose head falls into positions [PG g, PG (g + 1)): it walks them in order, rows of U
+//      contributions in flight (<= 3 rounds), and leaves every block's sum in LDS;
+//   3. lane group 0 walks the blocks in order: block sums -> run sums -> row = row * decay + run sum, stores every run's result.
+// Same association as chain_light / chain_heavy; rows that are exactly one chunk (FULL) only.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LPP, int VPL, int LWORDS>
+struct MedCfg {
+    static constexpr int GPB = WB / LPP;                     // lane groups per workgroup
+    static constexpr int PG = GPB * 16 <= WB ? 16 : WB / GPB;   // positions per group and segment
+    static constexpr int SEGP = GPB * PG;                    // positions per segment
+    static constexpr int RW = LPP * VPL * 4;                 // floats per row
+    // LDS (32-bit words): per position {row pointer (2), weight, decay^(layer-1), flags, own decay^layer, block}; per block
+    // {flags, decay, log slot}; per group its first position; the block sums
+    static constexpr int O_ROW = 0, O_W = 2 * SEGP, O_GP = 3 * SEGP, O_FL = 4 * SEGP, O_DEC = 5 * SEGP, O_BLK = 6 * SEGP,
+                         O_BFL = 7 * SEGP, BCAP_ = (LWORDS - 7 * SEGP - (GPB + 1) - 16 - 4) / (RW + 3),
+                         BCAP = BCAP_ > SEGP ? SEGP : BCAP_, O_BDEC = O_BFL + BCAP, O_BSLOT = O_BDEC + BCAP,
+                         O_OWN = O_BSLOT + BCAP, O_MISC = O_OWN + GPB + 1, O_SUM = (O_MISC + 16 + 3) / 4 * 4,
+                         WORDS = O_SUM + BCAP * RW;
+    static_assert(WORDS <= LWORDS, "chain_medium: LDS layout");
+    static_assert(BCAP >= 8, "chain_medium: LDS for at least 8 block sums");
+};
+
+template <int LPP, int VPL, int LWORDS>
+__device__ __forceinline__ void chain_medium(const tpnet_state& S, const WPlan& P, const Chain c, int layer,
+                                             uint32_t* __restrict__ lds_u) {
+    using M = MedCfg<LPP, VPL, LWORDS>;
+    constexpr int W = 4, F = VPL * W, U = (F == 4) ? 8 : 4;
+    constexpr int GPB = M::GPB, PG = M::PG, SEGP = M::SEGP, BCAP = M::BCAP, RW = M::RW;
+    static_assert(SEGP <= WB, "a thread per position");
+    const int tid = threadIdx.x, g = tid / LPP, gl = tid % LPP;
+    const int d = S.d, L = S.L;
+    const float** p_row = reinterpret_cast<const float**>(lds_u + M::O_ROW);
+    float* p_w = reinterpret_cast<float*>(lds_u + M::O_W);
+    float* p_gp = reinterpret_cast<float*>(lds_u + M::O_GP);
+    uint32_t* p_fl = lds_u + M::O_FL;
+    float* p_dec = reinterpret_cast<float*>(lds_u + M::O_DEC);
+    uint32_t* p_blk = lds_u + M::O_BLK;
+    uint32_t* b_fl = lds_u + M::O_BFL;                 // bit 0: the block heads a run, bit 1: it ends one
+    float* b_dec = reinterpret_cast<float*>(lds_u + M::O_BDEC);
+    uint32_t* b_slot = lds_u + M::O_BSLOT;             // chunk-relative position of the block's last contribution
+    uint32_t* own = lds_u + M::O_OWN;                  // [GPB + 1] first position a group owns (SEGP: none)
+    uint32_t* misc = lds_u + M::O_MISC;                // [2..5] block heads per wave, [6..9] one past a wave's last kept block tail
+    float* bsum = reinterpret_cast<float*>(lds_u + M::O_SUM);
+
+    float g0;
+    const float* qold = chain_start(S, P, c, layer, g0);
+    const bool from_table = (c.prev_ref & WREF_TABLE) != 0;
+    float acc[F], srun[F];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) ldv<W>(g == 0 ? qold : S.p0, j * LPP + gl, &acc[j * W]);     // (only group 0 walks the chain)
+#pragma unroll
+    for (int x = 0; x < F; ++x) srun[x] = 0.0f;
+    bool firstblk = false;
+    float cur_dec = 1.0f;
+
+    for (uint32_t s0 = 0; s0 < c.cnt;) {
+        __syncthreads();                                   // the previous segment (or unit) is done with the tables
+        // ---- 1. the segment's positions
+        const uint32_t pos = s0 + (uint32_t)tid;
+        const bool in = tid < SEGP && pos < c.cnt;
+        const uint32_t jm = c.j0 + (in ? pos : 0u);
+        const int32_t pv = in ? P.base.s_partner[jm] : 0;
+        const float wgt = in ? P.base.s_coef[jm] : 0.0f;
+        const uint32_t ref = in ? P.s_ref[jm] : 0u;
+        const float glog = in ? P.s_g[jm] : 1.0f;
+        const float decr = in ? P.s_dec[jm] : 1.0f;
+        if (tid <= GPB) own[tid] = SEGP;
+        // blocks are numbered in position order: heads counted by ballot over the segment's waves
+        const bool head = in && (ref & WREF_BLK_HEAD) != 0;
+        const unsigned long long hm = __ballot(head);
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0 && wave < 4) misc[2 + wave] = (uint32_t)__popcll(hm);
+        __syncthreads();
+        uint32_t blk = (uint32_t)__popcll(hm & ((2ull << lane) - 1ull)) - 1u;      // heads at or before this position, minus one
+        for (int wv = 0; wv < wave && wv < 4; ++wv) blk += misc[2 + wv];
+        const bool keep = in && blk < (uint32_t)BCAP;      // (a segment ends after BCAP blocks)
+        if (tid < SEGP) {
+            float gp;
+            const float* row = partner_row(S, P, layer, pv, ref, glog, gp);
+            p_row[tid] = row;
+            p_w[tid] = wgt;
+            p_gp[tid] = gp;
+            p_fl[tid] = keep ? ref : 0u;
+            p_dec[tid] = pow_rep(decr, layer);
+            p_blk[tid] = blk;
+        }
+        if (keep && head) {
+            atomicMin(&own[tid / PG], (uint32_t)tid);
+            b_fl[blk] = (ref & WREF_RUN_HEAD) ? 1u : 0u;
+            b_dec[blk] = (pos == 0u && from_table) ? g0 : pow_rep(decr, layer);
+        }
+        // the segment ends behind the last kept block that is whole (the SEGP positions may cut a block: it opens the next segment)
+        const bool tail = keep && (ref & WREF_BLK_TAIL) != 0;
+        const unsigned long long tm = __ballot(tail);
+        if (lane == 0 && wave < 4) misc[6 + wave] = tm ? (uint32_t)(wave * 64 + 64 - __clzll((long long)tm)) : 0u;
+        __syncthreads();
+        if (tail) {
+            if (ref & WREF_RUN_TAIL) atomicOr(&b_fl[blk], 2u);
+            b_slot[blk] = c.j0 + pos;
+        }
+        uint32_t npos = misc[6];
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) npos = misc[6 + wv] > npos ? misc[6 + wv] : npos;
+        __syncthreads();
+        const uint32_t nblk = p_blk[npos - 1u] + 1u;
+        // ---- 2. block sums: group g walks positions [own[g], first position a later group owns)
+        {
+            uint32_t a0 = own[g], z0 = npos;
+            for (int q = GPB - 1; q > g; --q)             // the first later group that owns a block bounds this group's walk
+                if (own[q] < z0) z0 = own[q];
+            if (a0 >= z0) { a0 = 0; z0 = 0; }
+            float sblk[F];
+#pragma unroll
+            for (int x = 0; x < F; ++x) sblk[x] = 0.0f;
+            for (uint32_t k0 = a0; k0 < z0; k0 += U) {
+                float r[U][F];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t q = k0 + k < z0 ? k0 + k : a0;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) ldv<W>(p_row[q], j * LPP + gl, &r[k][j * W]);
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const uint32_t q = k0 + k;
+                    if (q < z0) {
+                        const float w = p_w[q], gp = p_gp[q];
+                        const uint32_t fl = p_fl[q];
+                        const bool bh = (fl & WREF_BLK_HEAD) != 0;
+#pragma unroll
+                        for (int x = 0; x < F; ++x) {
+                            const float m = (r[k][x] * gp) * w;       // (P[i-1][partner], decayed) * time weight (TPNet.py:91-92)
+                            sblk[x] = bh ? m : sblk[x] + m;           // scatter-add in index order (TPNet.py:93-96)
+                        }
+                        if (fl & WREF_BLK_TAIL) {
+                            float* dst = bsum + (size_t)p_blk[q] * RW;
+#pragma unroll
+                            for (int j = 0; j < VPL; ++j) {
+                                float4 v4 = make_float4(sblk[j * W], sblk[j * W + 1], sblk[j * W + 2], sblk[j * W + 3]);
+                                reinterpret_cast<float4*>(dst)[j * LPP + gl] = v4;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. the chain: blocks in order
+        if (g == 0) {
+            for (uint32_t b = 0; b < nblk; ++b) {
+                const uint32_t bf = b_fl[b];
+                float sb[F];
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const float4 v4 = reinterpret_cast<const float4*>(bsum + (size_t)b * RW)[j * LPP + gl];
+                    sb[j * W] = v4.x; sb[j * W + 1] = v4.y; sb[j * W + 2] = v4.z; sb[j * W + 3] = v4.w;
+                }
+                if (bf & 1u) { firstblk = true; cur_dec = b_dec[b]; }
+#pragma unroll
+                for (int x = 0; x < F; ++x) srun[x] = firstblk ? sb[x] : srun[x] + sb[x];
+                firstblk = false;
+                if (bf & 2u) {
+#pragma unroll
+                    for (int x = 0; x < F; ++x) {
+                        acc[x] *= cur_dec;                   // decay to the run's clock (TPNet.py:83-85)
+                        acc[x] = acc[x] + srun[x];
+                    }
+                    float* lrow = P.log + ((int64_t)b_slot[b] * L + (layer - 1)) * (int64_t)d;
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) stv<W>(lrow, j * LPP + gl, &acc[j * W]);
+                }
+            }
+        }
+        s0 += npos;
+    }
+}
+
 // lanes per column part of a workgroup-walked chain, by the geometry's row chunk (LPP * VPL vectors)
 constexpr int heavy_lph(int lpp, int vpl) { return lpp * vpl <= 32 ? 4 : (lpp * vpl <= 64 ? 8 : 16); }
 
@@ -467,14 +650,20 @@ constexpr int heavy_lph(int lpp, int vpl) { return lpp * vpl <= 32 ? 4 : (lpp * 
 struct WStep {
     int64_t w_upd[TPNET_MAX_LAYERS];   // window of the update of layer i+1 at this step (-1: none)
     int64_t w_read;                    // window whose readouts run at this step (-1: none)
-    uint32_t seg[TPNET_MAX_LAYERS + 3];       // first block of: hub chains[layer 1..L], chains (all layers), readout; then the grid size
+    uint32_t seg[2 * TPNET_MAX_LAYERS + 3];   // first block of: hub chains[layer 1..L], medium chains[layer 1..L], chains (all layers), readout; then the grid size
     int32_t CP;                        // column parts of a workgroup-walked chain
     int32_t dbg_layer;                 // diagnostic builds: the layer whose units are stamped (0: none)
     int32_t dbg_skip;                  // timing experiments: 1 = no hub chains, 2 = no chains, 4 = no readout
     uint32_t n_active;                 // layers that have a window at this step
     uint32_t hub_ext;                  // 2 / 1: this step walks the chains of length classes 1..2 / of class 1 by workgroups too ...
     uint32_t hub_blocks;               // ... where they fit ONE round of the layer's hub workgroups
+    uint32_t med;                      // 1: chains of >= WIN_MED_MIN contributions up to the heavy threshold get a workgroup each (chain_medium)
 };
+
+// chains of a window that are NOT walked by one lane group each: the hubs, and the medium ones where chain_medium serves
+__device__ __forceinline__ uint32_t big_chains(const WStep& st, const WinDesc& wd, uint32_t n_hub) {
+    return (st.med && wd.n_med > n_hub) ? wd.n_med : n_hub;
+}
 
 // the chains of a window this step walks by workgroups: the heavy ones, and -- in a step with workgroups to spare -- the next one
 // or two length classes, as long as ONE round of the layer's hub workgroups takes them (a second round costs more than the lane
@@ -504,29 +693,30 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
     constexpr bool LR = false;
     constexpr int RWORDS = (RLPP < 16) ? C::NG * (WB / RLPP) : 1;
     constexpr int LWORDS = HeavyCfg<LPH>::WORDS > RWORDS ? HeavyCfg<LPH>::WORDS : RWORDS;
+    constexpr int SL = 2 * L;                                   // index of the lane-group chains' range
     __shared__ __attribute__((aligned(16))) uint32_t lds_u[LWORDS];
     const int gl = threadIdx.x % LPP;
     const int g = threadIdx.x / LPP;
     constexpr int GPB = WB / LPP;
     const uint32_t bx = blockIdx.x;
     // which range is this block in (compares against every bound: no dynamic indexing of the kernel arguments).
-    // Ranges: 0..L-1 hub chains of layer 1..L; L: the chains of all active layers, interleaved block by block (chain lists are
-    // sorted longest first: every layer's long chains start early); L+1: readout
+    // Ranges: 0..L-1 hub chains of layer 1..L; L..2L-1 medium chains of layer 1..L; 2L: the other chains of all active layers,
+    // interleaved block by block (chain lists are sorted longest first: every layer's long chains start early); 2L+1: readout
     int sidx = 0;
     uint32_t seg_lo = 0, seg_hi = st.seg[1];
     int64_t w = st.w_upd[0];
 #pragma unroll
-    for (int i = 1; i <= L + 1; ++i) {
+    for (int i = 1; i <= SL + 1; ++i) {
         if (bx >= st.seg[i]) {
             sidx = i;
             seg_lo = st.seg[i];
             seg_hi = st.seg[i + 1];
-            w = (i < L) ? st.w_upd[i] : st.w_read;
+            w = (i < L) ? st.w_upd[i] : (i < SL) ? st.w_upd[i - L] : st.w_read;
         }
     }
     uint32_t rb_ = bx - seg_lo, nblk_ = seg_hi - seg_lo;
-    int layer = sidx + 1;
-    if (sidx == L) {                                           // interleaved chains: block k -> the (k % nact)-th active layer
+    int layer = (sidx >= L && sidx < SL) ? sidx - L + 1 : sidx + 1;
+    if (sidx == SL) {                                          // interleaved chains: block k -> the (k % nact)-th active layer
         const uint32_t nact = st.n_active;
         const uint32_t r = rb_ % nact;
         rb_ = rb_ / nact;
@@ -545,13 +735,13 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
 #ifdef TPNET_STAMPS
     // diagnostic build: wall-clock start / end of every block of the stamped step (second half of the stamp buffer)
     unsigned long long* bst = (st.dbg_layer == -1 && P.base.dbg && bx < 16000) ? P.base.dbg + 65536 + (size_t)bx * 4 : nullptr;
-    if (bst && threadIdx.x == 0) { bst[0] = __builtin_amdgcn_s_memrealtime(); bst[2] = (unsigned long long)(sidx == L ? L + layer - 1 : (sidx > L ? 2 * L : sidx)); }
+    if (bst && threadIdx.x == 0) { bst[0] = __builtin_amdgcn_s_memrealtime(); bst[2] = (unsigned long long)(sidx == SL ? L + layer - 1 : (sidx > SL ? 2 * L : (sidx >= L ? 2 * L + 1 + sidx - L : sidx))); }
 #define BEND() do { if (bst) { __syncthreads(); if (threadIdx.x == 0) bst[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define BEND() do { } while (0)
 #endif
 
-    if (sidx == L + 1) {
+    if (sidx == SL + 1) {
 #ifdef TPNET_DEV
         if (st.dbg_skip & 4) return;
 #endif
@@ -625,10 +815,21 @@ __global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, W
         BEND();
         return;
     }
+    if (sidx < SL) {
+        // ---- medium chains of one layer: a workgroup each
+        if constexpr (FULL) {
+            const uint32_t n_hub = hub_chains(st, wd);
+            const uint32_t n_big = big_chains(st, wd, n_hub);
+            const Chain* __restrict__ list = P.chains + wd.start;
+            for (uint32_t m = n_hub + rb; m < n_big; m += nblk) chain_medium<LPP, VPL, LWORDS>(S, P, list[m], layer, lds_u);
+        }
+        BEND();
+        return;
+    }
 #ifdef TPNET_DEV
     if (st.dbg_skip & 2) return;
 #endif
-    const uint32_t n_hub = hub_chains(st, wd);
+    const uint32_t n_hub = big_chains(st, wd, hub_chains(st, wd));
     const Chain* __restrict__ small = P.chains + wd.start + n_hub;        // the others, longest first: a block's chains are alike
     const int64_t n_small = (int64_t)wd.n_chains - (int64_t)n_hub;
     for (int64_t base = (int64_t)rb * GPB; base < n_small; base += (int64_t)nblk * GPB) {
@@ -744,8 +945,9 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     const bool reads = have_readout && j - L >= 0 && j - L < nw;
     // (measured, C2: the first step 38 -> 30 us at 24 batches per window, 28 -> 19 at 15, 21 -> 18 at 10; the last update step beside
     // the readouts 44 -> 41, 31 -> 24, but 24 -> 27 at 10 batches per window; two update layers sharing the step: 41 -> 49, not taken)
-    ws.hub_ext = (ext_env >= 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 2u : 0u;
-    if (ext_env >= 2 && n_upd == 2 && !reads && p.K >= 14) ws.hub_ext = 1u;      // (two layers: the longest class only, 42 -> 33 us;
+    const bool med_on = wplan_medium_chains(st.d);             // (the medium chains have workgroups of their own then)
+    ws.hub_ext = (!med_on && ext_env >= 1 && n_upd == 1 && (!reads || p.K >= 14)) ? 2u : 0u;
+    if (!med_on && ext_env >= 2 && n_upd == 2 && !reads && p.K >= 14) ws.hub_ext = 1u;      // (two layers: the longest class only, 42 -> 33 us;
                                                                                  // in the full steps the same costs 55 -> 60 us: not taken)
     // (steps with three update layers, or two beside the readouts: no change with the longest class on workgroups -- measured)
     const uint32_t hub_blocks = ws.hub_ext ? (uint32_t)(hb_env > 0 ? hb_env : 384) * (uint32_t)L / (uint32_t)n_upd
@@ -760,7 +962,14 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
             nb += hub_blocks;   // (four-law sweeps, tools/degree_sensitivity.py: 128 -> 256 -> 384, each step -5..-7 % on streams with heavy hubs, nothing lost elsewhere)
         }
     }
-    ws.seg[L] = nb;
+    // then the medium chains: a workgroup each (a window of 10 C2 batches has ~110 of them, one of 24 batches ~400)
+    static const int mb_env = TPNET_DEV_INT(WIN_MB, 0);
+    ws.med = wplan_medium_chains(st.d) ? 1u : 0u;
+    for (int i = 0; i < L; ++i) {
+        ws.seg[L + i] = nb;
+        if (ws.med && ws.w_upd[i] >= 0) nb += (uint32_t)(mb_env > 0 ? mb_env : 384);
+    }
+    ws.seg[2 * L] = nb;
     {
         uint32_t nact = 0, per = 0;
         for (int i = 0; i < L; ++i) {
@@ -776,7 +985,7 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
         ws.n_active = nact ? nact : 1;
         nb += nact * per;
     }
-    ws.seg[L + 1] = nb;
+    ws.seg[2 * L + 1] = nb;
     ws.w_read = -1;
     {
         const int64_t w = j - L;
@@ -786,7 +995,7 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
             nb += (uint32_t)grid_for(npairs, rsplit ? WB / 16 : GPB, 256 * 8);
         }
     }
-    ws.seg[L + 2] = nb;
+    ws.seg[2 * L + 2] = nb;
     if (nb == 0) return TPNET_OK;
     TPNET_DISPATCH_G(geo, ({
         if constexpr (W == 4) {
