@@ -302,7 +302,8 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
     const bool from_table = (c.prev_ref & WREF_TABLE) != 0;
     float acc[4];
     ldv_pred<4>(qold, vi, g == 0 && vok, acc);
-    uint32_t next_run = 0;                  // rank of the first run the chain walk has not applied yet
+    uint32_t next_run = 0;                  // rank of the first run the chain walk has not applied yet (wave 0)
+    uint32_t next_run_all = 0;              // the same, known to every thread (through LDS)
 
     for (uint32_t T0 = 0; T0 < T; T0 += TSEG) {
         const uint32_t Tend = (T0 + TSEG < T) ? T0 + TSEG : T;
@@ -415,18 +416,21 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
         }
         __syncthreads();
         STAMP(3);
-        // ---- 5. the chain: runs whose last task is in, in order (rank-indexed tables: no dependent LDS reads)
+        // ---- 5. the chain: runs whose last task is in, in order.  Group 0 walks them in LDS (row = row * decay + run sum, left in
+        // the run's slot of r_sum); then EVERY group stores results -- one store instruction per wave for up to 64 runs, where the
+        // walking group's own stores were one instruction per run, each queued behind the CU's row gathers (3.8 of a hub's 10 us)
+        uint32_t last = next_run;
+        if (tid < 64) {
+            const bool dn = (uint32_t)tid >= next_run && (uint32_t)tid < R && r_toff[tid + 1] <= Tend;   // (a prefix of the runs left)
+            last = next_run + (uint32_t)__popcll(__ballot(dn));
+        }
         if (g == 0) {
-            uint32_t last = next_run;
-            while (last < R && r_toff[last + 1] <= Tend) ++last;
             for (uint32_t r0 = next_run; r0 < last; r0 += 4) {
                 float dec[4], rs[4][4];
-                uint32_t slot[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t rr = (r0 + q < last) ? r0 + q : last - 1;
                     dec[q] = (rr == 0 && from_table) ? g0 : r_decp[rr];
-                    slot[q] = r_slot[rr];
                     const float* rs_ = r_sum + (size_t)rr * PW + gl * 4;
 #pragma unroll
                     for (int x = 0; x < 4; ++x) rs[q][x] = rs_[x];
@@ -440,15 +444,30 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
                             acc[x] *= dec[q];                    // decay to the run's clock (TPNet.py:83-85)
                             acc[x] = acc[x] + rs[q][x];
                         }
-                        if (vok) {
-                            float* lrow = P.log + ((int64_t)slot[q] * L + (layer - 1)) * (int64_t)d;
-                            stv<4>(lrow, vi, acc);
-                        }
+                        float* rs_ = r_sum + (size_t)rr * PW + gl * 4;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) rs_[x] = acc[x];
                     }
                 }
             }
-            next_run = last;
+            if (tid == 0) nrun_p[1] = last;
         }
+        __syncthreads();
+        {
+            const uint32_t lastb_ = nrun_p[1];
+            for (uint32_t rr = next_run_all + (uint32_t)g; rr < lastb_; rr += G) {
+                float v[4];
+                const float* rs_ = r_sum + (size_t)rr * PW + gl * 4;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = rs_[x];
+                if (vok) {
+                    float* lrow = P.log + ((int64_t)r_slot[rr] * L + (layer - 1)) * (int64_t)d;
+                    stv<4>(lrow, vi, v);
+                }
+            }
+            next_run_all = lastb_;
+        }
+        if (tid < 64) next_run = last;
         __syncthreads();
     }
     STAMP(4);
@@ -493,7 +512,7 @@ __device__ __forceinline__ void chain_medium(const tpnet_state& S, const WPlan& 
                                              uint32_t* __restrict__ lds_u) {
     using M = MedCfg<LPP, VPL, LWORDS>;
     constexpr int W = 4, F = VPL * W, U = (F == 4) ? 8 : 4;
-    constexpr int GPB = M::GPB, PG = M::PG, SEGP = M::SEGP, BCAP = M::BCAP, RW = M::RW;
+    constexpr int GPB = M::GPB, SEGP = M::SEGP, BCAP = M::BCAP, RW = M::RW;
     static_assert(SEGP <= WB, "a thread per position");
     const int tid = threadIdx.x, g = tid / LPP, gl = tid % LPP;
     const int d = S.d, L = S.L;
@@ -524,6 +543,10 @@ __device__ __forceinline__ void chain_medium(const tpnet_state& S, const WPlan& 
     for (uint32_t s0 = 0; s0 < c.cnt;) {
         __syncthreads();                                   // the previous segment (or unit) is done with the tables
         // ---- 1. the segment's positions
+        // (positions per group: the segment spread over all groups -- a chain of 24 contributions is 8 groups x 3 positions, one round
+        // of row loads, not two groups x 16)
+        const uint32_t left = c.cnt - s0 < (uint32_t)SEGP ? c.cnt - s0 : (uint32_t)SEGP;
+        const uint32_t pg = (left + GPB - 1) / GPB < 2u ? 2u : (left + GPB - 1) / GPB;
         const uint32_t pos = s0 + (uint32_t)tid;
         const bool in = tid < SEGP && pos < c.cnt;
         const uint32_t jm = c.j0 + (in ? pos : 0u);
@@ -553,7 +576,7 @@ __device__ __forceinline__ void chain_medium(const tpnet_state& S, const WPlan& 
             p_blk[tid] = blk;
         }
         if (keep && head) {
-            atomicMin(&own[tid / PG], (uint32_t)tid);
+            atomicMin(&own[(uint32_t)tid / pg], (uint32_t)tid);
             b_fl[blk] = (ref & WREF_RUN_HEAD) ? 1u : 0u;
             b_dec[blk] = (pos == 0u && from_table) ? g0 : pow_rep(decr, layer);
         }
@@ -613,14 +636,16 @@ __device__ __forceinline__ void chain_medium(const tpnet_state& S, const WPlan& 
             }
         }
         __syncthreads();
-        // ---- 3. the chain: blocks in order
+        // ---- 3. the chain: blocks in order, in LDS (a run's result replaces its last block's sum); then every group stores rows --
+        // the walking group's own stores would be one instruction per run, each queued behind the CU's row gathers
         if (g == 0) {
             for (uint32_t b = 0; b < nblk; ++b) {
                 const uint32_t bf = b_fl[b];
                 float sb[F];
+                float4* slot = reinterpret_cast<float4*>(bsum + (size_t)b * RW);
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
-                    const float4 v4 = reinterpret_cast<const float4*>(bsum + (size_t)b * RW)[j * LPP + gl];
+                    const float4 v4 = slot[j * LPP + gl];
                     sb[j * W] = v4.x; sb[j * W + 1] = v4.y; sb[j * W + 2] = v4.z; sb[j * W + 3] = v4.w;
                 }
                 if (bf & 1u) { firstblk = true; cur_dec = b_dec[b]; }
@@ -633,9 +658,22 @@ __device__ __forceinline__ void chain_medium(const tpnet_state& S, const WPlan& 
                         acc[x] *= cur_dec;                   // decay to the run's clock (TPNet.py:83-85)
                         acc[x] = acc[x] + srun[x];
                     }
-                    float* lrow = P.log + ((int64_t)b_slot[b] * L + (layer - 1)) * (int64_t)d;
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) stv<W>(lrow, j * LPP + gl, &acc[j * W]);
+                    for (int j = 0; j < VPL; ++j)
+                        slot[j * LPP + gl] = make_float4(acc[j * W], acc[j * W + 1], acc[j * W + 2], acc[j * W + 3]);
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t b = (uint32_t)g; b < nblk; b += GPB) {
+            if (b_fl[b] & 2u) {
+                const float4* slot = reinterpret_cast<const float4*>(bsum + (size_t)b * RW);
+                float* lrow = P.log + ((int64_t)b_slot[b] * L + (layer - 1)) * (int64_t)d;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    const float4 v4 = slot[j * LPP + gl];
+                    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                    stv<W>(lrow, j * LPP + gl, v);
                 }
             }
         }
@@ -657,12 +695,14 @@ struct WStep {
     uint32_t n_active;                 // layers that have a window at this step
     uint32_t hub_ext;                  // 2 / 1: this step walks the chains of length classes 1..2 / of class 1 by workgroups too ...
     uint32_t hub_blocks;               // ... where they fit ONE round of the layer's hub workgroups
-    uint32_t med;                      // 1: chains of >= WIN_MED_MIN contributions up to the heavy threshold get a workgroup each (chain_medium)
+    uint32_t med;                      // chains below the heavy threshold that get a workgroup each (chain_medium): 0 none, 1 / 2 / 3 =
+                                       // from about half / a quarter of the threshold / from WIN_MED_MIN contributions
 };
 
 // chains of a window that are NOT walked by one lane group each: the hubs, and the medium ones where chain_medium serves
 __device__ __forceinline__ uint32_t big_chains(const WStep& st, const WinDesc& wd, uint32_t n_hub) {
-    return (st.med && wd.n_med > n_hub) ? wd.n_med : n_hub;
+    const uint32_t n = st.med == 3u ? wd.n_med : st.med == 2u ? wd.n_ext : st.med == 1u ? wd.n_ext1 : 0u;
+    return n > n_hub ? n : n_hub;
 }
 
 // the chains of a window this step walks by workgroups: the heavy ones, and -- in a step with workgroups to spare -- the next one
@@ -964,7 +1004,11 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     }
     // then the medium chains: a workgroup each (a window of 10 C2 batches has ~110 of them, one of 24 batches ~400)
     static const int mb_env = TPNET_DEV_INT(WIN_MB, 0);
-    ws.med = wplan_medium_chains(st.d) ? 1u : 0u;
+    // (a step that carries every role is bound by throughput, not by its longest units: there a workgroup per chain of 16..31
+    // contributions holds a slot of the CU with most of its lanes idle)
+    static const int med_full = TPNET_DEV_INT(WIN_MED_FULL, 2);   // (C2 epoch 513 -> 498 us, 400 batches 1 203 -> 1 129 us against level 3; levels 0 / 1: 525 / 1 226)
+    static const int med_part = TPNET_DEV_INT(WIN_MED_PART, 3);
+    ws.med = wplan_medium_chains(st.d) ? (uint32_t)((n_upd == L && reads) ? med_full : med_part) : 0u;
     for (int i = 0; i < L; ++i) {
         ws.seg[L + i] = nb;
         if (ws.med && ws.w_upd[i] >= 0) nb += (uint32_t)(mb_env > 0 ? mb_env : 384);
