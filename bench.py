@@ -312,6 +312,8 @@ def main():
         torch.cuda.synchronize()
 
 
+    warm_windowed = False
+
     def time_leg(run, k_steps, prep=None):
         """W untimed steps, then exactly k_steps timed ones between barrier + synchronize; max over ranks.  `prep(a, b)` (optional)
         builds a call's ARGUMENTS -- tensor views of the resident stream, the last timestamp as a float -- and runs before the
@@ -320,7 +322,9 @@ def main():
             # the W warm-up steps as up to FOUR calls: the first calls of a process pay one-time costs (lazy kernel loading,
             # allocator and stream set-up in the runtime, cold host caches) that a single short call does not absorb
             # (tools/sync_latency.py, 20 steps at C2: call 3 of a process 181-199 us, call 4 180-187, call 5 175-177, steady 172-175)
-            ncall = min(W, 4)
+            # (where the timed steps take the windowed pipeline, every warm-up call must be long enough to take it too -- at least
+            # four batches -- or the pipeline's kernels are first launched, i.e. loaded, inside the timed region: 2.5 ms instead of 0.15)
+            ncall = min(W, 4) if not warm_windowed else max(1, min(4, W // 4))
             cuts = [W * i // ncall for i in range(ncall + 1)]
             for a_, b_ in zip(cuts[:-1], cuts[1:]):
                 run(a_, b_)
@@ -376,6 +380,7 @@ def main():
 
     rp = None
     out_pos = out_neg = None
+    regions = []
     if shard == "single":
         rp = make_full_module()
         NG = rp.pair_wise_feature_dim
@@ -391,10 +396,11 @@ def main():
         gc.collect()
         gc.disable()                              # (no collector pause inside the timed region; re-enabled behind it)
 
-        # the warm-up steps run the schedule the timed steps will run ("auto" picks the windowed pipeline from 24 batches of
+        # the warm-up steps run the schedule the timed steps will run ("auto" picks the windowed pipeline from 16 batches of
         # <= 2048 edges, 56 larger ones; a warm-up call shorter than that would otherwise leave the pipeline's kernels to be
         # loaded inside the timed region: HIP resolves every kernel at its first launch, ~0.3 ms each)
-        timed_windowed = d % 4 == 0 and ((K >= 24 and Bg <= 2048) or (K >= 56 and Bg <= 4096))
+        timed_windowed = d % 4 == 0 and ((K >= 16 and Bg <= 2048) or (K >= 56 and Bg <= 4096))
+        warm_windowed = timed_windowed
 
         def prep(a, b_):
             sl_ = slice(a * Bg, b_ * Bg)
@@ -404,8 +410,18 @@ def main():
 
         def run(a, b_, pre=None):
             s_, d_, n_, t_, op_, on_, te_, sched = pre if pre is not None else prep(a, b_)
-            rp.run_stream(s_, d_, n_, t_, Bg, out_pos=op_, out_neg=on_, t_end=te_, schedule=sched)
-        elapsed = time_leg(run, K, prep)
+            rp.run_stream(s_, d_, n_, t_, Bg, out_pos=op_, out_neg=on_, t_end=te_, schedule=sched, replay=False)
+        # a short timed region (the driver's 20 steps are ~150 us) is ONE sample of a quantity that scatters by 10-20 % with the
+        # state the process and the GPU's clocks are in: up to 64 steps the region is measured three times in this process -- each
+        # time from a reset table: W warm-up steps, then the K timed steps -- and `value` is the median; the first region's number
+        # stays beside it (`first_region`)
+        n_regions = 3 if K <= 64 else 1
+        regions = []
+        for r_ in range(n_regions):
+            if r_ > 0:
+                rp.reset_random_projections()
+            regions.append(time_leg(run, K, prep))
+        elapsed = float(np.median(regions))
         gc.enable()
         rp.check_device_errors()
     elif shard == "cols":
@@ -438,6 +454,9 @@ def main():
             line["config"]["table_bytes_per_gpu"] = row_bytes
         if dropin is not None:
             line["dropin"] = dropin
+        if shard == "single" and len(regions) > 1:
+            line["timed_regions"] = {"n": len(regions), "value_is": "median", "wall_us": [r_ * 1e6 for r_ in regions],
+                                     "first_region": {"value": K * Bg / regions[0], "ms_per_step": regions[0] * 1e3 / K}}
         if extra:
             line.update(extra)
         print(json.dumps(line), flush=True)
@@ -469,7 +488,7 @@ def main():
 
     # kernel-level timing for the roofline object: HIP events on the stream the kernels run on (C side, tpnet_time_stream)
     # around the loop of launches of the dominant kernel, in an extra pass over the SAME batches [W, W + K) as the timed
-    # region -- so `roofline` describes the kernel `value` was produced by (k_step below 24 batches, k_wpipe from there).
+    # region -- so `roofline` describes the kernel `value` was produced by (k_step below 16 batches, k_wpipe from there).
     roof = None
     extra = {}
 

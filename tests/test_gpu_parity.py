@@ -1059,13 +1059,14 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     np.testing.assert_array_equal(e4[2], c1[2])
 
 
-@pytest.mark.parametrize("nb", [23, 24, 60])
-def test_auto_schedule_on_both_sides_of_its_threshold(nb):
-    """The shipped default ("auto") takes the per-batch kernels below 24 batches and the windowed pipeline from there
+@pytest.mark.parametrize("nb,d,N,B", [(15, 64, 500, 100), (16, 64, 500, 100), (60, 64, 500, 100),
+                                      (20, 128, 9228, 1000)])     # (the driver's timed shape: C2, 20 batches)
+def test_auto_schedule_on_both_sides_of_its_threshold(nb, d, N, B):
+    """The shipped default ("auto") takes the per-batch kernels below 16 batches and the windowed pipeline from there
     (tpnet_amd/csrc/api.hip, window_chunk): both sides against the oracle, and the choice itself (a windowed run leaves a
     plan that the next epoch replays; a per-batch run does not)."""
     _need_gpu()
-    d, L, N, B, lam = 64, 3, 500, 100, 2e-6
+    L, lam = 3, 2e-6
     rng = np.random.RandomState(nb)
     E = nb * B
     src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
@@ -1085,7 +1086,7 @@ def test_auto_schedule_on_both_sides_of_its_threshold(nb):
     rp.reset_random_projections()
     rp.random_projections[0].data.copy_(torch.from_numpy(P0))
     rp.run_stream(ds, dd, dn, dt, B, schedule="auto")
-    assert rp.last_stream_replayed == (nb >= 24)
+    assert rp.last_stream_replayed == (nb >= 16)
 
 
 def test_multi_chunk_packed_rows_with_odd_row_length():

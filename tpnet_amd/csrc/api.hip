@@ -50,11 +50,12 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL | TPNET_FLAG_SCHED_BATCH)) return 0;
     const int K = wplan_window_batches(batch, st.d, st.L);
     const int64_t nb = (E + batch - 1) / batch;
-    // short streams: with the three-launch planner (wplan3.hip; batches of <= 2 048 edges) the pipeline pays ~70 us of planning
-    // and L + 1 dependent launches up front, the per-batch schedule ~20 us and ~6.6 us per batch (C2): the pipeline wins from
-    // 24 batches (tools/short_sweep.py, end of round 3: 20 batches 186 against 170 us, 24: 194 against 196, 28: 202 against 221,
-    // 40: 236 against 295).  Larger batches keep the chunk planner's crossover (two device-wide sorts).
-    static const int min_nb3 = TPNET_DEV_INT(WIN_MIN_BATCHES, 24);
+    // short streams: the pipeline pays its plan (~31 us for 20 C2 batches with the dense planner, wplan_dense.hip) and L + 1 dependent
+    // launches up front, the per-batch schedule ~20 us and ~6.6 us per batch (C2): the pipeline wins from 16 batches
+    // (tools/short_sweep.py, round 4: 14 batches 138 against 134 us, 16: 135 against 145, 20: 143-158 against 173-179, 24: 157 against
+    // 198; until round 4, with the hashed planner and lane-group walks of chains up to 52 contributions: from 24).  Larger batches keep
+    // the chunk planner's crossover (two device-wide sorts).
+    static const int min_nb3 = TPNET_DEV_INT(WIN_MIN_BATCHES, 16);
     const int min_nb = batch <= PLAN_ONE_MAX ? min_nb3 : 56;
     if (K == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
     *K_out = K;

@@ -26,6 +26,7 @@ namespace tpnet {
 
 static constexpr int DCH = 256;                     // nodes per chunk = threads per workgroup of every kernel but the sort
 static constexpr int DENSE_MAX_WINDOWS = 256;       // (window, class) counters live in LDS: 8 KB
+static constexpr int DENSE_TL = 512;
 static constexpr int DENSE_MAX_CHUNKS = 2048;       // chunks of 256 nodes (a thread per node in phase B): N <= 524 288
 
 struct DView {                 // the dense planner's arrays (WPlan::dense, carved by wplan_carve)
@@ -116,11 +117,13 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /
 struct DVRef { uint32_t ref; double t_src; };
 
 // the version of node v before batch b, given m[b][v] (and, speculatively loaded, base[v] and the node's meta record)
-__device__ __forceinline__ DVRef dense_version(const BatchDesc* __restrict__ desc, uint2 m, uint32_t basev, uint4 m0, uint4 m1) {
+// (tl: the batches' closing clocks staged in LDS by the caller's workgroup, or nullptr -> read from the descriptors)
+__device__ __forceinline__ DVRef dense_version(const BatchDesc* __restrict__ desc, const double* tl, uint2 m, uint32_t basev,
+                                               uint4 m0, uint4 m1) {
     DVRef r;
     if (m.x > 0u) {
         r.ref = basev + m.x - 1u;                           // the tail of its previous run
-        r.t_src = desc[m.y >> 16].t_last;
+        r.t_src = tl ? tl[m.y >> 16] : desc[m.y >> 16].t_last;
     } else {
         const uint32_t c = m0.x & 1u;
         r.ref = WREF_TABLE | c;
@@ -144,7 +147,8 @@ struct DArgs {
 
 // phase C, contributions: batch-sorted position x
 __device__ __forceinline__ void dense_place(const WPlan& p, const WTmp& q, const DView& D, const DArgs& a,
-                                            const uint32_t* __restrict__ lstart, const uint32_t* __restrict__ cbase, int64_t x) {
+                                            const uint32_t* __restrict__ lstart, const uint32_t* __restrict__ cbase,
+                                            const double* tl, int64_t x) {
     const BatchDesc* __restrict__ desc = p.base.desc;
     const int KW = p.K;
     const int64_t b = x / (2 * a.Bfull);
@@ -159,13 +163,14 @@ __device__ __forceinline__ void dense_place(const WPlan& p, const WTmp& q, const
     // everything that depends on the ids alone is issued together: one round trip
     const uint2 mo = D.m[b * D.Ns + node];
     const uint2 mp = D.m[b * D.Ns + (uint32_t)partner];
+    const uint2 wsl_own = (fl & WREF_RUN_HEAD) ? D.wsl[(b / KW) * D.Ns + node] : make_uint2(0u, 0u);   // (chain heads: the chain's length)
     const uint32_t bo = D.base[node] + cbase[node / (uint32_t)DCH];
     const uint32_t bp = D.base[(uint32_t)partner] + cbase[(uint32_t)partner / (uint32_t)DCH];
     const uint4 o0 = reinterpret_cast<const uint4*>(a.meta + node)[0], o1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
     const uint4 p0 = reinterpret_cast<const uint4*>(a.meta + partner)[0], p1 = reinterpret_cast<const uint4*>(a.meta + partner)[1];
     const double Tb = desc[b].t_last, Tnow = desc[b].now;
-    const DVRef own = dense_version(desc, mo, bo, o0, o1);
-    const DVRef pr = dense_version(desc, mp, bp, p0, p1);
+    const DVRef own = dense_version(desc, tl, mo, bo, o0, o1);
+    const DVRef pr = dense_version(desc, tl, mp, bp, p0, p1);
     const uint32_t f = bo + mo.x + ri;
     p.base.s_partner[f] = partner;
     p.base.s_coef[f] = coef;
@@ -181,9 +186,7 @@ __device__ __forceinline__ void dense_place(const WPlan& p, const WTmp& q, const
             float g_first = 1.0f;
             if (own.ref & WREF_TABLE) g_first = decay3_f32(a.lambda, Tb - own.t_src);
             else dec = decay3_f32(a.lambda, Tb - own.t_src);    // (a log row's decay comes with the run: s_dec)
-            const int64_t bn = (w + 1) * KW;
-            const uint32_t pre_next = bn < a.nb ? D.m[bn * D.Ns + node].x : D.tot[node];
-            const uint32_t cnt = pre_next - mo.x;
+            const uint32_t cnt = wsl_own.x;                      // the node's contributions in the window (k_dense_win)
             const int c = wchain_class(cnt, p.heavy_thr);
             const uint32_t pair = (uint32_t)w * 8u + (uint32_t)c;
             const uint32_t chunk = node / (uint32_t)DCH;
@@ -217,14 +220,14 @@ __device__ __forceinline__ void dense_neg(const WPlan& p, const DView& D, const 
     const uint2 m = D.m[b * D.Ns + node];
     const uint32_t bs = basef[node];
     const uint4 m0 = reinterpret_cast<const uint4*>(a.meta + node)[0], m1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
-    const DVRef r = dense_version(desc, m, bs, m0, m1);
+    const DVRef r = dense_version(desc, nullptr, m, bs, m0, m1);
     p.e_ref[2 * a.Ec + e] = r.ref;
     p.e_g[2 * a.Ec + e] = decay3_f32(a.lambda, desc[b].now - r.t_src);
 }
 
 // the same inside phase C: the node's first position = its chunk's base (LDS) + its place in the chunk
 __device__ __forceinline__ void dense_neg_c(const WPlan& p, const DView& D, const DArgs& a, const uint32_t* __restrict__ cbase,
-                                            int64_t e) {
+                                            const double* tl, int64_t e) {
     const BatchDesc* __restrict__ desc = p.base.desc;
     int64_t node = a.neg[e];
     if ((uint64_t)node >= (uint64_t)a.N) node = 0;
@@ -232,7 +235,7 @@ __device__ __forceinline__ void dense_neg_c(const WPlan& p, const DView& D, cons
     const uint2 m = D.m[b * D.Ns + node];
     const uint32_t bs = D.base[node] + cbase[(uint32_t)node / (uint32_t)DCH];
     const uint4 m0 = reinterpret_cast<const uint4*>(a.meta + node)[0], m1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
-    const DVRef r = dense_version(desc, m, bs, m0, m1);
+    const DVRef r = dense_version(desc, tl, m, bs, m0, m1);
     p.e_ref[2 * a.Ec + e] = r.ref;
     p.e_g[2 * a.Ec + e] = decay3_f32(a.lambda, desc[b].now - r.t_src);
 }
@@ -375,8 +378,12 @@ __global__ __launch_bounds__(DCH) void k_dense_place(WPlan p, WTmp q, DView D, D
     __shared__ uint32_t wsum[DCH / 64];
     __shared__ uint32_t cbase[DENSE_MAX_CHUNKS];
     __shared__ uint32_t lstart[DENSE_MAX_WINDOWS * 8];
+    __shared__ double tlast[DENSE_TL];                   // the closing clocks of up to DENSE_TL batches (one dependent load less per lookup)
     const int tid = threadIdx.x;
     const int npair = (int)a.nw * 8;
+    const double* tl = a.nb <= DENSE_TL ? tlast : nullptr;
+    if (tl)
+        for (int64_t b = tid; b < a.nb; b += DCH) tlast[b] = p.base.desc[b].t_last;
     {
         uint32_t carry = 0;
         for (int64_t c0 = 0; c0 < a.nchunks; c0 += DCH) {
@@ -420,8 +427,8 @@ __global__ __launch_bounds__(DCH) void k_dense_place(WPlan p, WTmp q, DView D, D
     const int64_t nc = 2 * a.Ec;
     const int64_t items = nc + (a.nwhich == 3 ? a.Ec : 0);
     for (int64_t x = gid; x < items; x += gsz) {
-        if (x < nc) dense_place(p, q, D, a, lstart, cbase, x);
-        else dense_neg_c(p, D, a, cbase, x - nc);
+        if (x < nc) dense_place(p, q, D, a, lstart, cbase, tl, x);
+        else dense_neg_c(p, D, a, cbase, tl, x - nc);
     }
 }
 
