@@ -73,6 +73,16 @@ def _cpu_port_times(cfg, src, dst, neg, t, P0, threads, nb, with_mlp=False):
     return tr, tu
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3):
     """the torch-CPU port of the reference ops (oracle/torch_port.py, eager dense decay included) on
     this box's host cores, on a bounded prefix of the same workload: 2 warm-up batches, `reps` repetitions, median; all
@@ -89,7 +99,8 @@ def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3):
         out[name] = {"combined": n / med([a + b for a, b in runs]), "readout_only": n / med([a for a, _ in runs]),
                      "update_only": n / med([b for _, b in runs])}
     torch.set_num_threads(threads)
-    return {"value": out["all"]["combined"], "unit": "edges/s", "cores": threads, "kind": "port",
+    return {"value": out["all"]["combined"], "unit": "edges/s", "cores": threads, "cpu_model": _cpu_model(),
+            "host_logical_cpus": os.cpu_count(), "kind": "port",
             "readout_only": out["all"]["readout_only"], "update_only": out["all"]["update_only"],
             "with_mlp": out["all_mlp"]["combined"], "value_3_threads": out["3thr"]["combined"],
             "readout_only_3_threads": out["3thr"]["readout_only"], "update_only_3_threads": out["3thr"]["update_only"],
@@ -120,6 +131,57 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
     res = {"value": nb * B / el, "unit": "edges/s", "us_per_batch": el / nb * 1e6,
            "what": "module API per batch from host arrays: 2 x get_pair_wise_feature (with rp.mlp) + update; the faster of two "
                    "passes of %d batches" % nb}
+    # the same loop as a TRAINING step issues it (train_link_prediction.py:321-386): gradients recorded, a scalar loss of the
+    # features, zero_grad / backward / Adam step on rp.mlp every batch -- the prepared weight layouts are rebuilt after every step
+    dev_ = rp._dev()
+    opt = torch.optim.Adam(rp.mlp.parameters(), lr=1e-4)
+    labels = torch.cat([torch.ones(B, device=dev_), torch.zeros(B, device=dev_)])
+    lossf = torch.nn.BCEWithLogitsLoss()
+
+    def train_step(feats):
+        loss = lossf(torch.cat([f.sum(1) for f in feats]), labels)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    def decoder_train_pass():
+        rp.reset_random_projections()
+        for b in range(nb + 3):
+            if b == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            s = slice(b * B, (b + 1) * B)
+            if len(src[s]) != B:
+                break
+            f1 = rp.get_pair_wise_feature(src[s], dst[s])
+            f2 = rp.get_pair_wise_feature(src[s], neg[s])
+            rp.update(src[s], dst[s], t[s])
+            train_step((f1, f2))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    def torch_only_step():
+        """The same loss / zero_grad / backward / Adam step on plain torch layers over RESIDENT features (no readout, no update):
+        what the training machinery around the hot path costs on this GPU whatever serves the features."""
+        x = torch.rand(B, rp.pair_wise_feature_dim, device=dev_) * 8.0
+        def go(n):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                train_step((rp.mlp(x), rp.mlp(x)))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        go(5)
+        return go(20)
+    try:
+        elt = min(decoder_train_pass(), decoder_train_pass())
+        tonly = torch_only_step()
+        res["train"] = {"value": nb * B / elt, "unit": "edges/s", "us_per_batch": elt / nb * 1e6,
+                        "ratio_to_no_grad": elt / el,
+                        "torch_step_alone_us": tonly * 1e6, "ratio_to_torch_step_alone": (elt / nb) / tonly,
+                        "what": "the decoder-level loop as a training step issues it: gradients recorded, BCE loss of the two feature "
+                                "sums, zero_grad / backward / Adam step on rp.mlp every batch (train_link_prediction.py:321-386)"}
+    except Exception as ex:                       # noqa: BLE001 -- a secondary figure must not cost the main line
+        res["train"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     # encoder-level unit (SURVEY section 8d, secondary): the encoder's two calls per batch on top -- 4*B*K pairs each in the
     # reference's tile / repeat pattern (models/TPNet.py:311-316), K = 20 synthetic neighbours per node
     K = 20
@@ -184,10 +246,38 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
                 torch.cuda.synchronize()
             el_ = time.perf_counter() - t0_
             return {"value": nbe * B / el_, "unit": "edges/s", "us_per_batch": el_ / nbe * 1e6, "what": label}
+        def device_train_loop():
+            rp.reset_random_projections()
+            for b in range(nbe + 4):
+                if b == 4:
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                s = slice(b * B, (b + 1) * B)
+                fe = [rp.encoder_pair_features(smp, src[s], other, t[s], K) for other in (dst[s], neg[s])]
+                f1 = rp.get_pair_wise_feature(src[s], dst[s])
+                f2 = rp.get_pair_wise_feature(src[s], neg[s])
+                rp.update(src[s], dst[s], t[s])
+                # (the encoder's features enter the loss too: their gradient reaches rp.mlp through 4*B*K rows per call)
+                fx = [x if torch.is_tensor(x) else x[0] for x in fe]
+                loss = lossf(torch.cat([f1.sum(1), f2.sum(1)]), labels) + sum(x.mean() for x in fx)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            el_ = time.perf_counter() - t0_
+            return {"value": nbe * B / el_, "unit": "edges/s", "us_per_batch": el_ / nbe * 1e6,
+                    "what": "encoder_level_device as a training step issues it (gradients through self.mlp of every call, Adam step per batch)"}
         if _lib_anchored_ok(rp):
             res["encoder_level_device"] = device_loop(
                 f"neighbour ids resident on the device: 2 x encoder_pair_features on the batch's host arrays (staged, no copy; device sampler, K = {K}; "
                 f"anchored readout of 4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls")
+            try:
+                device_train_loop()
+                tr_ = device_train_loop()
+                tr_["ratio_to_no_grad"] = tr_["us_per_batch"] / res["encoder_level_device"]["us_per_batch"]
+                res["encoder_level_device"]["train"] = tr_
+            except Exception as ex:               # noqa: BLE001
+                res["encoder_level_device"]["train"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             if rp.num_layer == 3:
                 rp.fused_mlp = True
                 try:
@@ -494,8 +584,8 @@ def main():
 
     def pmc_traffic(kernel_short, edges_per_launch):
         """Memory-side bytes per launch of this kernel from this round's committed rocprofv3 PMC passes (tools/pmc.sh ->
-        profiles/r03_<config>_pmc.json), accepted only for the same kernel at the same work per launch (+-10 %)."""
-        path = os.path.join(ROOT, "profiles", f"r03_{args.config}_pmc.json")
+        profiles/r04_<config>_pmc.json), accepted only for the same kernel at the same work per launch (+-10 %)."""
+        path = os.path.join(ROOT, "profiles", f"r04_{args.config}_pmc.json")
         try:
             for ent in json.load(open(path)).get("kernels", []):
                 if ent.get("kernel") == kernel_short and ent.get("traffic_bytes_per_launch") and \
@@ -536,8 +626,16 @@ def main():
         # committed counters -- bytes that really crossed the Infinity Cache / HBM boundary per launch -- is the one to hold
         # against the 8 TB/s peak there)
         mem_gbs = traffic / (kern_ms.value * 1e-3) / 1e9 if (traffic and kern_ms.value > 0) else None
-        return {"bound": "hbm", "kernel": kname, "kernel_short": kshort, "windowed": windowed,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        # A table that sits in the 256 MB Infinity Cache is not served by HBM: where the section-8(d) byte count over time exceeds
+        # the HBM peak (the fused kernel moves fewer bytes than the unfused count at such shapes), the line says bound = "cache" and
+        # `frac` is the memory-side fraction (PMC bytes over time over 8 TB/s; null without counters) -- never a fraction above 1
+        # under bound = "hbm".  The algorithmic figure stays beside it.
+        frac_alg = achieved / HBM_PEAK_GBS
+        cache_bound = (28.0 * N * d < 256e6) and frac_alg > 1.0
+        return {"bound": "cache" if cache_bound else "hbm", "kernel": kname, "kernel_short": kshort, "windowed": windowed,
+                "achieved": (mem_gbs if cache_bound else achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ((mem_gbs / HBM_PEAK_GBS) if mem_gbs else None) if cache_bound else frac_alg,
+                "algorithmic_gbs": achieved, "algorithmic_frac": frac_alg,
                 "traffic": traffic, "traffic_source": traffic_src, "steps": nbat,
                 "memory_side_gbs": mem_gbs, "memory_side_frac": (mem_gbs / HBM_PEAK_GBS) if mem_gbs else None,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "launches": n_launch.value,
@@ -560,7 +658,7 @@ def main():
         try:
             cbw = copy_bandwidth_gbs(dev)
             roof["copy_bandwidth_gbs_measured"] = cbw
-            roof["frac_of_measured_copy_bandwidth"] = roof["achieved"] / cbw
+            roof["frac_of_measured_copy_bandwidth"] = roof["algorithmic_gbs"] / cbw
         except Exception:
             pass
 
@@ -593,6 +691,29 @@ def main():
             cold = [one(g_negs[i % 4], False)[0] for i in range(1, 6)]
             one(g_negs[0], None)                                       # leaves the plan behind
             rep = [one(g_negs[i % 4], None) for i in range(1, 6)]
+            # SURVEY section 8(d) asks for the figures with and without rp.mlp: the same epoch followed by self.mlp (fp32 class,
+            # tpnet_mlp64_f32) over its 2 E feature rows -- what get_pair_wise_feature returns for every (src, dst) and (src, neg)
+            with_mlp = None
+            if rp.pair_wise_feature_dim == 64:
+                from tpnet_amd import fused_feature as FF
+
+                def one_mlp(neg_dev, replay):
+                    rp.reset_random_projections()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    rp.run_stream(g_src, g_dst, neg_dev, g_t, B, out_pos=o_p, out_neg=o_n, t_end=t_end, replay=replay)
+                    with torch.no_grad():
+                        y1 = FF.mlp_f32(rp.mlp, o_p)
+                        y2 = FF.mlp_f32(rp.mlp, o_n)
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) if (y1 is not None and y2 is not None) else None
+                if one_mlp(g_negs[0], False) is not None:
+                    cm = [one_mlp(g_negs[i % 4], False) for i in range(1, 4)]
+                    one_mlp(g_negs[0], None)
+                    rm = [one_mlp(g_negs[i % 4], None) for i in range(1, 4)]
+                    with_mlp = {"what": "the same epoch + self.mlp (fp32 class, tpnet_mlp64_f32) over its 2 E feature rows, wall clock, median of 3",
+                                "cold": {"wall_us": float(np.median(cm)) * 1e6, "value": Ee / float(np.median(cm))},
+                                "replay": {"wall_us": float(np.median(rm)) * 1e6, "value": Ee / float(np.median(rm))}}
             rp.check_device_errors()
             # the dominant kernel of the epoch, timed like `roofline` (events around the loop of pipeline launches)
             rp.reset_random_projections()
@@ -608,7 +729,8 @@ def main():
                               "end_to_end_frac": bpe * Ee / med([r[0] for r in rep]) / 1e9 / HBM_PEAK_GBS,
                               "plan_replayed": bool(all(r[1] for r in rep)),
                               "what": "a later epoch: same stream, new negatives, the update's plan replayed"},
-                   "kernel": {k: er[k] for k in ("kernel_short", "frac", "achieved", "launches", "edges_per_launch",
+                   "with_mlp": with_mlp,
+                   "kernel": {k: er[k] for k in ("kernel_short", "bound", "frac", "achieved", "algorithmic_frac", "launches", "edges_per_launch",
                                                  "avg_launch_period_us", "memory_side_frac", "traffic", "stream_ms_events",
                                                  "end_to_end_frac")}}
             del o_p, o_n

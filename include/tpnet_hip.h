@@ -177,6 +177,12 @@ int tpnet_pair_feature(const tpnet_state* st, const int64_t* u, const int64_t* v
  * features that a separate readout produced (the anchored / shared-first-node kernels of the encoder's call). */
 int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, float* y, void* stream);
 
+/* The derived layouts of a tpnet_mlp from the Parameters of self.mlp = Linear(F, H) -> ReLU -> Linear(H, F) (models/TPNet.py:63-65)
+ * in ONE launch: w1 = mlp[0].weight [H][F], w2 = mlp[2].weight [F][H] (device, contiguous) -> w1t [F][H], w2t [H][F] and, for
+ * F = 64 / H = 256 (else NULL), w2f in the gathered order tpnet_mlp documents.  b1, b2 and tpnet_mlp::w1 are the Parameters'
+ * own storage.  A training loop calls this after every optimizer step (train_link_prediction.py:384-386). */
+int tpnet_mlp_prepare(const float* w1, const float* w2, int32_t F, int32_t H, float* w1t, float* w2t, float* w2f, void* stream);
+
 /* ---- host-array entry points: what the reference's per-batch calls hand over are HOST numpy arrays (models/TPNet.py:
  * 74-77, 107, 117; train_link_prediction.py:359-373).  These variants take host pointers, check the ids on the host
  * (TPNET_ERR_INDEX for an id outside [-N, N); negative ids wrap like ATen indexing), copy them into a slot of a pinned,

@@ -42,3 +42,20 @@ def _windowed_schedule_for_short_streams():
     RandomProjectionModule.default_schedule = "windowed"
     yield
     RandomProjectionModule.default_schedule = old
+
+
+@pytest.fixture(autouse=True)
+def _seeded_global_generators(request):
+    """Every test starts from generators seeded by its own name: a module's P[0] and self.mlp are drawn from torch's global
+    generator (models/TPNet.py:49-65), and a comparison that fails must fail again when it is re-run (the round-3 gradient
+    tests drew different weights in every run).  Tests that seed for themselves are unaffected."""
+    import zlib
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    try:
+        import numpy as np
+        np.random.seed(seed)
+        import torch
+        torch.manual_seed(seed)
+    except Exception:
+        pass
+    yield

@@ -10,6 +10,9 @@ import torch
 
 def _module(N, d, L, lam=1e-6, **kw):
     from tpnet_amd import RandomProjectionModule
+    # P[0] and self.mlp are drawn from torch's global generator (models/TPNet.py:49-65): seeded, so that a failing comparison
+    # can be reproduced (the round-3 gradient tests drew different weights in every run)
+    torch.manual_seed(1234 + 7 * N + 13 * d + L)
     args = dict(node_num=N, edge_num=4 * N, dim_factor=10, num_layer=L, time_decay_weight=lam, device="cuda:0",
                 use_matrix=False, beginning_time=np.float64(0.0), not_scale=False, enforce_dim=d)
     args.update(kw)
@@ -439,3 +442,34 @@ def test_encoder_pattern_on_host_arrays_is_recognised(d, K, m):
     with pytest.raises(IndexError):
         rp.get_pair_wise_feature(u, bad)
     rp.check_device_errors()
+
+
+@pytest.mark.gpu
+def test_mlp_prepare_layouts_follow_the_parameters():
+    """tpnet_mlp_prepare: the derived layouts of self.mlp in one launch (what a training loop pays after every optimizer step)
+    equal the torch expressions they replace -- two transposes and the gathered w2f of include/tpnet_hip.h -- and follow an
+    in-place update of the Parameters (the cache key is (data_ptr, _version): an optimizer step bumps the version)."""
+    from tpnet_amd import fused_feature as ff
+    rp = _module(50, 128, 3)
+    mlp = rp.mlp
+    prep = ff.prepared(mlp, 64)
+    w1t, w2t, w2f = prep[3]
+    torch.cuda.synchronize()
+    rows, cols = ff._w2f_index(mlp[2].weight.device)
+    assert torch.equal(w1t, mlp[0].weight.detach().t()) and torch.equal(w2t, mlp[2].weight.detach().t())
+    assert torch.equal(w2f, mlp[2].weight.detach()[rows, cols])
+    assert prep[1].w1 == mlp[0].weight.data_ptr() and prep[1].b1 == mlp[0].bias.data_ptr()
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.25)                                  # (what an optimizer step does: in place, _version bumped)
+    prep2 = ff.prepared(mlp, 64)
+    torch.cuda.synchronize()
+    assert prep2[3][0].data_ptr() == w1t.data_ptr()        # same buffers, rewritten
+    assert torch.equal(prep2[3][0], mlp[0].weight.detach().t()) and torch.equal(prep2[3][2], mlp[2].weight.detach()[rows, cols])
+    # and the fused forward uses them: against the torch layers on the same features
+    rng = np.random.RandomState(0)
+    u, v = rng.randint(1, 50, 300), rng.randint(1, 50, 300)
+    with torch.no_grad():
+        got = rp.get_pair_wise_feature(u, v)
+        want = mlp(rp.pair_gram(u, v))
+    assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))

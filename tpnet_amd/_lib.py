@@ -114,6 +114,7 @@ SIGNATURES = {
     "tpnet_check_errors": (C.c_int, [_SP, _P]),
     "tpnet_pair_feature": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp), _P, _P, _P]),
     "tpnet_mlp64_f32": (C.c_int, [_P, C.c_int64, C.POINTER(Mlp), _P, _P]),
+    "tpnet_mlp_prepare": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "tpnet_stage_create": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(_P)]),
     "tpnet_stage_destroy": (C.c_int, [_P]),
     "tpnet_stage_max_pairs": (C.c_int64, [_P]),

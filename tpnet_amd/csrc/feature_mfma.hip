@@ -320,9 +320,35 @@ int launch_pair_feature_bf16(const tpnet_state& st, const int64_t* u, const int6
     return TPNET_OK;
 }
 
+// the layouts the fused kernels read, from the Parameters of self.mlp: one launch per optimizer step (the torch expressions --
+// two transposes, a contiguous copy and an index gather -- were ~100 us of a training step)
+__global__ void k_mlp_prepare(const float* __restrict__ w1, const float* __restrict__ w2, int F, int H, float* __restrict__ w1t,
+                              float* __restrict__ w2t, float* __restrict__ w2f) {
+    const int n = F * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        // w1 [H][F] -> w1t [F][H];  w2 [F][H] -> w2t [H][F]   (coalesced writes)
+        { const int f = i / H, h = i - f * H; w1t[i] = w1[h * F + f]; }
+        { const int h = i / F, f = i - h * F; w2t[i] = w2[f * H + h]; }
+        if (w2f) {            // F = 64, H = 256: i = ((w * 2 + t) * 64 + lane) * 16 + s   (include/tpnet_hip.h, tpnet_mlp::w2f)
+            const int s_ = i & 15, lane = (i >> 4) & 63, t = (i >> 10) & 1, w = i >> 11;
+            w2f[i] = w2[(32 * t + (lane & 31)) * H + 32 * w + (s_ & 3) + 8 * (s_ >> 2) + 4 * (lane >> 5)];
+        }
+    }
+}
+
 }  // namespace tpnet
 
 using namespace tpnet;
+
+extern "C" int tpnet_mlp_prepare(const float* w1, const float* w2, int32_t F, int32_t H, float* w1t, float* w2t, float* w2f,
+                                 void* stream) {
+    if (!w1 || !w2 || !w1t || !w2t || F < 1 || H < 1 || (int64_t)F * H > (1 << 24)) return TPNET_ERR_BAD_ARG;
+    if (w2f && (F != 64 || H != 256)) return TPNET_ERR_BAD_ARG;
+    const int n = F * H;
+    hipLaunchKernelGGL(k_mlp_prepare, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1, w2, (int)F, (int)H, w1t, w2t, w2f);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
 
 extern "C" int tpnet_pair_feature_bf16(const tpnet_state* st, const int64_t* u, const int64_t* v, int64_t n, double now_time,
                                        double lambda, uint32_t flags, const void* w1_bf16, const float* b1,
