@@ -358,6 +358,16 @@ int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* p
                              const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
                              int64_t batch, int64_t b, double lambda, uint32_t launch_id, uint32_t flags, int32_t n_owned,
                              float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream);
+/* Batches [b0, b1) of a stream through tpnet_rows_step_targeted in ONE call (the per-batch loop of tpnet_amd/sharded.py was one
+ * FFI crossing, ~10 us of host time, per batch): pack_start[b] = offset of batch b's rows in pack_ids, send_cnt / recv_cnt
+ * HOST int64[nb][G], t_last HOST double[nb] (the clock batch b leaves: its rows of batch b + 1 are packed at it), launch ids
+ * launch_id_base + b. */
+int tpnet_rows_stream_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, const int64_t* pack_start,
+                               float* send_p0, float* send_q, const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G,
+                               int32_t me, double now_time, const double* t_last, const int64_t* src, const int64_t* dst,
+                               const int64_t* neg, const double* t, int64_t E, int64_t batch, int64_t b0, int64_t b1,
+                               double lambda, uint32_t launch_id_base, uint32_t flags, int32_t n_owned, float* out_pos,
+                               float* out_neg, void* workspace, size_t ws_bytes, void* stream);
 
 /* The targeted exchange's plan on the device (what tpnet_rows_step_targeted's callers need per batch): for rank `me` of G (owner(n)
  * = n % G), from the stream's device arrays, two launches and no synchronisation:

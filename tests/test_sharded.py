@@ -689,3 +689,21 @@ def test_device_exchange_plan_equals_torch_plan(G, N, E, B, with_neg):
     r.G, r.me, r.N, r.n_cap, r.H, r.rp, r.group = G, 0, N, (N + G - 1) // G, 3 * B, _Rp(), None
     with pytest.raises(IndexError):
         r.relabel_targeted_device(bad, dd, dn, B)
+
+
+@pytest.mark.gpu
+def test_rccl_branch_through_loopback():
+    """The `comm && G > 1` branch of tpnet_rows_step_targeted (csrc/rows_rccl.hip: grouped ncclSend / ncclRecv of two messages per
+    peer, received straight into the halo rows) -- which every gloo test bypasses and a one-GPU box cannot reach with real RCCL --
+    runs against an in-process stand-in for the eight RCCL entry points (tests/loopback/rccl_loopback.cpp): two shards in one
+    process, one stream each, driven batch by batch through tpnet_rows_stream_targeted.  Bit for bit equal to the same shards
+    with the rows moved by plain copies; equal to the single-GPU run within the tolerances of
+    test_sharded_stream_equals_single_gpu.  In a process of its own: the library resolves RCCL once per process."""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback")
+    if not os.path.exists(os.path.join(here, "librccl_loopback.so")):
+        subprocess.run(["make", "-C", here], check=True)
+    res = subprocess.run([sys.executable, os.path.join(here, "run_loopback.py")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "LOOPBACK OK" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])

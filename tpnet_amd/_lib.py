@@ -91,6 +91,9 @@ SIGNATURES = {
     "tpnet_rows_step_targeted": (C.c_int, [_SP, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P,
                                            C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_uint32, C.c_uint32, C.c_int32, _P,
                                            _P, _P, C.c_size_t, _P]),
+    "tpnet_rows_stream_targeted": (C.c_int, [_SP, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P,
+                                             C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_uint32, C.c_uint32,
+                                             C.c_int32, _P, _P, _P, C.c_size_t, _P]),
     "tpnet_sampler_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_sampler_build": (C.c_int, [_P, C.c_size_t, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
     "tpnet_sample_recent": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),

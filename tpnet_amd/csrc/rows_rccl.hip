@@ -170,4 +170,25 @@ int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* p
                             workspace, ws_bytes, stream);
 }
 
+int tpnet_rows_stream_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, const int64_t* pack_start,
+                               float* send_p0, float* send_q, const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G,
+                               int32_t me, double now_time, const double* t_last, const int64_t* src, const int64_t* dst,
+                               const int64_t* neg, const double* t, int64_t E, int64_t batch, int64_t b0, int64_t b1,
+                               double lambda, uint32_t launch_id_base, uint32_t flags, int32_t n_owned, float* out_pos,
+                               float* out_neg, void* workspace, size_t ws_bytes, void* stream) {
+    const int64_t nb = batch > 0 ? (E + batch - 1) / batch : 0;
+    if (batch < 1 || b0 < 0 || b1 > nb || b0 > b1 || !t_last || !send_cnt || !recv_cnt || !pack_start || G < 1) return TPNET_ERR_BAD_ARG;
+    if (launch_id_base == 0 || (uint64_t)launch_id_base + (uint64_t)nb >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
+    for (int64_t b = b0; b < b1; ++b) {
+        // the clock a batch's rows are packed at is the one the previous batch left (models/TPNet.py:99)
+        const double now = b == 0 ? now_time : t_last[b - 1];
+        const int rc = tpnet_rows_step_targeted(st, comm, pack_ids ? pack_ids + pack_start[b] : nullptr, send_p0, send_q,
+                                                send_cnt + (size_t)G * (size_t)b, recv_cnt + (size_t)G * (size_t)b, G, me, now, src, dst,
+                                                neg, t, E, batch, b, lambda, launch_id_base + (uint32_t)b, flags, n_owned, out_pos,
+                                                out_neg, workspace, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return TPNET_OK;
+}
+
 }  // extern "C"

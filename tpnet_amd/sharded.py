@@ -129,11 +129,14 @@ class ShardedStreamRunner:
     exchange = "allgather"     # "allgather" (v1: every touched row to every rank) | "targeted" (v2: each row only to the ranks
                                # that read it, received in place: run_stream_targeted); both with RCCL called from C
 
-    def __init__(self, rp_local, node_num: int, halo_rows: int, group=None):
+    def __init__(self, rp_local, node_num: int, halo_rows: int, group=None, world=None, rank=None):
         self.rp = rp_local
         self.group = group
-        self.G = dist.get_world_size(group)
-        self.me = dist.get_rank(group)
+        # world / rank given: a shard with no process group behind it (several shards in ONE process: the loopback test of the
+        # RCCL branch, tests/loopback) -- whoever drives it moves the rows and merges the outputs
+        self.detached = world is not None
+        self.G = int(world) if world is not None else dist.get_world_size(group)
+        self.me = int(rank) if rank is not None else dist.get_rank(group)
         self.N = int(node_num)
         self.n_cap = (self.N + self.G - 1) // self.G
         self.H = int(halo_rows)
@@ -144,18 +147,18 @@ class ShardedStreamRunner:
     @classmethod
     def create(cls, node_num: int, edge_num: int, dim: int, num_layer: int, time_decay_weight: float, device,
                beginning_time, halo_rows: int, not_scale: bool = False, group=None, seed: int = 0,
-               draw_on_device: bool = False):
+               draw_on_device: bool = False, world=None, rank=None):
         """Build the local shard.  `halo_rows` >= the distinct remote nodes one batch can touch (3 * batch is always enough).
         P[0] ~ N(0, 1/sqrt(dim)) (models/TPNet.py:58): each rank draws its own rows from a generator seeded with (seed,
         rank); tests inject a full matrix with set_full_p0."""
         from .random_projection import RandomProjectionModule
-        G = dist.get_world_size(group)
+        G = int(world) if world is not None else dist.get_world_size(group)
         n_cap = (node_num + G - 1) // G
         rp = RandomProjectionModule(node_num=n_cap + int(halo_rows), edge_num=edge_num, dim_factor=1, num_layer=num_layer,
                                     time_decay_weight=time_decay_weight, device=str(device), use_matrix=False,
                                     beginning_time=beginning_time, not_scale=not_scale, enforce_dim=dim,
                                     alloc_device=device)
-        self = cls(rp.to(device), node_num, halo_rows, group)
+        self = cls(rp.to(device), node_num, halo_rows, group, world=world, rank=rank)
         p0 = self.rp._plist()[0]
         if draw_on_device:         # (a 10 M-row shard: 5 GB of normals that need not pass through host memory)
             p0.data[:self.n_cap].copy_(cls.draw_rows(seed, self.me, self.n_cap, dim, p0.device))
@@ -454,12 +457,10 @@ class ShardedStreamRunner:
         return dict(src=lsrc, dst=ldst, neg=lneg, send_cnt=send_cnt, recv_cnt=recv_cnt, rtot=rtot, pack_ids=pack_ids.view(-1),
                     sstart=np.arange(nb, dtype=np.int64) * cap, recv_keys_dev=recv_keys)
 
-    def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
-        """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
-        grouped ncclSend / ncclRecv issued from C (tpnet_rows_step_targeted) whose receives land straight in the halo rows of
-        the local table, step -- two launches and one FFI call per batch.  (Without the C communicator: the same pack launch,
-        torch.distributed.all_to_all_single into the same rows; gloo in the tests: an all-gather of the send buffers from which
-        every rank takes its parts.)  Same results as the all-gather variant; each rank receives only what it reads."""
+    def prepare_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, comm="auto"):
+        """Everything a stream's per-batch calls need (exchange plan, relabelled ids, per-batch plan of the local kernels, send
+        buffers, outputs).  comm: "auto" = the C-side RCCL communicator of this shard's process group (None if it is not on
+        RCCL); or a communicator handle the caller made (tests/loopback)."""
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
@@ -467,13 +468,13 @@ class ShardedStreamRunner:
         E, B = int(src.numel()), int(batch_size)
         nb = (E + B - 1) // B
         L, d = rp.num_layer, rp.dim
-        bundle = (L + 1) * d
         NG = rp.pair_wise_feature_dim
         lam = float(rp.time_decay_weight)
         out_pos = torch.zeros((E, NG), dtype=torch.float32, device=dev)
         out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
+        ctx = dict(E=E, B=B, nb=nb, out_pos=out_pos, out_neg=out_neg, now=rp._now_host)
         if E == 0:
-            return out_pos, out_neg
+            return ctx
         R = self.relabel_targeted_device(src, dst, neg, B) if self.device_plan else None   # (checks the ids' range itself)
         if R is None:
             ends = [src, dst] + ([neg] if neg is not None else [])  # (the lists key on batch * N + node: a bad id would alias)
@@ -489,83 +490,123 @@ class ShardedStreamRunner:
         ls, ld, ln = R["src"], R["dst"], R["neg"]
         _lib.check(lib.tpnet_plan_stream(C.byref(st), ls.data_ptr(), ld.data_ptr(), t.data_ptr(), E, B, rp._now_host,
                                          lam, flags, ws.data_ptr(), ws.numel(), stream), "plan_stream")
-        lid0 = rp._next_launch_ids(nb)
-        scnt, rcnt = np.ascontiguousarray(R["send_cnt"]), np.ascontiguousarray(R["recv_cnt"])
-        stot, rtot = scnt.sum(axis=1), R["rtot"]
+        scnt, rcnt = np.ascontiguousarray(R["send_cnt"], dtype=np.int64), np.ascontiguousarray(R["recv_cnt"], dtype=np.int64)
+        stot = scnt.sum(axis=1)
         sstart = R["sstart"] if "sstart" in R else np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
-        n_cap = self.n_cap
         # the rows a peer reads leave as two messages (layer 0; layers 1..L) and arrive STRAIGHT in the reader's halo rows of p0 and
         # of copy 0 of q: pack -> grouped send / recv -> step, no unpack launch (halo rows are never targets: their copy stays 0)
         smax = max(int(stot.max()), 1)
-        send_p0 = torch.zeros((smax, d), dtype=torch.float32, device=dev)
-        send_q = torch.zeros((smax, L * d), dtype=torch.float32, device=dev)
-        nccl = G > 1 and dist.get_backend(self.group) == "nccl"
-        stp = C.byref(st)
-        pack_ptr = R["pack_ids"].data_ptr()
-        ls_p, ld_p, t_p = ls.data_ptr(), ld.data_ptr(), t.data_ptr()
-        ln_p = ln.data_ptr() if ln is not None else None
-        op_p = out_pos.data_ptr(); on_p = out_neg.data_ptr() if out_neg is not None else None
-        ws_p, ws_n = ws.data_ptr(), ws.numel()
-        t_last_l = [float(x) for x in t_last]
-        now = rp._now_host
-        comm = self._c_comm() if nccl else None
-        if comm is not None or G == 1:
-            # RCCL from C: ONE call per batch = pack + grouped ncclSend / ncclRecv + step, enqueued on the current stream
-            rows_step = lib.tpnet_rows_step_targeted
-            sc_p, rc_p = scnt.ctypes.data, rcnt.ctypes.data
-            for b in range(nb):
-                rc = rows_step(stp, comm, pack_ptr + 8 * int(sstart[b]), send_p0.data_ptr(), send_q.data_ptr(), sc_p + 8 * G * b,
-                               rc_p + 8 * G * b, G, me, now, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, n_cap, op_p,
-                               on_p, ws_p, ws_n, stream)
-                if rc:
-                    _lib.check(rc, "rows_step_targeted")
-                now = t_last_l[b]
+        if comm == "auto":
+            nccl = G > 1 and not self.detached and dist.get_backend(self.group) == "nccl"
+            comm = self._c_comm() if nccl else None
         else:
-            # another transport (torch.distributed all_to_all on RCCL without the C communicator; gloo in the tests): the same
-            # pack launch, the rows moved into the same halo rows, the same step
-            p0_t = rp._plist()[0].data                                       # [n_cap + H, d]
-            q_t = rp._eng["q"].view(2, rp.node_num, L * d)                   # copy 0 receives
-            if not nccl:
-                all_scnt = [None] * G
-                dist.all_gather_object(all_scnt, scnt, group=self.group)
-                gmax = max(max(int(a.sum(axis=1).max()) for a in all_scnt), 1)
-                g_p0 = [torch.empty((gmax, d), dtype=torch.float32, device=dev) for _ in range(G)]
-                g_q = [torch.empty((gmax, L * d), dtype=torch.float32, device=dev) for _ in range(G)]
-                pad_p0 = torch.zeros((gmax, d), dtype=torch.float32, device=dev)
-                pad_q = torch.zeros((gmax, L * d), dtype=torch.float32, device=dev)
-            for b in range(nb):
-                ns, nr = int(stot[b]), int(rtot[b])
-                _lib.check(lib.tpnet_pack_split(stp, pack_ptr + 8 * int(sstart[b]), ns, now, lam, send_p0.data_ptr(),
-                                                send_q.data_ptr(), n_cap, nr, stream), "pack_split")
-                if nccl:
-                    dist.all_to_all_single(p0_t[n_cap:n_cap + nr], send_p0[:ns], output_split_sizes=rcnt[b].tolist(),
-                                           input_split_sizes=scnt[b].tolist(), group=self.group)
-                    dist.all_to_all_single(q_t[0, n_cap:n_cap + nr], send_q[:ns], output_split_sizes=rcnt[b].tolist(),
-                                           input_split_sizes=scnt[b].tolist(), group=self.group)
-                else:
-                    pad_p0[:ns].copy_(send_p0[:ns]); pad_q[:ns].copy_(send_q[:ns])
-                    dist.all_gather(g_p0, pad_p0, group=self.group)
-                    dist.all_gather(g_q, pad_q, group=self.group)
-                    o = 0
-                    for s_ in range(G):                  # rows owner s_ packed for me: after what it packed for readers < me
-                        c = int(rcnt[b][s_])
-                        if c:
-                            a0 = int(all_scnt[s_][b][:me].sum())
-                            p0_t[n_cap + o:n_cap + o + c].copy_(g_p0[s_][a0:a0 + c])
-                            q_t[0, n_cap + o:n_cap + o + c].copy_(g_q[s_][a0:a0 + c])
-                            o += c
-                _lib.check(lib.tpnet_step_batch(stp, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, 0, n_cap, op_p, on_p,
-                                                ws_p, ws_n, stream), "step_batch")
-                now = t_last_l[b]
-        rp._now_host = now
-        rp._params_valid = False
-        rp._now_dirty = True
-        rp._table_written()
-        if G > 1 and merge_outputs:
+            nccl = comm is not None
+        ctx.update(R=R, t_last=np.ascontiguousarray(t_last, dtype=np.float64), ws=ws, st=st, stream=stream, flags=flags, lam=lam,
+                   ls=ls, ld=ld, ln=ln, t=t, scnt=scnt, rcnt=rcnt, stot=stot, rtot=R["rtot"],
+                   sstart=np.ascontiguousarray(sstart, dtype=np.int64), lid0=rp._next_launch_ids(nb),
+                   send_p0=torch.zeros((smax, d), dtype=torch.float32, device=dev),
+                   send_q=torch.zeros((smax, L * d), dtype=torch.float32, device=dev), comm=comm, nccl=nccl)
+        return ctx
+
+    def steps_targeted(self, ctx, b0: int, b1: int):
+        """Batches [b0, b1) of a prepared stream in ONE FFI call: per batch pack + grouped ncclSend / ncclRecv (comm; none with one
+        rank) + step, all enqueued on the current stream (tpnet_rows_stream_targeted)."""
+        if ctx["E"] == 0 or b0 >= b1:
+            return
+        lib = _lib.load()
+        ln, on = ctx["ln"], ctx["out_neg"]
+        rc = lib.tpnet_rows_stream_targeted(C.byref(ctx["st"]), ctx["comm"], ctx["R"]["pack_ids"].data_ptr(), ctx["sstart"].ctypes.data,
+                                            ctx["send_p0"].data_ptr(), ctx["send_q"].data_ptr(), ctx["scnt"].ctypes.data,
+                                            ctx["rcnt"].ctypes.data, self.G, self.me, ctx["now"], ctx["t_last"].ctypes.data,
+                                            ctx["ls"].data_ptr(), ctx["ld"].data_ptr(), ln.data_ptr() if ln is not None else None,
+                                            ctx["t"].data_ptr(), ctx["E"], ctx["B"], int(b0), int(b1), ctx["lam"], ctx["lid0"],
+                                            ctx["flags"], self.n_cap, ctx["out_pos"].data_ptr(),
+                                            on.data_ptr() if on is not None else None, ctx["ws"].data_ptr(), ctx["ws"].numel(),
+                                            self.rp._stream())
+        if rc:
+            _lib.check(rc, "rows_stream_targeted")
+
+    def finish_targeted(self, ctx, merge_outputs: bool = True):
+        rp = self.rp
+        if ctx["E"]:
+            rp._now_host = float(ctx["t_last"][-1])
+            rp._params_valid = False
+            rp._now_dirty = True
+            rp._table_written()
+        out_pos, out_neg = ctx["out_pos"], ctx["out_neg"]
+        if self.G > 1 and merge_outputs and not self.detached:
             dist.all_reduce(out_pos, group=self.group)
             if out_neg is not None:
                 dist.all_reduce(out_neg, group=self.group)
         return out_pos, out_neg
+
+    def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
+        """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
+        grouped ncclSend / ncclRecv issued from C (tpnet_rows_step_targeted) whose receives land straight in the halo rows of
+        the local table, step -- two launches per batch, ONE FFI call per stream (tpnet_rows_stream_targeted).  (Without the C
+        communicator: the same pack launch, torch.distributed.all_to_all_single into the same rows; gloo in the tests: an
+        all-gather of the send buffers from which every rank takes its parts.)  Same results as the all-gather variant; each
+        rank receives only what it reads."""
+        rp, G, me = self.rp, self.G, self.me
+        ctx = self.prepare_targeted(src, dst, neg, t, batch_size, t_host_last)
+        if ctx["E"] == 0:
+            return ctx["out_pos"], ctx["out_neg"]
+        if ctx["comm"] is not None or G == 1:
+            self.steps_targeted(ctx, 0, ctx["nb"])
+            return self.finish_targeted(ctx, merge_outputs)
+        # another transport (torch.distributed all_to_all on RCCL without the C communicator; gloo in the tests): the same
+        # pack launch, the rows moved into the same halo rows, the same step
+        lib = _lib.load()
+        dev = rp._dev()
+        E, B, nb = ctx["E"], ctx["B"], ctx["nb"]
+        L, d = rp.num_layer, rp.dim
+        lam, flags, stream, nccl = ctx["lam"], ctx["flags"], ctx["stream"], ctx["nccl"]
+        scnt, rcnt, stot, rtot, sstart = ctx["scnt"], ctx["rcnt"], ctx["stot"], ctx["rtot"], ctx["sstart"]
+        send_p0, send_q = ctx["send_p0"], ctx["send_q"]
+        stp = C.byref(ctx["st"])
+        pack_ptr = ctx["R"]["pack_ids"].data_ptr()
+        ls_p, ld_p, t_p = ctx["ls"].data_ptr(), ctx["ld"].data_ptr(), ctx["t"].data_ptr()
+        ln_p = ctx["ln"].data_ptr() if ctx["ln"] is not None else None
+        op_p = ctx["out_pos"].data_ptr(); on_p = ctx["out_neg"].data_ptr() if ctx["out_neg"] is not None else None
+        ws_p, ws_n = ctx["ws"].data_ptr(), ctx["ws"].numel()
+        lid0, n_cap = ctx["lid0"], self.n_cap
+        t_last_l = [float(x) for x in ctx["t_last"]]
+        now = ctx["now"]
+        p0_t = rp._plist()[0].data                                       # [n_cap + H, d]
+        q_t = rp._eng["q"].view(2, rp.node_num, L * d)                   # copy 0 receives
+        if not nccl:
+            all_scnt = [None] * G
+            dist.all_gather_object(all_scnt, scnt, group=self.group)
+            gmax = max(max(int(a.sum(axis=1).max()) for a in all_scnt), 1)
+            g_p0 = [torch.empty((gmax, d), dtype=torch.float32, device=dev) for _ in range(G)]
+            g_q = [torch.empty((gmax, L * d), dtype=torch.float32, device=dev) for _ in range(G)]
+            pad_p0 = torch.zeros((gmax, d), dtype=torch.float32, device=dev)
+            pad_q = torch.zeros((gmax, L * d), dtype=torch.float32, device=dev)
+        for b in range(nb):
+            ns, nr = int(stot[b]), int(rtot[b])
+            _lib.check(lib.tpnet_pack_split(stp, pack_ptr + 8 * int(sstart[b]), ns, now, lam, send_p0.data_ptr(),
+                                            send_q.data_ptr(), n_cap, nr, stream), "pack_split")
+            if nccl:
+                dist.all_to_all_single(p0_t[n_cap:n_cap + nr], send_p0[:ns], output_split_sizes=rcnt[b].tolist(),
+                                       input_split_sizes=scnt[b].tolist(), group=self.group)
+                dist.all_to_all_single(q_t[0, n_cap:n_cap + nr], send_q[:ns], output_split_sizes=rcnt[b].tolist(),
+                                       input_split_sizes=scnt[b].tolist(), group=self.group)
+            else:
+                pad_p0[:ns].copy_(send_p0[:ns]); pad_q[:ns].copy_(send_q[:ns])
+                dist.all_gather(g_p0, pad_p0, group=self.group)
+                dist.all_gather(g_q, pad_q, group=self.group)
+                o = 0
+                for s_ in range(G):                  # rows owner s_ packed for me: after what it packed for readers < me
+                    c = int(rcnt[b][s_])
+                    if c:
+                        a0 = int(all_scnt[s_][b][:me].sum())
+                        p0_t[n_cap + o:n_cap + o + c].copy_(g_p0[s_][a0:a0 + c])
+                        q_t[0, n_cap + o:n_cap + o + c].copy_(g_q[s_][a0:a0 + c])
+                        o += c
+            _lib.check(lib.tpnet_step_batch(stp, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, 0, n_cap, op_p, on_p,
+                                            ws_p, ws_n, stream), "step_batch")
+            now = t_last_l[b]
+        return self.finish_targeted(ctx, merge_outputs)
 
     def gather_full_layers(self):
         """All ranks' owned rows interleaved back into global order: [L+1, N, d] on every rank (tests / checkpoints of small
