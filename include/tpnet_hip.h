@@ -92,6 +92,10 @@ typedef struct tpnet_state {
                                        windows per chunk) even where the one-launch dense planner applies (table small against the
                                        stream: N * 12 bytes <= batch * L * d * 4).  Same bits again */
 
+#define TPNET_FLAG_NO_MFMA_READOUT 256u /* tpnet_pair_gram_anchored and the encoder calls built on it: keep the vector-ALU readout where
+                                       the matrix-core one applies (rows of 64 / 128 floats, L = 3, K >= 4: split-bf16 operands,
+                                       three pieces per value, fp32 accumulation -- fp32 class, other summation order) */
+
 const char* tpnet_strerror(int status);
 int tpnet_abi_version(void);
 int tpnet_last_hip_error(void);
@@ -217,7 +221,9 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
  * get_pair_wise_feature(tile(neigh, 2), concat(repeat(a1, K), repeat(a2, K))) before self.mlp.  One lane group walks a row:
  * the anchors' rows are fetched once per row (not once per pair) and stay in registers, their own Gram blocks are reduced
  * once per row.  Needs rows of exactly one chunk of 16-byte vectors (d = 64, 128, 256, 512: tpnet_pair_gram_anchored_supported
- * returns 1); other shapes take tpnet_pair_gram_shared / tpnet_pair_gram. */
+ * returns 1); other shapes take tpnet_pair_gram_shared / tpnet_pair_gram.  Rows of 64 / 128 floats with L = 3 and K >= 4 are
+ * served by the matrix cores (csrc/encoder_mfma.hip: 16 x 16 x 32 bf16 products on operands split into three bf16 pieces, fp32
+ * accumulation over d inside the pipe -- no cross-lane reduction; TPNET_FLAG_NO_MFMA_READOUT keeps the vector-ALU walk). */
 int tpnet_pair_gram_anchored(const tpnet_state* st, const int64_t* neigh, const int64_t* a1, const int64_t* a2,
                              int64_t n_rows, int32_t K, double now_time, double lambda, uint32_t flags, float* out1,
                              float* out2, void* stream);

@@ -473,3 +473,64 @@ def test_mlp_prepare_layouts_follow_the_parameters():
         got = rp.get_pair_wise_feature(u, v)
         want = mlp(rp.pair_gram(u, v))
     assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,n", [(128, 20, 37), (128, 4, 9), (128, 5, 13), (128, 33, 3), (64, 20, 11), (64, 7, 50), (128, 20, 2000),
+                                   (128, 16, 1), (128, 6, 1)])
+def test_encoder_readout_on_the_matrix_cores(d, K, n):
+    """csrc/encoder_mfma.hip (tpnet_pair_gram_anchored on rows of 64 / 128 floats, L = 3, K >= 4: 16 x 16 x 32 bf16 products on
+    operands split into three bf16 pieces) against the oracle on the reference's pair list (models/TPNet.py:311-321) and against
+    the vector-ALU walk: lists whose length is no multiple of 4 or 16 slots, tiles that straddle two rows, padding id 0,
+    coinciding anchors, raw Gram entries (not_scale) inside 1e-6 |R_a| |R_b| (SURVEY Appendix C asks 1e-4)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from oracle import tpnet_oracle as O
+    rng = np.random.RandomState(K * 131 + d + n)
+    N, L = 260, 3
+    for not_scale in (False, True):
+        rp = _module(N, d, L, not_scale=not_scale)
+        st = O.OracleState(rp.random_projections[0].detach().cpu().numpy(), L, 1e-6, 0.0)
+        for src, dst, t in _stream(rng, N, 150, 3):
+            rp.update(src, dst, t)
+            O.update(st, src, dst, t)
+        neigh = rng.randint(0, N, (n, K)).astype(np.int64)
+        neigh[rng.rand(n, K) < 0.2] = 0
+        a1 = rng.randint(1, N, n).astype(np.int64)
+        a2 = rng.randint(1, N, n).astype(np.int64)
+        a2[n // 2] = a1[n // 2]
+        u = np.tile(neigh.reshape(-1), 2)
+        v = np.concatenate([np.repeat(a1, K), np.repeat(a2, K)])
+        got = rp.pair_gram_anchored(neigh, a1, a2).view(-1, 64).cpu().numpy()
+        valu = rp.pair_gram_anchored(neigh, a1, a2, matrix_cores=False).view(-1, 64).cpu().numpy()
+        if not_scale:
+            # raw entries against the float64 Gram: |delta| <= 1e-6 |R_a| |R_b| + the fp32 rounding of the entry itself (the
+            # vector-ALU walk holds the same bound)
+            want = O.pair_gram(st, u, v, not_scale=True, accumulate=np.float64).reshape(-1, 8, 8)
+            diag = np.sqrt(np.abs(want[:, np.arange(8), np.arange(8)]))                              # |R_a| per row of the pair
+            bound = 1e-6 * diag[:, :, None] * diag[:, None, :] + 2e-7 * np.abs(want)
+            assert np.all(np.abs(got.reshape(-1, 8, 8) - want) <= bound), float(np.max(np.abs(got.reshape(-1, 8, 8) - want) / (bound + 1e-30)))
+            assert np.all(np.abs(valu.reshape(-1, 8, 8) - want) <= bound)
+        else:
+            want = O.pair_gram(st, u, v)
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(got, valu, rtol=2e-5, atol=2e-6)
+        rp.check_device_errors()
+    # ids out of range (device-resident ids are checked by the kernel): NaN features for the pairs they are in, counted
+    rp = _module(N, d, L)
+    neigh = rng.randint(1, N, (n, K)).astype(np.int64)
+    a1 = rng.randint(1, N, n).astype(np.int64)
+    a2 = rng.randint(1, N, n).astype(np.int64)
+    neigh[0, K - 1] = N + 5
+    bad_row = n - 1
+    a2[bad_row] = -3
+    dev = lambda x: torch.from_numpy(x).cuda()
+    got = rp.pair_gram_anchored(dev(neigh), dev(a1), dev(a2)).cpu().numpy()              # [2, n*K, 64]
+    nanrow = np.isnan(got).all(axis=2)
+    exp = np.zeros((2, n * K), dtype=bool)
+    exp[:, K - 1] = True
+    exp[:, bad_row * K:(bad_row + 1) * K] = True
+    assert np.array_equal(nanrow, exp)
+    assert not np.isnan(got[~exp]).any()
+    with pytest.raises(IndexError):
+        rp.check_device_errors()

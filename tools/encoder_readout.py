@@ -40,6 +40,9 @@ for cfg, K in (("C1", 20), ("C2", 20), ("C3", 20)):
     dn, d1, d2 = D(neigh), D(np.tile(src[s], 2)), D(np.tile(dst[s], 2))
     ta = timeit(lambda: lib.tpnet_pair_gram_anchored(C.byref(st), dn.data_ptr(), d1.data_ptr(), d2.data_ptr(), neigh.shape[0], K,
                                                       now, lam, 0, out.data_ptr(), out[n:].data_ptr(), stream))
+    tv = timeit(lambda: lib.tpnet_pair_gram_anchored(C.byref(st), dn.data_ptr(), d1.data_ptr(), d2.data_ptr(), neigh.shape[0], K,
+                                                      now, lam, 256, out.data_ptr(), out[n:].data_ptr(), stream))
     byt = 2 * n * (8 * c["d"] * 4 + 256)
     print(f"{cfg} B={B} K={K}: {2 * n} pairs, d={c['d']}: generic {tg:.1f} us ({byt / tg / 1e3:.0f} GB/s algorithmic), "
-          f"shared-first {ts:.1f} us -> {tg / ts:.2f}x, anchored {ta:.1f} us -> {tg / ta:.2f}x", flush=True)
+          f"shared-first {ts:.1f} us -> {tg / ts:.2f}x, anchored {ta:.1f} us -> {tg / ta:.2f}x (matrix cores where they apply; "
+          f"vector-ALU walk {tv:.1f} us)", flush=True)

@@ -18,6 +18,7 @@ FLAG_SCHED_WINDOWED = 16
 FLAG_SCHED_BATCH = 32
 FLAG_PLAN_SORTED = 64
 FLAG_PLAN_HASHED = 128
+FLAG_NO_MFMA_READOUT = 256
 
 ERR_INDEX = -4
 

@@ -381,6 +381,9 @@ int tpnet_pair_gram_anchored(const tpnet_state* st, const int64_t* neigh, const 
         // anchor side, on index arrays the caller would otherwise build -- not available without them: report it
         return TPNET_ERR_BAD_ARG;
     }
+    // rows of 64 / 128 floats: the same blocks on the matrix cores (encoder_mfma.hip, fp32 class)
+    if ((flags & TPNET_FLAG_NO_MFMA_READOUT) == 0 && encoder_mfma_supported(*st, n_rows, K) && !((reinterpret_cast<uintptr_t>(out1) | reinterpret_cast<uintptr_t>(out2)) & 15))
+        return launch_encoder_gram_mfma(*st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, out1, out2, (hipStream_t)stream);
     return launch_pair_gram_anchored(*st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, out1, out2, (hipStream_t)stream);
 }
 

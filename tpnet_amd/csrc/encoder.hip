@@ -40,7 +40,7 @@ int tpnet_anchored_features(const tpnet_state* st, const int64_t* neigh, const i
     hipStream_t s = (hipStream_t)stream;
     const int64_t F = 64;
     const int64_t half = n_rows * (int64_t)K;                // pairs per anchor side
-    int rc = launch_pair_gram_anchored(*st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, gram, gram + half * F, s);
+    int rc = tpnet_pair_gram_anchored(st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, gram, gram + half * F, stream);
     if (rc) return rc;
     rc = mlp_rows(mlp, gram, 2 * half, out, s);
     if (rc) return rc;
@@ -61,7 +61,7 @@ int tpnet_encoder_features(const tpnet_state* st, const void* sampler, int64_t E
     int64_t* a1 = nodes + 4 * B;
     int64_t* a2 = a1 + 2 * B;
     int64_t* neigh = a2 + 2 * B;
-    if (encoder_generic_readout(*st) && st->L == 3 && !(flags & TPNET_FLAG_PACKED) && mlp->F == 64 && mlp->H == 256 && mlp->w1 &&
+    if (encoder_generic_readout(*st) && !encoder_mfma_supported(*st, 2 * B, K) && st->L == 3 && !(flags & TPNET_FLAG_PACKED) && mlp->F == 64 && mlp->H == 256 && mlp->w1 &&
         mlp->w2f && mlp->b1 && mlp->b2 && !((reinterpret_cast<uintptr_t>(gram) | reinterpret_cast<uintptr_t>(out)) & 15)) {
         // narrow rows: the generic readout on the pair lists the sampler kernel wrote behind the neighbour ids, then the dense layers
         const int64_t half = 2 * B * (int64_t)K;

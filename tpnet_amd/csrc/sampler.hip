@@ -289,7 +289,7 @@ int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, in
     const int64_t tot = 2 * B * (int64_t)K;
     int grid = (int)((tot + 255) / 256);
     if (grid > 8192) grid = 8192;
-    int64_t* pu = encoder_generic_readout(*st) ? neigh + 2 * B * (int64_t)K : nullptr;
+    int64_t* pu = (encoder_generic_readout(*st) && !encoder_mfma_supported(*st, 2 * B, K)) ? neigh + 2 * B * (int64_t)K : nullptr;
     hipLaunchKernelGGL(k_encoder_sample, dim3(grid), dim3(256), 0, s, v.row_start, v.nbr, v.nbr_t, num_nodes, src, other, t, B, (int)K,
                        nodes, t2, a1, a2, neigh, pu, pu ? pu + 4 * B * (int64_t)K : nullptr);
     TPNET_HIP_TRY(hipGetLastError());
@@ -310,7 +310,7 @@ int tpnet_encoder_gram(const tpnet_state* st, const void* sampler, int64_t E, in
     int64_t* a2 = a1 + 2 * B;
     int64_t* neigh = a2 + 2 * B;
     const int NN = 2 * st->L + 2;
-    if (encoder_generic_readout(*st)) {
+    if (encoder_generic_readout(*st) && !encoder_mfma_supported(*st, 2 * B, K)) {
         const int64_t half = 2 * B * (int64_t)K;
         return tpnet_pair_gram(st, neigh + half, neigh + 3 * half, 2 * half, now_time, lambda, flags, out, stream);
     }

@@ -730,12 +730,13 @@ class RandomProjectionModule(nn.Module):
             return _ff.apply_with_grad(self.mlp, launch, n, NG)
         return launch(torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"]))
 
-    def pair_gram_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids):
+    def pair_gram_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids, matrix_cores=True):
         """The encoder's readout before self.mlp (models/TPNet.py:311-324): neighbor_ids [n, K] (the sampled neighbours of n
         rows), two anchors per row (the edge's src and dst).  Returns [2, n*K, (2L+2)^2]: G(neighbour, first anchor) for every
         (row, neighbour), then G(neighbour, second anchor) -- viewed as [2*n*K, .] this is the reference's
         get_pair_wise_feature(tile(neighbours, 2), concat(repeat(first, K), repeat(second, K))) pair order.  One lane group per
-        row keeps both anchors' rows in registers for its K neighbours (tpnet_pair_gram_anchored)."""
+        row keeps both anchors' rows in registers for its K neighbours (tpnet_pair_gram_anchored); rows of 64 / 128 floats with
+        L = 3 and K >= 4 take the matrix cores (csrc/encoder_mfma.hip) unless matrix_cores=False."""
         self._ensure_engine()
         if isinstance(neighbor_ids, torch.Tensor):
             if neighbor_ids.dim() != 2:
@@ -757,7 +758,7 @@ class RandomProjectionModule(nn.Module):
         a1, a2 = self._to_device(self._check_ids(first_anchor_ids, "first_anchor_ids"),
                                  self._check_ids(second_anchor_ids, "second_anchor_ids"))
         out = torch.empty((2, n * K, self.pair_wise_feature_dim), dtype=torch.float32, device=self._dev())
-        flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        flags = (_lib.FLAG_NOT_SCALE if self.not_scale else 0) | (0 if matrix_cores else _lib.FLAG_NO_MFMA_READOUT)
         _lib.check(lib.tpnet_pair_gram_anchored(self._st_ref(), wd.data_ptr(), a1.data_ptr(), a2.data_ptr(), n, K,
                                                 self._now_host, float(self.time_decay_weight), flags, out[0].data_ptr(),
                                                 out[1].data_ptr(), self._stream()), "pair_gram_anchored")
