@@ -31,13 +31,15 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 5 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
+#define TPNET_ABI_VERSION 6 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
                                3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream);
                                4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
                                     (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored;
                                5: + tpnet_run_stream_tagged / tpnet_plan_tag (a stream's plan replayed across epochs), the encoder's call as one
                                     crossing (tpnet_anchored_features, tpnet_encoder_features, tpnet_host_encoder_features), the targeted
-                                    exchange's plan on the device (tpnet_xplan_targeted) */
+                                    exchange's plan on the device (tpnet_xplan_targeted);
+                               6: + tpnet_mlp::wimg / tpnet_mlp_prepare_image (the encoder's readout and self.mlp in ONE launch on the matrix
+                                    cores), TPNET_FLAG_NO_MFMA_READOUT, tpnet_rows_stream_targeted */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -166,6 +168,10 @@ typedef struct tpnet_mlp {
      * [32 w + (s & 3) + 8 (s >> 2) + 4 (lane >> 5)]  (w = 0..7 hidden tile, t = 0..1 output tile, s = 0..15 k-step) */
     const float* w1;
     const float* w2f;
+    /* optional (NULL: the encoder's calls run readout and dense layers as two launches), F = 64 / H = 256 only: the image
+     * tpnet_mlp_prepare_image writes -- both weight matrices split into two bf16 pieces per value, every 16-byte element the
+     * operand of one lane of one v_mfma_f32_16x16x32_bf16, then b1 and b2 (tpnet_mlp_image_bytes() bytes, 16-byte aligned) */
+    const void* wimg;
 } tpnet_mlp;
 
 /* get_pair_wise_feature INCLUDING self.mlp (models/TPNet.py:112-129) in one launch: the features of tpnet_pair_gram stay
@@ -186,6 +192,11 @@ int tpnet_mlp64_f32(const float* x, int64_t n, const tpnet_mlp* mlp, float* y, v
  * F = 64 / H = 256 (else NULL), w2f in the gathered order tpnet_mlp documents.  b1, b2 and tpnet_mlp::w1 are the Parameters'
  * own storage.  A training loop calls this after every optimizer step (train_link_prediction.py:384-386). */
 int tpnet_mlp_prepare(const float* w1, const float* w2, int32_t F, int32_t H, float* w1t, float* w2t, float* w2f, void* stream);
+/* tpnet_mlp::wimg from the Parameters of self.mlp = Linear(64, 256) -> ReLU -> Linear(256, 64): w1 [256][64], b1 [256], w2 [64][256],
+ * b2 [64] (device, contiguous) -> img (device, tpnet_mlp_image_bytes() bytes), one launch; to be called again whenever a
+ * Parameter changed (the biases are copied into the image too). */
+size_t tpnet_mlp_image_bytes(void);
+int tpnet_mlp_prepare_image(const float* w1, const float* b1, const float* w2, const float* b2, void* img, void* stream);
 
 /* ---- host-array entry points: what the reference's per-batch calls hand over are HOST numpy arrays (models/TPNet.py:
  * 74-77, 107, 117; train_link_prediction.py:359-373).  These variants take host pointers, check the ids on the host
@@ -425,7 +436,10 @@ int tpnet_encoder_rows(const tpnet_state* st, const void* sampler, int64_t E, in
 
 /* The encoder's call INCLUDING self.mlp (models/TPNet.py:311-324, 129; L = 3, rows of one chunk of 16-byte vectors): gram =
  * tpnet_pair_gram_anchored's output [2][n_rows*K][64] (kept: what a backward pass needs), out = mlp(gram) in the fp32 class
- * (tpnet_mlp64_f32's kernel), both on `stream`: the encoder's call as ONE crossing. */
+ * (tpnet_mlp64_f32's kernel), both on `stream`: the encoder's call as ONE crossing.  Where tpnet_encoder_fused_supported
+ * returns 1 (rows of 64 / 128 floats, K >= 4, mlp->wimg given) readout and dense layers are ONE launch on the matrix cores
+ * (csrc/encoder_mfma.hip) and gram may be NULL: the pre-mlp features are then never written. */
+int tpnet_encoder_fused_supported(const tpnet_state* st, int64_t n_rows, int32_t K, const tpnet_mlp* mlp);
 int tpnet_anchored_features(const tpnet_state* st, const int64_t* neigh, const int64_t* a1, const int64_t* a2, int64_t n_rows,
                             int32_t K, double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* gram,
                             float* out, void* stream);

@@ -47,9 +47,15 @@ def _assert_mlp_grads_close(mlp, gram, gy, got, want):
         gh = (gy.double() @ w2).abs() * near                                      # what a flip there moves
         amb_w1 = gh.t() @ x.abs()                                                # [256, 64]
         amb_b1 = gh.sum(0)                                                       # [256]
+        # every gradient is a sum over the n rows formed by an fp32 GEMM: two evaluations (other blocking, features that differ in
+        # their last bits) differ by rounding noise that grows with the sum of the terms' magnitudes, not with the sum itself (long
+        # lists, cancelling sums: 6e-4 on an entry of 30 at 80 000 rows) -- 2e-7 of that sum is added (a missing row would be 1e-5 of it)
+        hid = torch.relu(pre)
+        gha = (gy.double() @ w2).abs() * (pre > 0).double()
+        noise = [gha.t() @ x.abs(), gha.sum(0), gy.double().abs().t() @ hid, gy.double().abs().sum(0)]
     extra = [amb_w1, amb_b1, None, None]
-    for a, b, e in zip(got, want, extra):
-        tol = 1e-4 + 1e-4 * b.abs().double()
+    for a, b, e, nz in zip(got, want, extra, noise):
+        tol = 1e-4 + 1e-4 * b.abs().double() + 2e-7 * nz
         if e is not None:
             tol = tol + e
         assert bool(((a.double() - b.double()).abs() <= tol).all()), float((a.double() - b.double()).abs().max())
@@ -453,7 +459,7 @@ def test_mlp_prepare_layouts_follow_the_parameters():
     rp = _module(50, 128, 3)
     mlp = rp.mlp
     prep = ff.prepared(mlp, 64)
-    w1t, w2t, w2f = prep[3]
+    w1t, w2t, w2f, img = prep[3]
     torch.cuda.synchronize()
     rows, cols = ff._w2f_index(mlp[2].weight.device)
     assert torch.equal(w1t, mlp[0].weight.detach().t()) and torch.equal(w2t, mlp[2].weight.detach().t())
@@ -465,6 +471,28 @@ def test_mlp_prepare_layouts_follow_the_parameters():
     prep2 = ff.prepared(mlp, 64)
     torch.cuda.synchronize()
     assert prep2[3][0].data_ptr() == w1t.data_ptr()        # same buffers, rewritten
+
+    # the weight image of the encoder's one-launch kernel (tpnet_mlp_prepare_image, include/tpnet_hip.h): hi + lo of every element at
+    # the documented operand position reproduces the Parameter to 2^-16, biases behind the four matrices
+    def bf16(a):
+        return (a.astype(np.uint32) << 16).view(np.float32)
+    raw = prep2[3][3].cpu().numpy()
+    w1 = mlp[0].weight.detach().cpu().numpy(); w2 = mlp[2].weight.detach().cpu().numpy()
+    parts = [bf16(raw[o:o + 32768].view(np.uint16)).reshape(-1, 64, 8) for o in (0, 32768, 65536, 98304)]
+    lane = np.arange(64); j = np.arange(8)
+    for w in range(16):
+        for s_ in range(2):
+            want = w1[(16 * w + (lane & 15))[:, None], (32 * s_ + 8 * (lane >> 4))[:, None] + j[None, :]]
+            got = parts[0][w * 2 + s_] + parts[1][w * 2 + s_]
+            assert np.all(np.abs(got - want) <= 2.0 ** -15 * np.abs(want))
+    for k2 in range(8):
+        for t_ in range(4):
+            hid = 16 * (2 * k2 + (j >> 2))[None, :] + 4 * (lane >> 4)[:, None] + (j & 3)[None, :]
+            want = w2[(16 * t_ + (lane & 15))[:, None], hid]
+            got = parts[2][k2 * 4 + t_] + parts[3][k2 * 4 + t_]
+            assert np.all(np.abs(got - want) <= 2.0 ** -15 * np.abs(want))
+    assert np.array_equal(raw[131072:131072 + 1024].view(np.float32), mlp[0].bias.detach().cpu().numpy())
+    assert np.array_equal(raw[132096:132096 + 256].view(np.float32), mlp[2].bias.detach().cpu().numpy())
     assert torch.equal(prep2[3][0], mlp[0].weight.detach().t()) and torch.equal(prep2[3][2], mlp[2].weight.detach()[rows, cols])
     # and the fused forward uses them: against the torch layers on the same features
     rng = np.random.RandomState(0)
@@ -534,3 +562,47 @@ def test_encoder_readout_on_the_matrix_cores(d, K, n):
     assert not np.isnan(got[~exp]).any()
     with pytest.raises(IndexError):
         rp.check_device_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K,n", [(128, 20, 200), (128, 5, 13), (64, 8, 77), (128, 4, 1), (128, 7, 3), (128, 20, 2000)])
+def test_encoder_readout_and_dense_layers_in_one_launch(d, K, n):
+    """The encoder's call (models/TPNet.py:311-324, 129) as ONE launch on the matrix cores (csrc/encoder_mfma.hip, MLP = true:
+    Gram tiles, then self.mlp on their 16 feature rows in the same wave, weights from the prepared image in LDS) against the torch
+    fp32 layers on the vector-ALU readout's features: fp32 class (<= 2e-5 of the output scale), wave shares with an odd number
+    of tiles, lists shorter than one tile pair; with gradients recorded the pre-mlp features are written too, the outputs keep
+    their bits and the gradients of self.mlp's four tensors match autograd on the torch layers."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    from tpnet_amd import _lib
+    rng = np.random.RandomState(K * 17 + d + n)
+    N = 300
+    rp = _module(N, d, 3)
+    for src, dst, t in _stream(rng, N, 150, 3):
+        rp.update(src, dst, t)
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    neigh = rng.randint(0, N, (n, K)).astype(np.int64)
+    neigh[rng.rand(n, K) < 0.2] = 0
+    a1, a2 = rng.randint(1, N, n).astype(np.int64), rng.randint(1, N, n).astype(np.int64)
+    prep = rp._overlapped_mlp()
+    assert prep is not None and _lib.load().tpnet_encoder_fused_supported(rp._st_ref(), n, K, prep[2]) == 1
+    with torch.no_grad():
+        got = rp.get_pair_wise_feature_anchored(dev(neigh), dev(a1), dev(a2))
+        feats = rp.pair_gram_anchored(neigh, a1, a2, matrix_cores=False).view(-1, 64)
+        want = rp.mlp(feats)
+    scale = float(want.abs().max())
+    err = (got - want).abs()
+    assert bool((err <= 2e-5 * scale + 1e-4 * want.abs()).all()), (float(err.max()), scale)
+    # with gradients recorded: same outputs, pre-mlp features kept for the backward pass
+    got2 = rp.get_pair_wise_feature_anchored(dev(neigh), dev(a1), dev(a2))
+    assert got2.requires_grad and torch.equal(got2.detach(), got)
+    gy = torch.from_numpy(rng.randn(*got.shape).astype(np.float32)).cuda()
+    got2.backward(gy)
+    grads = [p.grad.clone() for p in rp.mlp.parameters()]
+    for p in rp.mlp.parameters():
+        p.grad = None
+    ref = rp.mlp(feats)
+    ref.backward(gy)
+    want_g = [p.grad.clone() for p in rp.mlp.parameters()]
+    _assert_mlp_grads_close(rp.mlp, feats, gy, grads, want_g)
+    rp.check_device_errors()

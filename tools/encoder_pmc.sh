@@ -38,6 +38,7 @@ for _ in range(REPS):
     lib.tpnet_pair_gram_anchored(C.byref(st), dn.data_ptr(), d1.data_ptr(), d2.data_ptr(), neigh.shape[0], K, now, lam, 0,
                                  out.data_ptr(), out[n:].data_ptr(), stream)
 with torch.no_grad():
+    for _ in range(REPS): rp.get_pair_wise_feature_anchored(dn, d1, d2)          # readout + dense layers in one launch
     for _ in range(REPS): ff.mlp_f32(rp.mlp, out)
     for _ in range(REPS): rp.get_pair_wise_feature(src[s], dst[s])
 torch.cuda.synchronize()

@@ -5,6 +5,10 @@ import collections, csv, glob, json, os, sys
 O = sys.argv[1]
 KEYS = ("k_pair_gram_anchored", "k_pair_gram", "k_mlp64_x3", "k_pair_feature", "k_encoder_mfma", "k_encoder_gram_mfma")
 def short(name):
+    if "k_encoder_fused" in name:
+        return "k_encoder_fused"
+    if "k_encoder_gram_mfma" in name:
+        return "k_encoder_gram_mfma"
     for k in KEYS:
         if k in name:
             return k

@@ -40,7 +40,7 @@ class PlanTag(C.Structure):
 class Mlp(C.Structure):
     """tpnet_mlp: device arrays of self.mlp in the fused kernel's layout (include/tpnet_hip.h)."""
     _fields_ = [("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2t", C.c_void_p), ("b2", C.c_void_p), ("F", C.c_int32),
-                ("H", C.c_int32), ("w1", C.c_void_p), ("w2f", C.c_void_p)]
+                ("H", C.c_int32), ("w1", C.c_void_p), ("w2f", C.c_void_p), ("wimg", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/tpnet_hip.h declares (tests check this)
@@ -118,6 +118,9 @@ SIGNATURES = {
     "tpnet_check_errors": (C.c_int, [_SP, _P]),
     "tpnet_pair_feature": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp), _P, _P, _P]),
     "tpnet_mlp64_f32": (C.c_int, [_P, C.c_int64, C.POINTER(Mlp), _P, _P]),
+    "tpnet_encoder_fused_supported": (C.c_int, [_SP, C.c_int64, C.c_int32, C.POINTER(Mlp)]),
+    "tpnet_mlp_image_bytes": (C.c_size_t, []),
+    "tpnet_mlp_prepare_image": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "tpnet_mlp_prepare": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "tpnet_stage_create": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(_P)]),
     "tpnet_stage_destroy": (C.c_int, [_P]),

@@ -27,15 +27,25 @@ using namespace tpnet;
 
 extern "C" {
 
+int tpnet_encoder_fused_supported(const tpnet_state* st, int64_t n_rows, int32_t K, const tpnet_mlp* mlp) {
+    if (!st || !st->p0 || !st->q || !st->meta || st->N < 1 || st->d < 1) return 0;
+    return encoder_fused_supported(*st, n_rows, K, mlp) ? 1 : 0;
+}
+
 int tpnet_anchored_features(const tpnet_state* st, const int64_t* neigh, const int64_t* a1, const int64_t* a2, int64_t n_rows,
                             int32_t K, double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* gram,
                             float* out, void* stream) {
     if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L != 3) return TPNET_ERR_BAD_ARG;
-    if (n_rows < 0 || K < 0 || (n_rows > 0 && K > 0 && (!neigh || !a1 || !a2 || !gram || !out || !mlp))) return TPNET_ERR_BAD_ARG;
+    if (n_rows < 0 || K < 0 || (n_rows > 0 && K > 0 && (!neigh || !a1 || !a2 || !out || !mlp))) return TPNET_ERR_BAD_ARG;
     if (n_rows == 0 || K == 0) return TPNET_OK;
     if (flags & TPNET_FLAG_PACKED) return TPNET_ERR_BAD_ARG;
     if (mlp->F != 64 || mlp->H != 256 || !mlp->w1 || !mlp->w2f || !mlp->b1 || !mlp->b2) return TPNET_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(gram) | reinterpret_cast<uintptr_t>(out)) & 15) return TPNET_ERR_BAD_ARG;
+    // readout + dense layers in ONE launch on the matrix cores (encoder_mfma.hip); a runtime that refuses it: two launches below
+    if (!(flags & TPNET_FLAG_NO_MFMA_READOUT) && encoder_fused_supported(*st, n_rows, K, mlp) &&
+        launch_encoder_fused(*st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, mlp, gram, out, (hipStream_t)stream) == TPNET_OK)
+        return TPNET_OK;
+    if (!gram) return TPNET_ERR_BAD_ARG;
     if (!pair_gram_anchored_supported(*st)) return TPNET_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t F = 64;
@@ -51,7 +61,7 @@ int tpnet_encoder_features(const tpnet_state* st, const void* sampler, int64_t E
                            const int64_t* other, const double* t, int64_t B, int32_t K, double now_time, double lambda,
                            uint32_t flags, const tpnet_mlp* mlp, void* scratch, size_t scratch_bytes, float* gram, float* out,
                            void* stream) {
-    if (!st || !sampler || B < 0 || K < 1 || (B > 0 && (!src || !other || !t || !scratch || !gram || !out || !mlp)))
+    if (!st || !sampler || B < 0 || K < 1 || (B > 0 && (!src || !other || !t || !scratch || !out || !mlp)))
         return TPNET_ERR_BAD_ARG;
     if (B == 0) return TPNET_OK;
     // rows + neighbours exactly as tpnet_encoder_gram lays them out in `scratch`
@@ -61,7 +71,7 @@ int tpnet_encoder_features(const tpnet_state* st, const void* sampler, int64_t E
     int64_t* a1 = nodes + 4 * B;
     int64_t* a2 = a1 + 2 * B;
     int64_t* neigh = a2 + 2 * B;
-    if (encoder_generic_readout(*st) && !encoder_mfma_supported(*st, 2 * B, K) && st->L == 3 && !(flags & TPNET_FLAG_PACKED) && mlp->F == 64 && mlp->H == 256 && mlp->w1 &&
+    if (gram && encoder_generic_readout(*st) && !encoder_mfma_supported(*st, 2 * B, K) && st->L == 3 && !(flags & TPNET_FLAG_PACKED) && mlp->F == 64 && mlp->H == 256 && mlp->w1 &&
         mlp->w2f && mlp->b1 && mlp->b2 && !((reinterpret_cast<uintptr_t>(gram) | reinterpret_cast<uintptr_t>(out)) & 15)) {
         // narrow rows: the generic readout on the pair lists the sampler kernel wrote behind the neighbour ids, then the dense layers
         const int64_t half = 2 * B * (int64_t)K;

@@ -148,6 +148,10 @@ int launch_pair_gram_anchored(const tpnet_state& st, const int64_t* neigh, const
 bool encoder_mfma_supported(const tpnet_state& st, int64_t n_rows, int K);
 int launch_encoder_gram_mfma(const tpnet_state& st, const int64_t* neigh, const int64_t* a1, const int64_t* a2, int64_t n_rows,
                              int K, double now, double lambda, uint32_t flags, float* out1, float* out2, hipStream_t s);
+// the same + self.mlp in ONE launch (gram: optional copy of the pre-mlp features [2][n_rows * K][64]; out [2 * n_rows * K][64])
+bool encoder_fused_supported(const tpnet_state& st, int64_t n_rows, int K, const tpnet_mlp* mlp);
+int launch_encoder_fused(const tpnet_state& st, const int64_t* neigh, const int64_t* a1, const int64_t* a2, int64_t n_rows, int K,
+                         double now, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* gram, float* out, hipStream_t s);
 // One launch: readout of batch b (if out_pos/out_neg) on the pre-batch state + update of batch b.
 int launch_step(const tpnet_state& st, const StreamArgs& a, const Plan& p, int64_t b, int64_t batch, int32_t ne,
                 double lambda, uint32_t launch_id, uint32_t flags, hipStream_t s);

@@ -130,14 +130,21 @@ def prepared(mlp, F):
             keep, st = cache[3], cache[1]
         else:
             H = w1.shape[0]
+            x64 = F == 64 and H == 256
             keep = (torch.empty((F, H), dtype=torch.float32, device=w1.device), torch.empty((H, F), dtype=torch.float32, device=w1.device),
-                    torch.empty(F * H, dtype=torch.float32, device=w1.device) if F == 64 and H == 256 else None)
+                    torch.empty(F * H, dtype=torch.float32, device=w1.device) if x64 else None,
+                    # the weight image of the encoder's one-launch readout + dense layers (csrc/encoder_mfma.hip)
+                    torch.empty(int(_lib.load().tpnet_mlp_image_bytes()), dtype=torch.uint8, device=w1.device) if x64 else None)
             st = _lib.Mlp(w1t=keep[0].data_ptr(), b1=b1.data_ptr(), w2t=keep[1].data_ptr(), b2=b2.data_ptr(), F=F, H=H,
                           w1=w1.data_ptr() if keep[2] is not None else None,
-                          w2f=keep[2].data_ptr() if keep[2] is not None else None)
+                          w2f=keep[2].data_ptr() if keep[2] is not None else None,
+                          wimg=keep[3].data_ptr() if keep[3] is not None else None)
         _lib.check(_lib.load().tpnet_mlp_prepare(w1.data_ptr(), w2.data_ptr(), F, w1.shape[0], keep[0].data_ptr(), keep[1].data_ptr(),
                                                  keep[2].data_ptr() if keep[2] is not None else None,
                                                  C.c_void_p(torch.cuda.current_stream(w1.device).cuda_stream)), "mlp_prepare")
+        if keep[3] is not None:
+            _lib.check(_lib.load().tpnet_mlp_prepare_image(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), keep[3].data_ptr(),
+                                                           C.c_void_p(torch.cuda.current_stream(w1.device).cuda_stream)), "mlp_prepare_image")
         cache = (key, st, C.byref(st), keep, (w1, b1, w2, b2), (w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()))
         _PREPARED[mlp] = cache
     return cache

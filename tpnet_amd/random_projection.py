@@ -29,6 +29,10 @@ _MAX_LAUNCH_ID = 0x7FFFFFFF - (1 << 24)
 
 
 # the current stream's raw handle without building a torch.cuda.Stream object (the hot methods need it every call)
+def _ptr_or_null(t):
+    return t.data_ptr() if t is not None else None
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
 
 
@@ -723,12 +727,12 @@ class RandomProjectionModule(nn.Module):
         def launch(gram):
             out = torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"])
             _lib.check(lib.tpnet_anchored_features(self._st_ref(), wd.data_ptr(), a1.data_ptr(), a2.data_ptr(), m, K, self._now_host,
-                                                   float(self.time_decay_weight), flags, prep[2], gram.data_ptr(), out.data_ptr(),
+                                                   float(self.time_decay_weight), flags, prep[2], _ptr_or_null(gram), out.data_ptr(),
                                                    _raw_stream(self._eng["dev_index"])), "anchored_features")
             return out
         if _ff.needs_grad(prep[4]):
             return _ff.apply_with_grad(self.mlp, launch, n, NG)
-        return launch(torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"]))
+        return launch(self._gram_buffer(m, K, prep, n, NG))
 
     def pair_gram_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids, matrix_cores=True):
         """The encoder's readout before self.mlp (models/TPNet.py:311-324): neighbor_ids [n, K] (the sampled neighbours of n
@@ -764,6 +768,13 @@ class RandomProjectionModule(nn.Module):
                                                 out[1].data_ptr(), self._stream()), "pair_gram_anchored")
         return out
 
+    def _gram_buffer(self, n_rows, K, prep, n, NG):
+        """Where the pre-mlp features of an encoder call go when no backward pass needs them: nowhere (None) if readout and dense
+        layers are ONE launch (tpnet_encoder_fused_supported), else a scratch tensor between the two launches."""
+        if _lib.load().tpnet_encoder_fused_supported(self._st_ref(), n_rows, K, prep[2]):
+            return None
+        return torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"])
+
     def _overlapped_mlp(self):
         """The prepared fp32 weights of self.mlp if the encoder's one-call path applies (readout chunks and their dense layers side
         by side, tpnet_anchored_features): L = 3, the reference's Linear-ReLU-Linear on this GPU, not the opt-in bf16 layers."""
@@ -791,12 +802,12 @@ class RandomProjectionModule(nn.Module):
                     out = torch.empty((2 * n * K, NG), dtype=torch.float32, device=self._eng["dev"])
                     _lib.check(lib.tpnet_anchored_features(self._st_ref(), wd.data_ptr(), a1.data_ptr(), a2.data_ptr(), n, K,
                                                            self._now_host, float(self.time_decay_weight), flags, prep[2],
-                                                           gram.data_ptr(), out.data_ptr(), _raw_stream(self._eng["dev_index"])),
+                                                           _ptr_or_null(gram), out.data_ptr(), _raw_stream(self._eng["dev_index"])),
                                "anchored_features")
                     return out
                 if _ff.needs_grad(prep[4]):
                     return _ff.apply_with_grad(self.mlp, launch, 2 * n * K, NG)
-                return launch(torch.empty((2 * n * K, NG), dtype=torch.float32, device=self._eng["dev"]))
+                return launch(self._gram_buffer(n, K, prep, 2 * n * K, NG))
         g = self.pair_gram_anchored(neighbor_ids, first_anchor_ids, second_anchor_ids)
         return self._apply_mlp(g.view(-1, self.pair_wise_feature_dim))
 
@@ -842,18 +853,18 @@ class RandomProjectionModule(nn.Module):
                     _lib.check(lib.tpnet_host_encoder_features(
                         self._st_ref(), self._eng["stage"].handle, sampler._buf.data_ptr(), sampler.E, sampler.num_nodes,
                         src_ids.ctypes.data, other_ids.ctypes.data, times.ctypes.data, B, K, self._now_host,
-                        float(self.time_decay_weight), flags, prep[2], scratch.data_ptr(), nbytes, gram.data_ptr(), out.data_ptr(),
+                        float(self.time_decay_weight), flags, prep[2], scratch.data_ptr(), nbytes, _ptr_or_null(gram), out.data_ptr(),
                         _raw_stream(self._eng["dev_index"])), "host_encoder_features")
                     return out
                 _lib.check(lib.tpnet_encoder_features(self._st_ref(), sampler._buf.data_ptr(), sampler.E, sampler.num_nodes,
                                                       src_ids.data_ptr(), other_ids.data_ptr(), times.data_ptr(), B, K,
                                                       self._now_host, float(self.time_decay_weight), flags, prep[2],
-                                                      scratch.data_ptr(), nbytes, gram.data_ptr(), out.data_ptr(),
+                                                      scratch.data_ptr(), nbytes, _ptr_or_null(gram), out.data_ptr(),
                                                       _raw_stream(self._eng["dev_index"])), "encoder_features")
                 return out
             if _ff.needs_grad(prep[4]):
                 return _ff.apply_with_grad(self.mlp, launch, 4 * B * K, NG), neigh
-            return launch(torch.empty((4 * B * K, NG), dtype=torch.float32, device=dev)), neigh
+            return launch(self._gram_buffer(2 * B, K, prep, 4 * B * K, NG)), neigh
         if host:
             s_d, o_d, t_d = self._to_device(self._check_ids(src_ids, "src_ids"), self._check_ids(other_ids, "other_ids"), times)
             return self.encoder_pair_features(sampler, s_d, o_d, t_d, num_neighbors)
