@@ -752,9 +752,9 @@ def main():
             lr = roof_pass(*args_r)
             lr["value"] = Kr * B / (lr["stream_ms_events"] * 1e-3)
             lr["unit"] = "edges/s (HIP events around the whole call: planning and write-back included)"
-            # the longest stream that is ONE chunk (64 windows of 24 batches), run again after a reset: the plan is replayed
+            # the longest stream that is ONE chunk (256 windows of 24 batches / 16 GiB of version log), run again after a reset: the plan is replayed
             kwin = max(2, min(64, 24576 // B))                       # batches per window of a long stream
-            Kc = min(Kr, min(64, ((4 << 30) // (2 * L * d * 4)) // (kwin * B)) * kwin)       # 64 windows, or what 4 GiB of version log hold
+            Kc = min(Kr, min(256, ((16 << 30) // (2 * L * d * 4)) // (kwin * B)) * kwin)     # 256 windows, or what 16 GiB of version log hold
             slc = slice(W * Bg, (W + Kc) * Bg)
             bpe = bytes_per_edge(d, L)
 

@@ -245,13 +245,13 @@ size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch);
 
 /* Workspace for tpnet_run_stream on a table of N rows x d columns x L layers and a stream of up to max_edges edges: the
  * larger of the per-batch plan (capped at a chunk of ~2 M edges; longer streams are walked chunk by chunk) and what the
- * WINDOWED schedule needs: its plan + a version log of 2*L*d*4 bytes per edge of a chunk (at most 4 GiB).  With at
+ * WINDOWED schedule needs: its plan + a version log of 2*L*d*4 bytes per edge of a chunk (at most 16 GiB).  With at
  * least this much, tpnet_run_stream runs a stream of small batches (<= 4096 edges, d % 4 == 0) as a software pipeline
  * over windows of batches -- one launch per window carrying one layer of the update for each of L consecutive windows
  * plus the readouts of the window behind them -- instead of one launch per batch; with less it falls back to per-batch
  * launches.  The two schedules differ in f32 summation order only (both within 1e-4 of the reference). */
 size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch);
-/* The same with the version log of a chunk capped at log_cap_bytes (0 = the library's 4 GiB): the windowed schedule costs
+/* The same with the version log of a chunk capped at log_cap_bytes (0 = the library's 16 GiB): the windowed schedule costs
  * 2*L*d*4 bytes of log per edge of a chunk (C2: 3 KB per edge, 484 MB for one Wikipedia epoch) plus ~0.5 KB per edge of plan; a
  * caller short of memory trades chunk length (more pipeline fills and drains) for workspace.  tpnet_run_stream takes whatever
  * chunk the workspace it is given holds. */

@@ -1009,7 +1009,8 @@ def test_three_launch_planner_equals_chunk_planner(d, L, N, B, nb):
             m.check_device_errors()
 
 
-@pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 400, 64, 50), (64, 2, 3000, 200, 30), (128, 3, 9000, 1000, 20)])
+@pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 400, 64, 50), (64, 2, 3000, 200, 30), (128, 3, 9000, 1000, 20),
+                                        (64, 3, 2000, 100, 2048)])     # (2 048 batches: 86 windows, ONE chunk -- replayed too)
 def test_plan_replay_across_epochs(d, L, N, B, nb):
     """train_link_prediction.py:234-253: every epoch resets the projections and runs the SAME stream with new negatives.
     The second epoch replays the first one's plan (only the negatives' readout references are formed again) and gives the

@@ -6,7 +6,7 @@
 // -- the 2 : 1 read : write mix of profiles/r03_C4.md (131 MB read + 66 MB written per 10 000-edge launch).  Node ids are hashed
 // (uniform), every row access is an HBM miss as at C4.  What it answers: the rate the memory system gives THIS mix at this
 // launch size, to hold k_step's 4.3 TB/s against (the guide's 5.5-5.8 TB/s is for pure reads).
-//   usage: c4_mix_probe [units=10000] [reps=40] [block=256] [inflight=12|6|4] [nt_store=0|1] [nt_load=0|1] [grid_cap=0]
+//   usage: c4_mix_probe [units=10000] [reps=40] [block=256] [inflight=12|6|4] [nt_store=0|1] [nt_load=0|1] [grid_cap=0] [N=10000000] [meta=0|1]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -33,9 +33,10 @@ __device__ __forceinline__ void st(v4f* p, v4f v) {
 }
 
 // INFL = 1 KB rows in flight per group before they are summed: 12 (a whole unit), 6 or 4
-template <int INFL, bool NTS, bool NTL>
+// META: every node's current copy comes from a 32-byte per-node record (a dependent random read in front of the rows, as in k_step)
+template <int INFL, bool NTS, bool NTL, bool META = false>
 __global__ void k_mix(const float* __restrict__ p0, float* __restrict__ q, float* __restrict__ feat, int64_t N, int64_t units,
-                      uint64_t seed) {
+                      uint64_t seed, const uint4* __restrict__ meta = nullptr) {
     const int gl = threadIdx.x & 31;
     const int64_t gpb = blockDim.x / 32;
     for (int64_t u = (int64_t)blockIdx.x * gpb + threadIdx.x / 32; u < units; u += (int64_t)gridDim.x * gpb) {
@@ -46,6 +47,13 @@ __global__ void k_mix(const float* __restrict__ p0, float* __restrict__ q, float
             const uint64_t h = mix64(seed + (uint64_t)u * 3 + k);
             node[k] = (int64_t)(h % (uint64_t)N);
             cur[k] = (int)((h >> 40) & 1);
+        }
+        if constexpr (META) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint4 m = meta[node[k] * 2];
+                cur[k] = (int)((m.x + (uint32_t)cur[k]) & 1u);
+            }
         }
         // the 12 rows of the unit: row r = (node r / 4, layer r % 4); layer 0 in p0, layers 1..3 in the node's bundle
         const v4f* rp[12];
@@ -92,7 +100,8 @@ __global__ void k_mix(const float* __restrict__ p0, float* __restrict__ q, float
 
 template <int INFL>
 static void launch(bool nts, bool ntl, int grid, int block, hipStream_t s, const float* p0, float* q, float* feat, int64_t N, int64_t units,
-                   uint64_t seed) {
+                   uint64_t seed, const uint4* meta) {
+    if (meta) { hipLaunchKernelGGL((k_mix<INFL, false, false, true>), dim3(grid), dim3(block), 0, s, p0, q, feat, N, units, seed, meta); return; }
     if (nts && ntl) hipLaunchKernelGGL((k_mix<INFL, true, true>), dim3(grid), dim3(block), 0, s, p0, q, feat, N, units, seed);
     else if (nts) hipLaunchKernelGGL((k_mix<INFL, true, false>), dim3(grid), dim3(block), 0, s, p0, q, feat, N, units, seed);
     else if (ntl) hipLaunchKernelGGL((k_mix<INFL, false, true>), dim3(grid), dim3(block), 0, s, p0, q, feat, N, units, seed);
@@ -108,12 +117,15 @@ int main(int argc, char** argv) {
     const bool ntl = argc > 6 ? atoi(argv[6]) != 0 : false;
     const int grid_cap = argc > 7 ? atoi(argv[7]) : 0;
     const int64_t N = argc > 8 ? atoll(argv[8]) : 10000000;
+    const bool use_meta = argc > 9 ? atoi(argv[9]) != 0 : false;
     float *p0, *q, *feat;
     CK(hipMalloc(&p0, (size_t)N * 1024));
     CK(hipMalloc(&q, (size_t)N * 3072 * 2));
     CK(hipMalloc(&feat, (size_t)units * 512));
     CK(hipMemset(p0, 0, (size_t)N * 1024));
     CK(hipMemset(q, 0, (size_t)N * 3072 * 2));
+    uint4* meta = nullptr;
+    if (use_meta) { CK(hipMalloc(&meta, (size_t)N * 32)); CK(hipMemset(meta, 0, (size_t)N * 32)); }
     CK(hipDeviceSynchronize());
     const int gpb = block / 32;
     int grid = (int)((units + gpb - 1) / gpb);
@@ -124,9 +136,9 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     auto run = [&](uint64_t seed) {
-        if (infl == 12) launch<12>(nts, ntl, grid, block, s, p0, q, feat, N, units, seed);
-        else if (infl == 6) launch<6>(nts, ntl, grid, block, s, p0, q, feat, N, units, seed);
-        else launch<4>(nts, ntl, grid, block, s, p0, q, feat, N, units, seed);
+        if (infl == 12) launch<12>(nts, ntl, grid, block, s, p0, q, feat, N, units, seed, meta);
+        else if (infl == 6) launch<6>(nts, ntl, grid, block, s, p0, q, feat, N, units, seed, meta);
+        else launch<4>(nts, ntl, grid, block, s, p0, q, feat, N, units, seed, meta);
     };
     for (int i = 0; i < 5; ++i) run(1000 + i);
     CK(hipStreamSynchronize(s));
@@ -138,6 +150,7 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps;
     const double rd = (double)units * 12288.0, wr = (double)units * (6144.0 + 512.0);
+    if (use_meta) printf("[dependent 32-byte meta read per node] ");
     printf("units %lld block %d grid %d inflight %d nt_store %d nt_load %d: %.2f us per launch, read %.1f MB + written %.1f MB -> %.2f TB/s "
            "(read side %.2f, write side %.2f)\n", (long long)units, block, grid, infl, (int)nts, (int)ntl, us, rd / 1e6, wr / 1e6,
            (rd + wr) / us / 1e6, rd / us / 1e6, wr / us / 1e6);

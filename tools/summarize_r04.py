@@ -18,7 +18,7 @@ def main(cfg):
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     lines = [f"# rocprofv3 summary, {cfg} ({c['desc']}, L=3), round 4 (commit {commit})", ""]
     entries = []
-    for mode, what in (("timed20", "the driver's 20 timed batches (one run_stream call, schedule "auto")"),
+    for mode, what in (("timed20", "the driver's 20 timed batches (one run_stream call, schedule auto)"),
                        ("epoch", f"ONE epoch of the config's own stream ({c['E']} edges), cold plan"),
                        ("long", "2 048 batches of the stream (the long-stream regime)"),
                        ("batch", "a run of full batches (batches of 10 000 edges take the per-batch kernel)"),

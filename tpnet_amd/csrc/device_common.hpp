@@ -57,6 +57,15 @@ static constexpr int BLOCK_SMALL = TPNET_BLOCK_SMALL;
 constexpr int min_waves_per_simd(int lpp, int vpl, int w) {
     return (w != 4) ? 2 : (lpp < 16) ? 4 : (lpp == 16 && vpl == 1) ? TPNET_MINW16 : (lpp == 32 && vpl == 1) ? TPNET_MINW32 : 2;
 }
+// the 256-thread step kernel on rows of 256 floats (32 lanes x 2 vectors: C3, C4) compiles to 173 VGPRs -- five registers above
+// what three waves per SIMD allow (168), so a CU held 8 waves = 16 units in flight; C4 is bound by (units in flight) x (bytes
+// per unit) / (latency of a unit's three dependent round trips), see profiles/r04_C4.md
+#ifndef TPNET_MINW_WIDE256
+#define TPNET_MINW_WIDE256 3
+#endif
+constexpr int step_min_waves(int lpp, int vpl, int w, int bs) {
+    return (w == 4 && lpp == 32 && vpl == 2 && bs == BLOCK_SMALL) ? TPNET_MINW_WIDE256 : min_waves_per_simd(lpp, vpl, w);
+}
 static constexpr int HEAVY_BLOCKS_SMALL = 48, HEAVY_BLOCKS_LARGE = 128;
 
 // ---------------------------------------------------------------------------------------------------------------

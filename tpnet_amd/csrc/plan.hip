@@ -941,7 +941,10 @@ uint32_t wplan_heavy_threshold(int K, int64_t batch, int d) {
 
 int64_t wplan_max_chunk_edges(int64_t batch, int d, int L) {
     static const char* env = TPNET_DEV_STR(WIN_CHUNK_MB);
-    const int64_t log_cap = (env ? (int64_t)atoi(env) : 4096) << 20;         // bytes of version log per chunk (C2: 1 GiB 4.6 us per batch, 4 GiB 4.1: fewer pipeline drains)
+    // bytes of version log per chunk (C2: 1 GiB 4.6 us per batch, 4 GiB 4.1: fewer pipeline drains).  16 GiB since round 4 (4 until
+    // then): a plan is replayed across epochs only where the stream is ONE chunk, and on a GPU with 288 GB the log of every dataset
+    // of the reference fits one (C2 rows: 5.6 M edges per chunk; a caller short of memory caps it: tpnet_stream_workspace_bytes_capped)
+    const int64_t log_cap = (env ? (int64_t)atoi(env) : 16384) << 20;
     int64_t e = log_cap / (2 * (int64_t)L * d * 4);
     const int64_t hard = (int64_t)(WREF_SLOT_MASK >> 1);                     // slots are 26-bit sorted positions
     if (e > hard) e = hard;

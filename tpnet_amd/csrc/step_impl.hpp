@@ -28,7 +28,7 @@ template <int LPP, int VPL, int W, int L, bool FULL, bool NT, int BS, bool FUSE>
 // exist) lead the signature as plain scalars: the first 16 SGPRs of kernel arguments are preloaded by the command
 // processor at wave launch (-mllvm -amdgpu-kernarg-preload-count=16), so the role of a wave is decided and its id / item
 // loads are issued without waiting for a kernarg fetch.
-__global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
+__global__ __launch_bounds__(BS, step_min_waves(LPP, VPL, W, BS)) void k_step(const int64_t* __restrict__ a_src, const int64_t* __restrict__ a_dst,
                                                 const int64_t* __restrict__ a_neg, const Item* __restrict__ items,
                                                 const Item* __restrict__ heavy, uint32_t e0_, int32_t ne_,
                                                 uint32_t flags, int HEAVY_BLOCKS, uint32_t bid, double lambda,
@@ -39,6 +39,10 @@ __global__ __launch_bounds__(BS, min_waves_per_simd(LPP, VPL, W)) void k_step(co
     constexpr int NG = GramCfg<LPP, L>::NG;
     constexpr int STG = GramCfg<LPP, L>::template stage_floats<BS>();
     __shared__ float part[(VPL * W * BS > STG) ? VPL * W * BS : STG];   // heavy items' partial sums / readout staging
+    // (round 4, measured and not kept: the multi-pass launches' NEXT pair fetched ahead -- its ids two passes early into registers,
+    // its two meta records one pass early straight into LDS with global_load_lds_dwordx4, so that a pass starts with its row loads:
+    // bit-identical results, but the kernel sits at the 168 registers three waves per SIMD allow, the pipeline's state spilled
+    // 17 of them, and a batch of 10 000 edges took 52.4 us instead of 46.5 on the C4 table, 40.4 instead of 32.6 at C3)
     unsigned long long* dbg = p.dbg;
     (void)dbg;
     STAMP(0);
