@@ -502,10 +502,11 @@ def main():
             s_, d_, n_, t_, op_, on_, te_, sched = pre if pre is not None else prep(a, b_)
             rp.run_stream(s_, d_, n_, t_, Bg, out_pos=op_, out_neg=on_, t_end=te_, schedule=sched, replay=False)
         # a short timed region (the driver's 20 steps are ~150 us) is ONE sample of a quantity that scatters by 10-20 % with the
-        # state the process and the GPU's clocks are in: up to 64 steps the region is measured three times in this process -- each
+        # state the process and the GPU's clocks are in: up to 64 steps the region is measured five times in this process -- each
         # time from a reset table: W warm-up steps, then the K timed steps -- and `value` is the median; the first region's number
-        # stays beside it (`first_region`)
-        n_regions = 3 if K <= 64 else 1
+        # stays beside it (`first_region`: the first timed call of a process is 25-40 us slower than every later one, eight runs of
+        # the driver's line in profiles/r04_driver_line_runs.md)
+        n_regions = 5 if K <= 64 else 1
         regions = []
         for r_ in range(n_regions):
             if r_ > 0:

@@ -23,6 +23,16 @@ static constexpr int WB = 256;            // threads per workgroup of both kerne
 #ifndef TPNET_WPIPE_MINW
 #define TPNET_WPIPE_MINW 4
 #endif
+// waves per SIMD the pipeline kernel is built for, per geometry: what the compiler reaches (a clean build has no -Wpass-failed).
+// Narrow rows (<= 32 lanes x 1 vector) fit four; rows of 256 / 512 floats hold their 2 (L + 1) row fragments and the Gram's
+// partial sums in 170-256 registers: three waves for exact-fit rows of up to 256 floats (L <= 3 on 32 x 2), two otherwise --
+// those launches run at 0.57-0.58 of 8 TB/s on the memory side, where the plain copy is (profiles/r04_C3.md, r04_C5.md)
+constexpr int wpipe_min_waves(int lpp, int vpl, int l, bool full) {
+    return (lpp <= 32 && vpl == 1) ? TPNET_WPIPE_MINW
+         : (lpp == 32 && vpl == 2) ? ((full && l <= 3) ? 3 : 2)
+         : (lpp == 64 && vpl == 1) ? (full ? 3 : 2)
+         : 2;
+}
 
 // g^n by repeated multiplication, as the per-batch kernels form the layers' decay (update.hpp: gu[i] = gu[i-1] * g)
 __device__ __forceinline__ float pow_rep(float g, int n) {
@@ -721,7 +731,7 @@ __device__ __forceinline__ uint32_t hub_chains(const WStep& st, const WinDesc& w
 // RS: the readout takes the 16-lane x 2-vector geometry while the chains keep 32 lanes x 1 vector (rows of 17..32 vectors:
 // a long list of independent pairs wants four pairs per wave, a chain wants a contribution per lane and round)
 template <int LPP, int VPL, int L, bool FULL, bool RS>
-__global__ __launch_bounds__(WB, TPNET_WPIPE_MINW) void k_wpipe(tpnet_state S, WPlan P, StreamArgs a, WStep st, int64_t Ec, int64_t B,
+__global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpipe(tpnet_state S, WPlan P, StreamArgs a, WStep st, int64_t Ec, int64_t B,
                                               double lambda, uint32_t flags) {
     constexpr int W = 4;
     constexpr int LPH = heavy_lph(LPP, VPL);
