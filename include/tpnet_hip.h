@@ -480,6 +480,11 @@ int tpnet_mlp64_bf16(const float* x, int64_t n, const void* w1_bf16, const float
 int64_t tpnet_mlp64_bwd_partial_floats(void);
 int tpnet_mlp64_bwd_bf16(const float* x, const float* gy, int64_t n, const void* w1_bf16, const float* b1,
                          const void* w2t_bf16, float* partial, int32_t n_partial, void* stream);
+/* The same backward in the fp32 class of the default forward paths (round 4): every operand in two bf16 pieces, every product as
+ * lo*hi + hi*lo + hi*hi with fp32 accumulation; weights from the f32 layouts of `mlp` (mlp->w1 = mlp[0].weight [256][64], mlp->w2t =
+ * mlp[2].weight transposed [256][64], mlp->b1).  Same partial layout and return value as tpnet_mlp64_bwd_bf16. */
+int tpnet_mlp64_bwd_f32(const float* x, const float* gy, int64_t n, const tpnet_mlp* mlp, float* partial, int32_t n_partial,
+                        void* stream);
 
 /* get_pair_wise_feature with self.mlp on the bf16 matrix cores INSIDE the readout kernel (L = 3, d % 4 == 0 and d >= 64):
  * 8 waves form the features of 32 pairs into an LDS tile, which is the B operand of layer 1; wave w owns hidden units

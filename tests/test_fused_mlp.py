@@ -254,3 +254,70 @@ def test_mlp_backward_on_the_matrix_cores_is_exact_on_integers():
         for a, b, c, name in zip(got, want, again, ("gW1", "gb1", "gW2", "gb2")):
             assert torch.equal(a, c), name
             assert torch.equal(a, b), f"{name}, n={n}: max |delta| {(a - b).abs().max().item()}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [33, 5000, 80000])
+def test_mlp_backward_in_the_fp32_class(n):
+    """tpnet_mlp64_bwd_f32 (csrc/mlp_bwd.hip, F32 = true: two-piece bf16 operands, three products, fp32 accumulation; one partial
+    per workgroup, summed in a fixed order) against the float64 expressions of the gradients of self.mlp's four tensors
+    (models/TPNet.py:64-65): within 4e-5 of the sum of the terms' magnitudes (two-piece operands: 2^-16 per product, in the
+    recomputed hidden layer and in the contraction over the rows; observed 3-5e-6), ReLU flips at pre-activations that are zero
+    up to rounding allowed for; run-to-run identical bits; through autograd the module's
+    long calls take it (fused_feature.weight_grads_f32) and short ones the torch expressions."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    import ctypes as C
+    from tpnet_amd import _lib, fused_feature as ff
+    torch.manual_seed(n)
+    mlp = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64)).cuda()
+    x = torch.rand(n, 64, device="cuda") * 9.0
+    x[:, 5] = 0.0
+    gy = torch.randn(n, 64, device="cuda")
+    prep = ff.prepared(mlp, 64)
+    lib = _lib.load()
+    pf = int(lib.tpnet_mlp64_bwd_partial_floats())
+    nblk = min(256, (n + 31) // 32)
+    outs = []
+    for _ in range(2):
+        part = torch.empty((nblk, pf), device="cuda")
+        rc = lib.tpnet_mlp64_bwd_f32(x.data_ptr(), gy.data_ptr(), n, prep[2], part.data_ptr(), nblk,
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == nblk
+        outs.append(part.sum(0))
+    assert torch.equal(outs[0], outs[1])
+    tot = outs[0].double()
+    gw1, gw2, gb1 = tot[:256 * 64].view(256, 64), tot[256 * 64:2 * 256 * 64].view(64, 256), tot[2 * 256 * 64:]
+    w1, b1, w2 = mlp[0].weight.detach().double(), mlp[0].bias.detach().double(), mlp[2].weight.detach().double()
+    xd, gd = x.double(), gy.double()
+    pre = xd @ w1.t() + b1
+    on = (pre > 0).double()
+    hid = pre * on
+    gh = (gd @ w2) * on
+    near = (pre.abs() < 1e-4 * (1.0 + xd.abs().max())).double()           # a flip there moves row `unit` of the first layer's gradients
+    gha = (gd @ w2).abs()
+    # magnitudes the rounding of the recomputed operands scales with: gH = W2^T gY and H = relu(W1 x + b1) are themselves sums whose
+    # error goes with the sum of their terms' magnitudes (a hidden unit that is barely on has a small H and a full-size error)
+    ghm = (gd.abs() @ w2.abs()) * on
+    hm = (xd.abs() @ w1.abs().t() + b1.abs()) * on
+    checks = [(gw1, gh.t() @ xd, ghm.t() @ xd.abs(), (gha * near).t() @ xd.abs()),
+              (gb1, gh.sum(0), ghm.sum(0), (gha * near).sum(0)),
+              (gw2, gd.t() @ hid, gd.abs().t() @ hm, gd.abs().t() @ (pre.abs() * near))]
+    for got, want, mag, amb in checks:
+        tol = 4e-5 * mag + amb + 1e-6 * float(want.abs().max())
+        assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+    # through autograd: mlp_f32 on a long list takes the kernel, and agrees with the torch layers' autograd
+    for p in mlp.parameters():
+        p.grad = None
+    y = ff.mlp_f32(mlp, x)
+    y.backward(gy)
+    g_mod = [p.grad.clone().double() for p in mlp.parameters()]
+    for p in mlp.parameters():
+        p.grad = None
+    mlp(x).backward(gy)
+    g_ref = [p.grad.clone().double() for p in mlp.parameters()]
+    zero = torch.zeros(64, device="cuda", dtype=torch.float64)
+    mags = [(checks[0][2], checks[0][3]), (checks[1][2], checks[1][3]), (checks[2][2], checks[2][3]), (gd.abs().sum(0), zero)]
+    for a, b, (m, amb) in zip(g_mod, g_ref, mags):
+        # (both sides may flip a ReLU at a zero pre-activation against the float64 evaluation, each its own way: twice the budget)
+        assert bool(((a - b).abs() <= 5e-5 * m + 2 * amb + 1e-5).all()), float(((a - b).abs() / (5e-5 * m + 2 * amb + 1e-5)).max())

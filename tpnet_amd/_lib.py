@@ -109,6 +109,7 @@ SIGNATURES = {
     "tpnet_mlp64_bf16": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "tpnet_mlp64_bwd_partial_floats": (C.c_int64, []),
     "tpnet_mlp64_bwd_bf16": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, _P]),
+    "tpnet_mlp64_bwd_f32": (C.c_int, [_P, _P, C.c_int64, C.POINTER(Mlp), _P, C.c_int32, _P]),
     "tpnet_pair_feature_bf16": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, _P, _P, _P, _P, _P, _P,
                                           _P]),
     "tpnet_gather_elems": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_double, C.c_double, _P, _P]),

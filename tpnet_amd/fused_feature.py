@@ -52,11 +52,43 @@ def _w2f_cols(dev):
     return _w2f_index(dev)[1]
 
 
+# rows from which the matrix-core backward serves a call (below, the five torch GEMMs are small and as fast)
+MFMA_BWD_FROM = 4096
+
+
+def weight_grads_f32(x, gy, w1, b1, w2, prep):
+    """Gradients of (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias) given the pre-mlp features x [n, 64] and the gradient
+    gy [n, 64] of self.mlp's output, fp32 class.  Long lists (the encoder's calls: 80 000 rows each at C2) take ONE launch on the
+    matrix cores (tpnet_mlp64_bwd_f32: hidden layer recomputed, both weight-gradient products contracted over the rows with
+    two-piece bf16 operands and fp32 accumulation, one partial result per workgroup, summed in a fixed order) instead of five
+    fp32 GEMMs and three elementwise passes over n x 256 floats; `prep` = the prepared() entry the forward used -- if a Parameter
+    changed since (never in a normal training step), or for short lists and CPU tensors, the torch expressions serve."""
+    n = int(x.shape[0])
+    if (prep is not None and x.is_cuda and n >= MFMA_BWD_FROM and x.dtype == torch.float32 and prep[1].w1 and prep[1].w2t
+            and prep[0][:6] == (w1.data_ptr(), w1._version, b1.data_ptr(), b1._version, w2.data_ptr(), w2._version)):
+        lib = _lib.load()
+        x = x.contiguous()
+        gy = gy.contiguous().float()
+        pf = int(lib.tpnet_mlp64_bwd_partial_floats())
+        nblk = min(256, (n + 31) // 32)
+        part = torch.empty((nblk, pf), dtype=torch.float32, device=x.device)
+        rc = lib.tpnet_mlp64_bwd_f32(x.data_ptr(), gy.data_ptr(), n, prep[2], part.data_ptr(), nblk,
+                                     C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc > 0:
+            tot = part[:rc].sum(0)
+            H, F = w1.shape
+            return tot[:H * F].view(H, F), tot[2 * H * F:2 * H * F + H], tot[H * F:2 * H * F].view(F, H), gy.sum(0)
+    pre = torch.addmm(b1, x, w1.t())                 # fp32 recompute of the hidden layer
+    hid = torch.relu(pre)
+    gh = (gy @ w2) * (pre > 0)
+    return gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0)
+
+
 class _MlpF32(torch.autograd.Function):
-    """self.mlp alone on the fp32 matrix cores (tpnet_mlp64_f32); backward = the fp32 torch expressions."""
+    """self.mlp alone on the fp32 matrix cores (tpnet_mlp64_f32); backward = weight_grads_f32."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, mlp_ref):
+    def forward(ctx, x, w1, b1, w2, b2, mlp_ref, prep=None):
         x = x.contiguous()
         y = torch.empty_like(x)
         if x.shape[0]:
@@ -65,16 +97,19 @@ class _MlpF32(torch.autograd.Function):
             if rc:
                 _lib.check(rc, "mlp64_f32")
         ctx.save_for_backward(x, w1, b1, w2)
+        ctx.prep = prep
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w1, b1, w2 = ctx.saved_tensors
-        pre = torch.addmm(b1, x, w1.t())
-        hid = torch.relu(pre)
-        gh = (gy @ w2) * (pre > 0)
-        gx = gh @ w1 if ctx.needs_input_grad[0] else None     # (the readout's features carry no gradient; a caller's own x may)
-        return gx, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None
+        if ctx.needs_input_grad[0]:                            # (the readout's features carry no gradient; a caller's own x may)
+            pre = torch.addmm(b1, x, w1.t())
+            hid = torch.relu(pre)
+            gh = (gy @ w2) * (pre > 0)
+            return gh @ w1, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None, None
+        gw1, gb1, gw2, gb2 = weight_grads_f32(x, gy, w1, b1, w2, ctx.prep)
+        return None, gw1, gb1, gw2, gb2, None, None
 
 
 def mlp_f32(mlp, x):
@@ -85,7 +120,7 @@ def mlp_f32(mlp, x):
     if prep is None or not prep[1].w1:
         return None
     if needs_grad(prep[4]):
-        return _MlpF32.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, prep[2])
+        return _MlpF32.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, prep[2], prep)
     return _MlpF32.forward(_NoCtx(), x, None, None, None, None, prep[2])
 
 
@@ -154,23 +189,18 @@ class _FusedFeature(torch.autograd.Function):
     """forward(w1, b1, w2, b2, launch): `launch(out_gram)` enqueues the fused kernel and returns the features."""
 
     @staticmethod
-    def forward(ctx, w1, b1, w2, b2, launch, n, F):
+    def forward(ctx, w1, b1, w2, b2, launch, n, F, prep=None):
         gram = torch.empty((n, F), dtype=torch.float32, device=w1.device)
         out = launch(gram)
         ctx.save_for_backward(gram, w1, b1, w2)
+        ctx.prep = prep
         return out
 
     @staticmethod
     def backward(ctx, gy):
         x, w1, b1, w2 = ctx.saved_tensors
-        pre = torch.addmm(b1, x, w1.t())                 # fp32 recompute of the hidden layer
-        hid = torch.relu(pre)
-        gw2 = gy.t() @ hid
-        gb2 = gy.sum(0)
-        gh = (gy @ w2) * (pre > 0)
-        gw1 = gh.t() @ x
-        gb1 = gh.sum(0)
-        return gw1, gb1, gw2, gb2, None, None, None
+        gw1, gb1, gw2, gb2 = weight_grads_f32(x, gy, w1, b1, w2, ctx.prep)
+        return gw1, gb1, gw2, gb2, None, None, None, None
 
 
 def needs_grad(keep_params) -> bool:
@@ -178,4 +208,4 @@ def needs_grad(keep_params) -> bool:
 
 
 def apply_with_grad(mlp, launch, n, F):
-    return _FusedFeature.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n, F)
+    return _FusedFeature.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n, F, _PREPARED.get(mlp))
