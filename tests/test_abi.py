@@ -204,3 +204,26 @@ def test_plan_tag_layout(hip_lib):
     from tpnet_amd import _lib
     assert ctypes.sizeof(_lib.PlanTag) == 23 * 8
     assert _lib.PlanTag.built.offset == 24
+
+
+def test_mlp_and_state_structs_as_a_c_compiler_lays_them_out(tmp_path):
+    """include/tpnet_hip.h compiled as plain C (gcc): sizeof / offsetof of tpnet_state and tpnet_mlp (ABI 6: + wimg) equal the
+    ctypes mirrors a binding uses (tpnet_amd/_lib.py) -- a field added on one side only would shift every pointer behind it."""
+    import shutil
+    import subprocess
+    from tpnet_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    fields = ["w1t", "b1", "w2t", "b2", "F", "H", "w1", "w2f", "wimg"]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tpnet_hip.h"\nint main(void) {\n'
+                   + 'printf("%zu %zu\\n", sizeof(tpnet_mlp), sizeof(tpnet_state));\n'
+                   + "".join(f'printf("%zu\\n", offsetof(tpnet_mlp, {f}));\n' for f in fields)
+                   + "return 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(_lib.Mlp) and int(out[1]) == ctypes.sizeof(_lib.State)
+    for f, off in zip(fields, out[2:]):
+        assert getattr(_lib.Mlp, f).offset == int(off), f

@@ -47,10 +47,13 @@ static constexpr int EMF_B = 512;                                           // t
 static constexpr int IMG_W1H = 0, IMG_W1L = 32768, IMG_W2H = 65536, IMG_W2L = 98304, IMG_B1 = 131072, IMG_B2 = IMG_B1 + 1024;
 static constexpr int IMG_BYTES = IMG_B2 + 256;                              // 132 352
 static constexpr int EMF_NP = 4;                                            // producer waves (= consumer waves) per workgroup
-static constexpr int EMF_TILE = 8 * EM_RS * 4;                              // bytes of a staged tile: 8 feature rows
-static constexpr int EMF_STG = IMG_BYTES;                                   // two tiles per producer
-static constexpr int EMF_SYNC = EMF_STG + EMF_NP * 2 * EMF_TILE;            // per producer: ready, freed, 2 x {first slot, validity}
-static constexpr int EMF_LDS = EMF_SYNC + EMF_NP * 32;                      // 149 888 bytes
+static constexpr int EMF_TILE = 8 * EM_RS * 4;                              // bytes of a producer's own tile of 8 raw feature rows
+static constexpr int EMF_HAND = 2048;                                       // bytes of a hand-off buffer: 8 rows as layer 1's B operand,
+                                                                            // hi plane [(s * 4 + g) * 8 + p] x 16 bytes, lo plane + 1024
+static constexpr int EMF_PP = EMF_TILE + 2 * EMF_HAND;                      // per producer: its tile + two hand-off buffers
+static constexpr int EMF_STG = IMG_BYTES;
+static constexpr int EMF_SYNC = EMF_STG + EMF_NP * EMF_PP;                  // per producer: ready, freed, 2 x {first slot, validity}
+static constexpr int EMF_LDS = EMF_SYNC + EMF_NP * 32;                      // 157 568 bytes
 
 #ifdef TPNET_STAMPS
 // diagnostic build only (make STAMPS=1): shader-clock stamps of the fused kernel's waves, 64 per wave (tools/encoder_stamps.py)
@@ -114,14 +117,14 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ rp, float (&
     }
 }
 
-// load layout -> operand layout (lane (c, g) takes what lane 4 c + g loaded), decay applied on the way
-template <int KS>
+// load layout -> operand layout (lane (c, g) takes what lane 4 c + g loaded); SCALE: the row's pending decay applied on the way
+template <int KS, bool SCALE = true>
 __device__ __forceinline__ void to_lanes(const float (&raw)[KS][8], float rs, int pull, float (&v)[KS][8]) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            v[s][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(raw[s][k] * rs)));
+            v[s][k] = __int_as_float(__builtin_amdgcn_ds_bpermute(pull, __float_as_int(SCALE ? raw[s][k] * rs : raw[s][k])));
 }
 // ... and the split on top
 template <int KS, int SPLIT>
@@ -261,11 +264,12 @@ __device__ __forceinline__ int walk_tiles(const tpnet_state& S, const int64_t* _
             // ---- this tile's rows -> operand lanes; the next tile's rows (and anchors) ride under the matrix work; then step by
             // step: split of step s + 1 under the products of step s
             if constexpr (HANDOFF) EM_STAMP(4 + 4 * tile_no);
+            // (the neighbours' pending decay g^layer scales the 4 x 4 blocks below, 10 multiplications per lane, instead of the 32
+            // loaded values: layer a of neighbour g against layer b of anything carries g^a, and the anchors' operands are scaled
+            // when they are formed, once per anchor set)
             float av[KS][8];
-            {
-                const float gd = __shfl(mv.g, 4 * t + g);
-                to_lanes<KS>(raw, decay_pow(gd, l_layer), pull, av);
-            }
+            const float gd = __shfl(mv.g, 4 * t + g);
+            to_lanes<KS, false>(raw, 1.0f, pull, av);
             if (t + 1 < ntile) {
                 issue_tile(t + 1);
                 const int n0n = __builtin_amdgcn_readlane(node, 4 * (t + 1));
@@ -278,6 +282,13 @@ __device__ __forceinline__ int walk_tiles(const tpnet_state& S, const int64_t* _
                 SplitOp<SPLIT> aop;
                 split8<SPLIT>(av[s], aop);
                 mm_step2<SPLIT>(aop, anch[s], dww, dwa);
+            }
+            {
+                const float p2 = gd * gd, p3 = p2 * gd;            // g, g*g, (g*g)*g: decay_pow's association
+                const int cbq = c & 3;
+                const float scol = cbq == 0 ? 1.0f : cbq == 1 ? gd : cbq == 2 ? p2 : p3;   // the w.w block's column: layer c & 3 of the same neighbour
+                dwa[1] *= gd; dwa[2] *= p2; dwa[3] *= p3;
+                dww[0] *= scol; dww[1] *= gd * scol; dww[2] *= p2 * scol; dww[3] *= p3 * scol;
             }
             // ---- accumulators -> an LDS tile of 8 feature rows (pair p = side * 4 + neighbour; element 8 a + b of the
             // [w rows | anchor rows]^2 Gram).  Lane (c, g) holds D[4 g + q][c], q = 0..3.
@@ -295,13 +306,6 @@ __device__ __forceinline__ int walk_tiles(const tpnet_state& S, const int64_t* _
             const bool pok_g = (okmask >> g) & 1u;
             const bool pin_g = (inmask >> g) & 1u;
             float* tb = stg;
-            if constexpr (HANDOFF) {
-                tb = stg + (tile_no & 1) * (8 * EM_RS);
-                // the buffer's previous tile (two tiles ago) must have been taken
-                if (tile_no >= 2)
-                    while (__hip_atomic_load(sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < tile_no - 1)
-                        __builtin_amdgcn_s_sleep(1);
-            }
             if constexpr (HANDOFF) EM_STAMP(6 + 4 * tile_no);
             const int cb = c & 3, cn = c >> 2;
             if (cn == g) {                                                // w.w block of neighbour g: (a = q, b = cb), both sides
@@ -328,6 +332,14 @@ __device__ __forceinline__ int walk_tiles(const tpnet_state& S, const int64_t* _
                 }
             }
             __builtin_amdgcn_wave_barrier();       // one wave: LDS executes in issue order
+            char* hb = nullptr;
+            if constexpr (HANDOFF) {
+                hb = reinterpret_cast<char*>(stg) + EMF_TILE + (tile_no & 1) * EMF_HAND;
+                // the hand-off buffer's previous tile (two tiles ago) must have been taken
+                if (tile_no >= 2)
+                    while (__hip_atomic_load(sync + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < tile_no - 1)
+                        __builtin_amdgcn_s_sleep(1);
+            }
             // ---- feature rows out: clamp, log(x + 1) (models/TPNet.py:127-128), 16 lanes per 256-byte row
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -347,7 +359,21 @@ __device__ __forceinline__ int walk_tiles(const tpnet_state& S, const int64_t* _
                     v[k] = x;
                 }
                 if (!pok_g) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                if constexpr (HANDOFF) *reinterpret_cast<f32x4*>(tb + p * EM_RS + 4 * col4) = v;  // the dense layers read them back
+                if constexpr (HANDOFF) {
+                    // the dense layers' B operand, already in two pieces (here every lane holds 4 features: the split is dense):
+                    // feature f = 4 col4 + k of pair p sits in step s = f >> 5, k-group (f >> 3) & 3, element f & 7
+                    typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const __bf16 hh = (__bf16)v[k];
+                        hi[k] = hh;
+                        lo[k] = (__bf16)(v[k] - (float)hh);
+                    }
+                    char* e = hb + (((col4 >> 3) * 4 + ((col4 >> 1) & 3)) * 8 + p) * 16 + (col4 & 1) * 8;
+                    *reinterpret_cast<bf16x4*>(e) = hi;
+                    *reinterpret_cast<bf16x4*>(e + 1024) = lo;
+                }
                 if (pin_g && (!HANDOFF || out1 != nullptr)) {
                     float* o = (it ? out2 : out1) + (int64_t)(base + 4 * t + g) * 64 + 4 * col4;
                     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o));
@@ -386,10 +412,13 @@ __global__ __launch_bounds__(EMB) void k_encoder_gram_mfma(tpnet_state S, const 
                                        stg_all + wave * (8 * EM_RS), nullptr);
 }
 
-// ReLU in ONE instruction: v_med3_f32(x, 0, +inf) (fmaxf costs a canonicalising v_max first; inline assembly would hide the
-// matrix-result hazard from the compiler's wait-state insertion -- it did, with garbage features).  A NaN becomes 0, as with
-// mlp_x3.hip's x > 0 ? x : 0 (med3 of a NaN operand returns the minimum of the others).
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// ReLU in ONE instruction: the signed-integer maximum of the bits and 0 (fmaxf / med3 cost a canonicalising v_max first; inline
+// assembly would hide the matrix-result hazard from the compiler's wait-state insertion -- it did, with garbage features).
+// Negative floats (-0 included) have the sign bit set = negative integers; a positive NaN stays a NaN, as in torch's relu.
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
 
 // the dense layers of one consumer wave: takes the tiles its producer publishes, 16 rows per pass
 __device__ __forceinline__ void dense_consumer(const char* smem, const float* stg, int* sync, int n_tiles, int T, int slot_end,
@@ -416,14 +445,12 @@ __device__ __forceinline__ void dense_consumer(const char* smem, const float* st
         const int e = k & 1;
         while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 1) __builtin_amdgcn_s_sleep(1);
         EM_STAMP(4 + 4 * k);
-        const float* tb = stg + e * (8 * EM_RS);
+        const char* hb = reinterpret_cast<const char*>(stg) + EMF_TILE + e * EMF_HAND;
         if ((c >> 3) == e) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(tb + (c & 7) * EM_RS + 32 * s + 8 * g);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(tb + (c & 7) * EM_RS + 32 * s + 8 * g + 4);
-                const float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                split8<2>(v, bx[s]);
+                bx[s].p[0] = *reinterpret_cast<const bf16x8*>(hb + ((s * 4 + g) * 8 + (c & 7)) * 16);
+                bx[s].p[1] = *reinterpret_cast<const bf16x8*>(hb + 1024 + ((s * 4 + g) * 8 + (c & 7)) * 16);
             }
             slot0 = sync[2 + 2 * e];
             okbits = (uint32_t)sync[3 + 2 * e];
@@ -540,7 +567,7 @@ __global__ __launch_bounds__(EMF_B) void k_encoder_fused(tpnet_state S, const in
     const int wid = blockIdx.x * EMF_NP + p;
     const int slot_begin = (wid * tpw * 4 < T) ? wid * tpw * 4 : T;
     const int slot_end = (slot_begin + tpw * 4 < T) ? slot_begin + tpw * 4 : T;
-    float* stg = reinterpret_cast<float*>(smem + EMF_STG) + p * (2 * 8 * EM_RS);
+    float* stg = reinterpret_cast<float*>(smem + EMF_STG + p * EMF_PP);
     int* sync = reinterpret_cast<int*>(smem + EMF_SYNC) + p * 8;
     if (wave < EMF_NP) {
         const int done = walk_tiles<KS, SPLIT, true>(S, neigh, a1, a2, n_rows, K, T, slot_begin, slot_end, now, lambda, flags, gram,
