@@ -12,6 +12,7 @@ ap.add_argument("--config", default="C2"); ap.add_argument("--batches", type=int
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--batch", type=int, default=0); ap.add_argument("--dim", type=int, default=0)
 ap.add_argument("--edges", type=int, default=0, help="exact stream length (overrides --batches; -1 = the config's own E)")
 ap.add_argument("--schedule", default=None)
+ap.add_argument("--replay", action="store_true", help="let every repetition after the first replay the stream's plan (a later epoch)")
 a = ap.parse_args()
 c = dict(CONFIGS[a.config]); c["d"] = a.dim or c["d"]; B = a.batch or c["B"]; E = a.batches * B
 if a.edges:
@@ -29,6 +30,6 @@ op = torch.empty((E, 64), device=dev); on = torch.empty((E, 64), device=dev)
 for r in range(a.reps):
     rp.reset_random_projections()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    rp.run_stream(ds, dd, dn, dt, B, out_pos=op, out_neg=on, t_end=float(t[-1]), schedule=a.schedule, replay=False)
+    rp.run_stream(ds, dd, dn, dt, B, out_pos=op, out_neg=on, t_end=float(t[-1]), schedule=a.schedule, replay=(None if a.replay else False))
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     print(f"{a.config} d={c['d']} B={B} rep {r}: {E / el / 1e6:.1f} M edges/s, {el / a.batches * 1e6:.2f} us/batch", flush=True)
