@@ -234,3 +234,20 @@ def test_torch_port_readout_matches_reference(golden_dir, name):
     port.P = [torch.from_numpy(np.array(g["P"][i])) for i in range(L + 1)]
     np.testing.assert_array_equal(port.pair_gram(g["u"], g["v"], not_scale=True).numpy(), g["gram_raw"])
     np.testing.assert_array_equal(port.pair_gram(g["u"], g["v"]).numpy(), g["gram_scaled"])
+
+
+def test_mlp_weight_gradients_fall_back_to_the_torch_expressions_on_the_host():
+    """tpnet_amd/fused_feature.weight_grads_f32 serves the module's backward: long lists on a GPU take the matrix-core kernel
+    (tested with -m gpu), everything else -- CPU tensors, short lists, a stale prepared entry -- the fp32 torch expressions, which
+    must equal autograd's gradients of Linear(64, 256) -> ReLU -> Linear(256, 64) (models/TPNet.py:63-65)."""
+    import torch
+    from tpnet_amd import fused_feature as ff
+    torch.manual_seed(3)
+    mlp = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64))
+    x = torch.rand(500, 64) * 7.0
+    gy = torch.randn(500, 64)
+    got = ff.weight_grads_f32(x, gy, mlp[0].weight.detach(), mlp[0].bias.detach(), mlp[2].weight.detach(), None)
+    mlp(x).backward(gy)
+    want = [p.grad for p in mlp.parameters()]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-4 * float(b.abs().max()))
