@@ -612,3 +612,36 @@ def test_encoder_readout_and_dense_layers_in_one_launch(d, K, n):
     want_g = [p.grad.clone() for p in rp.mlp.parameters()]
     _assert_mlp_grads_close(rp.mlp, feats, gy, grads, want_g)
     rp.check_device_errors()
+
+
+@pytest.mark.gpu
+def test_one_launch_encoder_call_on_random_shapes():
+    """k_encoder_fused over forty random (rows, K, d) shapes -- shares of one tile and of many, odd tile counts (a half-empty last
+    pass of the dense layers), producers without tiles, K from 4 to 45, rows of 64 and 128 floats -- against the two-launch path
+    (vector-ALU walk + torch layers): the hand-off between the producer and consumer waves must neither lose nor repeat a tile."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    rng = np.random.RandomState(2024)
+    N = 500
+    mods = {}
+    for d in (64, 128):
+        rp = _module(N, d, 3)
+        for src, dst, t in _stream(rng, N, 200, 2):
+            rp.update(src, dst, t)
+        mods[d] = rp
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    for trial in range(40):
+        d = (64, 128)[trial % 2]
+        rp = mods[d]
+        K = int(rng.randint(4, 46))
+        n = int(rng.choice([1, 2, 3, 5, 17, 64, 257, 1000, 3000]))
+        neigh = rng.randint(0, N, (n, K)).astype(np.int64)
+        a1, a2 = rng.randint(1, N, n).astype(np.int64), rng.randint(1, N, n).astype(np.int64)
+        with torch.no_grad():
+            got = rp.get_pair_wise_feature_anchored(dev(neigh), dev(a1), dev(a2))
+            want = rp.mlp(rp.pair_gram_anchored(neigh, a1, a2, matrix_cores=False).view(-1, 64))
+        scale = float(want.abs().max())
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * scale + 1e-6, (trial, d, K, n, err, scale)
+    for rp in mods.values():
+        rp.check_device_errors()
