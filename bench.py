@@ -185,7 +185,10 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
     # encoder-level unit (secondary): the encoder's two calls per batch on top -- 4*B*K pairs each in the
     # reference's tile / repeat pattern (models/TPNet.py:311-316), K = 20 synthetic neighbours per node
     K = 20
-    nbe = max(1, min(8, nb, len(src) // B - 4))
+    # (24 batches per pass since round 4, 8 before: the loop's start -- the host is a call ahead before the GPU has anything to do --
+    # and its final synchronisation are ~40 us that 8 batches of ~140 us did not amortise: 138-144 us per batch where the kernel
+    # timeline of the same loop shows 131, tools/encoder_trace2.py)
+    nbe = max(1, min(24, nb, len(src) // B - 4))
     rng = np.random.RandomState(7)
     N = rp.node_num
     calls = []                                   # the index arrays of every call, built before the clock starts (that part is the
@@ -213,7 +216,7 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
                 rp.update(src[s], dst[s], t[s])
             torch.cuda.synchronize()
         return time.perf_counter() - t0_
-    # (two passes, the faster one: a pass of 8 batches is ~3 ms, and one stray host stall -- a pinned allocation, a page fault in a
+    # (two passes, the faster one: a pass of 24 batches is ~4-6 ms, and one stray host stall -- a pinned allocation, a page fault in a
     # fresh buffer -- has shown up as 3x the figure)
     el = min(encoder_pass(), encoder_pass())
     res["encoder_level"] = {"value": nbe * B / el, "unit": "edges/s", "us_per_batch": el / nbe * 1e6,
