@@ -451,7 +451,6 @@ int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, cons
                  bool want_readout, bool replay, hipStream_t s) {
     if (!wplan3_applies(st, Ec, batch, p.K) || !p.wmask || !p.wcls || !p.wtab || !p.wblk) return TPNET_ERR_BAD_ARG;
     const int64_t nb = (Ec + batch - 1) / batch;
-    const int64_t nc = 2 * Ec;
     WTmp q = wtmp_full(st, p, Ec, batch);
     const int64_t nw = (nb + p.K - 1) / p.K;
     int node_bits = 1;
