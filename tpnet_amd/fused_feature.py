@@ -52,8 +52,9 @@ def _w2f_cols(dev):
     return _w2f_index(dev)[1]
 
 
-# rows from which the matrix-core backward serves a call (below, the five torch GEMMs are small and as fast)
-MFMA_BWD_FROM = 4096
+# rows from which the matrix-core backward serves a call: one launch + a sum of partials against ten small torch launches -- at the
+# decoder's 1 000 rows per call a training step went 704 -> 520-570 us (bench.py, dropin.train); below, the torch expressions
+MFMA_BWD_FROM = 512
 
 
 def weight_grads_f32(x, gy, w1, b1, w2, prep):
