@@ -462,6 +462,14 @@ int tpnet_host_encoder_features(const tpnet_state* st, tpnet_stage* stage, const
  * 311-316: src = tile(neigh, 2), dst = concat(repeat(a1, K), repeat(a2, K)))?  Returns K >= 2, else 0 (N is unused: the ids' range
  * is the caller's to check). */
 int64_t tpnet_host_encoder_pattern(const int64_t* src, const int64_t* dst, int64_t n, int64_t N);
+/* The encoder's call from the reference's own HOST index arrays in one crossing (ABI 6): pattern check, range check, the n / 2
+ * neighbour ids + the anchors staged through `stage` (slot_bytes >= (n / 2 + n / K) * 8; the kernel reads them there) and
+ * tpnet_anchored_features launched on `stream`.  *K_out = the pattern's K (>= 4) if the call was served, 0 if not (not the
+ * pattern, K < 4, an id outside [0, N), a shape the kernels do not serve): the caller then takes the general path.  gram: as for
+ * tpnet_anchored_features (may be NULL where tpnet_encoder_fused_supported). */
+int tpnet_host_anchored_features(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst, int64_t n,
+                                 double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* gram, float* out,
+                                 int32_t* K_out, void* stream);
 
 /* ---- the step behind the path (BASELINE config 5): self.mlp = Linear(64,256)->ReLU->Linear(256,64)
  * (models/TPNet.py:64-65,129) fused in one kernel on the bf16 matrix cores, fp32 accumulate, L = 3 only.

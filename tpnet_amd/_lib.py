@@ -132,6 +132,8 @@ SIGNATURES = {
     "tpnet_host_update": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,
                                     C.c_size_t, _P]),
     "tpnet_host_encoder_pattern": (C.c_int64, [_P, _P, C.c_int64, C.c_int64]),
+    "tpnet_host_anchored_features": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.POINTER(Mlp), _P, _P,
+                                              C.POINTER(C.c_int32), _P]),
     "tpnet_xplan_capacity": (C.c_int64, []),
     "tpnet_xplan_targeted": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
                                        _P, _P, _P]),

@@ -270,4 +270,87 @@ int64_t tpnet_host_encoder_pattern(const int64_t* src, const int64_t* dst, int64
     return g;
 }
 
+
+// The encoder's call from the reference's OWN host index arrays (models/TPNet.py:311-316: src = tile(neigh, 2), dst =
+// concat(repeat(a1, K), repeat(a2, K)), 2 x 640 KB at C2) in ONE crossing (round 4): the pattern check (the halves of src equal; dst
+// made of constant blocks of K), the ids' range, the staging of the n / 2 neighbour ids + 2 n / (2 K) anchors into the pinned ring
+// (the kernel reads them there: no copy is enqueued) and the launch of readout + self.mlp.  Until round 4 the module did the
+// check in C (37 us), two numpy reductions for the range (10 us) and a pinned copy + an enqueued host-to-device copy from Python
+// (30 us): 82 us of host time per call against 46 us of GPU time -- the loop was host-bound.  The loops below are written for
+// the vectoriser (AVX2 where the CPU has it: the function is multi-versioned); what remains is reading the 1.28 MB once.
+// *K_out = the pattern's K (>= 4) if the call was served; 0 = not this pattern / not served (the caller takes the general path,
+// which also reports ids out of range).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TPNET_HOST_SIMD
+#else
+#define TPNET_HOST_SIMD __attribute__((target_clones("avx2", "default")))
+#endif
+TPNET_HOST_SIMD
+static int64_t pattern_and_stage(const int64_t* src, const int64_t* dst, int64_t n, int64_t N, int64_t* out_neigh, int64_t k_given,
+                                 int64_t* out_a1, int64_t* out_a2) {
+    // second phase (k_given > 0): copy + range; first phase (k_given == 0): detection only.  Returns K, or 0.
+    const int64_t h = n / 2;
+    if (k_given == 0) {
+        if (memcmp(src, src + h, (size_t)h * 8) != 0) return 0;
+        int64_t k0 = 1;
+        while (k0 < h && dst[k0] == dst[0]) ++k0;
+        if (k0 < 2 || h % k0 != 0) return 0;
+        uint64_t acc = 0;
+        for (int64_t j = 0; j < n; j += k0) {
+            const int64_t first = dst[j];
+            uint64_t a = 0;
+            for (int64_t k = 1; k < k0; ++k) a |= (uint64_t)(dst[j + k] ^ first);
+            acc |= a;
+        }
+        return acc == 0 ? k0 : 0;
+    }
+    const int64_t K = k_given, m = h / K;
+    int64_t mx = 0;
+    uint64_t neg = 0;
+    for (int64_t i = 0; i < h; ++i) {                       // neighbour ids: copy, max and sign in one pass
+        const int64_t x = src[i];
+        out_neigh[i] = x;
+        neg |= (uint64_t)x;
+        mx = x > mx ? x : mx;
+    }
+    for (int64_t j = 0; j < m; ++j) {
+        const int64_t x = dst[j * K], y = dst[h + j * K];
+        out_a1[j] = x;
+        out_a2[j] = y;
+        neg |= (uint64_t)x | (uint64_t)y;
+        mx = x > mx ? x : mx;
+        mx = y > mx ? y : mx;
+    }
+    return ((neg >> 63) == 0 && mx < N) ? K : 0;
+}
+
+int tpnet_host_anchored_features(const tpnet_state* st, tpnet_stage* stage, const int64_t* h_src, const int64_t* h_dst, int64_t n,
+                                 double now_time, double lambda, uint32_t flags, const tpnet_mlp* mlp, float* gram, float* out,
+                                 int32_t* K_out, void* stream) {
+    if (!K_out) return TPNET_ERR_BAD_ARG;
+    *K_out = 0;
+    if (!st || !stage || !h_src || !h_dst || !mlp || !out || st->N < 1 || n < 8 || (n & 1)) return TPNET_OK;
+    const int64_t h = n / 2;
+    const int64_t K = pattern_and_stage(h_src, h_dst, n, st->N, nullptr, 0, nullptr, nullptr);
+    if (K < 4 || K > (1 << 20)) return TPNET_OK;
+    const int64_t m = h / K;
+    // served where readout + dense layers are one launch, or the two-launch path has its feature buffer
+    if (!(tpnet_encoder_fused_supported(st, m, (int32_t)K, mlp) || (gram && tpnet_pair_gram_anchored_supported(st)))) return TPNET_OK;
+    const size_t bytes = (size_t)(h + 2 * m) * 8;
+    if (bytes > stage->slot_bytes) return TPNET_OK;
+    hipStream_t s = (hipStream_t)stream;
+    char *host = nullptr, *dev = nullptr;
+    int rc = stage_acquire(stage, bytes, s, &host, &dev);
+    if (rc) return rc;
+    int64_t* hn = reinterpret_cast<int64_t*>(host);
+    if (pattern_and_stage(h_src, h_dst, n, st->N, hn, K, hn + h, hn + h + m) == 0) return TPNET_OK;   // an id out of range: general path
+    const int64_t* dn = reinterpret_cast<const int64_t*>(dev);
+    rc = tpnet_anchored_features(st, dn, dn + h, dn + h + m, m, (int32_t)K, now_time, lambda, flags, mlp, gram, out, stream);
+    if (rc) return rc;
+    rc = stage_release(stage, bytes, s);
+    if (rc) return rc;
+    *K_out = (int32_t)K;
+    return TPNET_OK;
+}
+
 }  // extern "C"
