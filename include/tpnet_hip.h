@@ -39,7 +39,8 @@ extern "C" {
                                     crossing (tpnet_anchored_features, tpnet_encoder_features, tpnet_host_encoder_features), the targeted
                                     exchange's plan on the device (tpnet_xplan_targeted);
                                6: + tpnet_mlp::wimg / tpnet_mlp_prepare_image (the encoder's readout and self.mlp in ONE launch on the matrix
-                                    cores), TPNET_FLAG_NO_MFMA_READOUT, tpnet_rows_stream_targeted */
+                                    cores), TPNET_FLAG_NO_MFMA_READOUT, tpnet_rows_stream_targeted, tpnet_mlp64_bwd_f32, tpnet_host_anchored_features;
+                                    tpnet_run_stream_tagged replays streams of up to 64 chunks */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -254,7 +255,8 @@ size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max
 /* The same with the version log of a chunk capped at log_cap_bytes (0 = the library's 16 GiB): the windowed schedule costs
  * 2*L*d*4 bytes of log per edge of a chunk (C2: 3 KB per edge, 484 MB for one Wikipedia epoch) plus ~0.5 KB per edge of plan; a
  * caller short of memory trades chunk length (more pipeline fills and drains) for workspace.  tpnet_run_stream takes whatever
- * chunk the workspace it is given holds. */
+ * chunk the workspace it is given holds.  Both functions add, for a stream of 2 .. 64 chunks, the room that keeps every chunk's
+ * plan (everything but the log) resident: what tpnet_run_stream_tagged needs to replay such a stream. */
 size_t tpnet_stream_workspace_bytes_capped(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch,
                                            size_t log_cap_bytes);
 
@@ -281,8 +283,9 @@ int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* d
 /* The same loop for a stream that is run AGAIN: train_link_prediction.py:234-253 replays the same chronological stream every
  * epoch (reset_random_projections at the epoch's start, then the same batches), so the plan of the update -- sorted
  * contributions, chains, version references of src / dst -- is the same every epoch; only the negatives are drawn anew.  A call
- * that runs the windowed schedule on the whole stream as ONE chunk leaves its plan in the workspace and describes it in
- * tag->built; a later call with equal arguments, the same workspace and the same two signatures skips the planning and only
+ * that runs the windowed schedule on the whole stream leaves its plan in the workspace and describes it in tag->built -- the stream
+ * is ONE chunk, or (since ABI 6) up to 64 chunks whose plans find room side by side in front of the one version log they share
+ * (tpnet_stream_workspace_bytes sizes the workspace for that) --; a later call with equal arguments, the same workspace and the same two signatures skips the planning and only
  * resolves the negatives' readout references again (tag->replayed = 1).  The CALLER vouches with the signatures:
  *   stream_sig: identifies the CONTENTS of src / dst / t (equal value = unchanged arrays; 0 = never replay);
  *   table_sig:  identifies the table's per-node (current copy, reference time) state before the call -- e.g. one constant

@@ -43,6 +43,25 @@ def test_size_helpers(hip_lib):
     assert hip_lib.tpnet_meta_bytes(9228) == 9228 * 32
 
 
+def test_stream_workspace_sizes_for_one_and_for_several_chunks(hip_lib):
+    """tpnet_stream_workspace_bytes(_capped): a stream that fits one chunk gets that chunk's plan + version log; a longer one (here:
+    the log capped) the plans of its chunks side by side + ONE chunk's log (what a replay of every chunk needs) -- more than one
+    chunk's workspace, less than the uncapped stream's; beyond 64 chunks: one chunk's."""
+    N, d, L, B = 9228, 128, 3, 1000
+    row = 2 * L * d * 4                                                   # log bytes per edge
+    full = hip_lib.tpnet_stream_workspace_bytes(N, d, L, 480 * B, B)
+    assert full > 480 * B * row
+    assert hip_lib.tpnet_stream_workspace_bytes_capped(N, d, L, 480 * B, B, 0) == full
+    assert hip_lib.tpnet_stream_workspace_bytes_capped(N, d, L, 480 * B, B, 1000 * B * row) == full        # the cap does not bind
+    one = hip_lib.tpnet_stream_workspace_bytes(N, d, L, 48 * B, B)
+    four = hip_lib.tpnet_stream_workspace_bytes_capped(N, d, L, 480 * B, B, 120 * B * row)
+    ten = hip_lib.tpnet_stream_workspace_bytes_capped(N, d, L, 480 * B, B, 48 * B * row)
+    assert one < ten < four < full
+    assert ten - one < 0.2 * 480 * B * row                                # (the ten plans without their logs: a fraction of the log)
+    many = hip_lib.tpnet_stream_workspace_bytes_capped(N, d, L, 70 * 48 * B, B, 48 * B * row)              # 70 chunks: no arena
+    assert many == one
+
+
 def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     from tpnet_amd import _lib
     st = _lib.State(p0=None, q=None, meta=None, N=10, d=16, L=3, err=None)

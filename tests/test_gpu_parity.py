@@ -1060,6 +1060,76 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     np.testing.assert_array_equal(e4[2], c1[2])
 
 
+@pytest.mark.parametrize("d,L,N,B,nb,per", [(64, 3, 2000, 100, 300, 130), (128, 3, 9000, 1000, 70, 30), (64, 2, 3000, 200, 150, 70)])
+def test_plan_replay_of_a_stream_of_several_chunks(d, L, N, B, nb, per):
+    """A stream longer than one chunk (here: the version log capped at `per` batches' worth, `stream_log_cap_bytes`; without a cap:
+    beyond 16 GiB of log or 256 windows) keeps the plan of EVERY chunk -- one region per chunk in front of the one log they share
+    (api.hip, window_chunk / run_stream_windowed) -- so the second epoch replays all of them: same bits as the cold one-chunk run,
+    and the replay is invalidated as a one-chunk plan is."""
+    _need_gpu()
+    from tpnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(d + B + nb)
+    E = nb * B - B // 3
+    lam = 2e-6
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    neg2 = rng.randint(0, N, E).astype(np.int64)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dn2, dt = dev(src), dev(dst), dev(neg), dev(neg2), dev(t)
+
+    def epoch(rp, negs, **kw):
+        rp.reset_random_projections()
+        rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+        fp, fn = rp.run_stream(ds, dd, negs, dt, B, schedule="windowed", **kw)
+        return fp.clone(), fn.clone(), _layers(rp), rp.last_stream_replayed
+
+    one = _module(N, d, L, lam, t[0], P0=P0)
+    c1 = epoch(one, dn, replay=False)
+    c2_ = epoch(one, dn2, replay=False)
+    rp = _module(N, d, L, lam, t[0], P0=P0)
+    rp.stream_log_cap_bytes = per * B * 2 * L * d * 4
+    e1 = epoch(rp, dn)
+    assert rp._eng["ws"].numel() < one._eng["ws"].numel()       # (several chunks: less log than the whole stream's)
+    e2 = epoch(rp, dn2)
+    e3 = epoch(rp, dn)
+    assert not e1[3] and e2[3] and e3[3]
+    for got, want in ((e1, c1), (e2, c2_), (e3, c1)):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        np.testing.assert_array_equal(got[2], want[2])
+    # update-only epochs replay too (a plan with readouts is not one without: planned once more, then replayed)
+    assert not epoch_update_only(rp, ds, dd, dt, B, P0)
+    assert epoch_update_only(rp, ds, dd, dt, B, P0)
+    np.testing.assert_array_equal(_layers(rp), c1[2])
+    # an in-place write to the stream is seen, so is another user of the workspace
+    dd[3] = dd[3]
+    assert not epoch(rp, dn)[3]
+    assert epoch(rp, dn)[3]
+    rp.reset_random_projections()
+    rp.update(src[:B], dst[:B], t[:B])
+    e4 = epoch(rp, dn)
+    assert not e4[3]
+    assert torch.equal(e4[0], c1[0]) and torch.equal(e4[1], c1[1])
+    # a workspace sized for ONE capped chunk: chunk by chunk all the same, replayed or not as the chunks' plans find room in it
+    small = _module(N, d, L, lam, t[0], P0=P0)
+    ws = torch.empty(lib.tpnet_stream_workspace_bytes(N, d, L, per * B, B), dtype=torch.uint8, device=DEV)
+    small._ensure_engine()
+    small._eng["ws"] = ws
+    small._ws_need = {(E, B, True, 0, 0): ws.numel()}
+    epoch(small, dn)
+    s2 = epoch(small, dn2)
+    assert small._eng["ws"] is ws
+    assert torch.equal(s2[0], c2_[0]) and torch.equal(s2[1], c2_[1])
+    np.testing.assert_array_equal(s2[2], c2_[2])
+
+
+def epoch_update_only(rp, ds, dd, dt, B, P0):
+    rp.reset_random_projections()
+    rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+    rp.run_stream(ds, dd, None, dt, B, schedule="windowed", want_pos=False, want_neg=False)
+    return rp.last_stream_replayed
+
+
 @pytest.mark.parametrize("nb,d,N,B", [(15, 64, 500, 100), (16, 64, 500, 100), (60, 64, 500, 100),
                                       (20, 128, 9228, 1000)])     # (the driver's timed shape: C2, 20 batches)
 def test_auto_schedule_on_both_sides_of_its_threshold(nb, d, N, B):

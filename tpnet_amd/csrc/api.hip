@@ -42,13 +42,49 @@ struct StepTimer {
     int64_t wedges = 0;        // edges of the recorded windows
 };
 
+// The plans of a multi-chunk stream side by side -- one region per chunk, each with every array of a plan but the version log --
+// in front of ONE version log: what lets a stream of several chunks be replayed (run_stream_windowed).  At most 64 chunks.
+constexpr int64_t ARENA_MAX_CHUNKS = 64;
+static size_t arena_region_bytes(int64_t N, int d, int L, int64_t chunk, int64_t batch) {
+    return (wplan_bytes(chunk, batch, N, d, L) - wplan_log_bytes(chunk, d, L) + 511) / 256 * 256;
+}
+static size_t arena_bytes(int64_t N, int d, int L, int64_t E, int64_t chunk, int64_t batch) {
+    const int64_t n = (E + chunk - 1) / chunk;
+    return (size_t)n * arena_region_bytes(N, d, L, chunk, batch) + wplan_log_bytes(chunk, d, L) + 512;
+}
+
+// edges per window (*Ew_out) and the most a chunk may cover whatever the workspace (whole windows, or all of E); 0: not windowed
+static int64_t window_chunk_limit(int64_t N, int d, int L, int64_t E, int64_t batch, uint32_t flags, int* K_out, int64_t* Ew_out) {
+    const int K = wplan_window_batches(batch, d, L);
+    if (K == 0) return 0;
+    *K_out = K;
+    int64_t Ew = (int64_t)K * batch;
+    // packed rows of (2L+2)(2L+3)/2 floats: every chunk's output must start on a 16-byte boundary (launch_wstep)
+    const int NN = 2 * L + 2;
+    if ((flags & TPNET_FLAG_PACKED) && ((NN * (NN + 1) / 2) % 4) != 0 && Ew % 4 != 0) Ew *= (Ew % 2 == 0) ? 2 : 4;
+    *Ew_out = Ew;
+    int64_t cap = wplan_max_chunk_edges(batch, d, L);                // the version log of a chunk is bounded
+    // batches that fit one workgroup's LDS: chunks of at most 64 windows, which the hashed planner serves (wplan3.hip) -- ONE set
+    // of plan kernels whatever the stream's length (a chunk that falls to the sorted planner meets rocPRIM's large-size sort
+    // kernels for the first time in the middle of a long call: HIP resolves a kernel at its first launch, ~0.3 ms each)
+    // (the dense planner, wplan_dense.hip: one launch, up to 256 windows)
+    const bool dense = !(flags & (TPNET_FLAG_PLAN_SORTED | TPNET_FLAG_PLAN_HASHED)) && wplan_dense_eligible(N, d, L, batch);
+    const int64_t maxw = dense ? 256 : WIN_MAX_WINDOWS;
+    if (batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED) && cap > maxw * Ew) cap = maxw * Ew;
+    const int64_t hard = cap / Ew * Ew;
+    return (E <= cap) ? E : hard;
+}
+
 // The windowed path (wstep.hip) serves a stream when its arithmetic contract allows it (no eager decay / strictly
 // sequential sums: those are the per-batch kernels' exact mode), the rows take 16-byte vectors, there are enough batches
 // for a window to pay, and the caller's workspace holds the plan of at least one window.  Returns the chunk (edges per
-// plan: whole windows of Kmax batches, or all of E) and Kmax; 0 = use the per-batch path.
-static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, int64_t batch, uint32_t flags, int* K_out) {
+// plan: whole windows of Kmax batches, or all of E) and Kmax; 0 = use the per-batch path.  `region_out` (may be null: the caller
+// has no use for a replayable layout): set to the bytes per chunk region where the stream takes several chunks and the workspace
+// holds them side by side (arena_bytes), else to 0.
+static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, int64_t batch, uint32_t flags, int* K_out,
+                            size_t* region_out = nullptr) {
+    if (region_out) *region_out = 0;
     if (flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL | TPNET_FLAG_SCHED_BATCH)) return 0;
-    const int K = wplan_window_batches(batch, st.d, st.L);
     const int64_t nb = (E + batch - 1) / batch;
     // short streams: the pipeline pays its plan (~31 us for 20 C2 batches with the dense planner, wplan_dense.hip) and L + 1 dependent
     // launches up front, the per-batch schedule ~20 us and ~6.6 us per batch (C2): the pipeline wins from 16 batches
@@ -57,24 +93,28 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
     // the chunk planner's crossover (two device-wide sorts).
     static const int min_nb3 = TPNET_DEV_INT(WIN_MIN_BATCHES, 16);
     const int min_nb = batch <= PLAN_ONE_MAX ? min_nb3 : 56;
-    if (K == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
-    *K_out = K;
-    int64_t Ew = (int64_t)K * batch;
-    // packed rows of (2L+2)(2L+3)/2 floats: every chunk's output must start on a 16-byte boundary (launch_wstep)
-    const int NN = 2 * st.L + 2;
-    if ((flags & TPNET_FLAG_PACKED) && ((NN * (NN + 1) / 2) % 4) != 0 && Ew % 4 != 0) Ew *= (Ew % 2 == 0) ? 2 : 4;
-    int64_t cap = wplan_max_chunk_edges(batch, st.d, st.L);                // the version log of a chunk is bounded
-    // batches that fit one workgroup's LDS: chunks of at most 64 windows, which the hashed planner serves (wplan3.hip) -- ONE set
-    // of plan kernels whatever the stream's length (a chunk that falls to the sorted planner meets rocPRIM's large-size sort
-    // kernels for the first time in the middle of a long call: HIP resolves a kernel at its first launch, ~0.3 ms each)
-    // (the dense planner, wplan_dense.hip: one launch, up to 256 windows)
-    const bool dense = !(flags & (TPNET_FLAG_PLAN_SORTED | TPNET_FLAG_PLAN_HASHED)) && wplan_dense_eligible(st.N, st.d, st.L, batch);
-    const int64_t maxw = dense ? 256 : WIN_MAX_WINDOWS;
-    if (batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED) && cap > maxw * Ew) cap = maxw * Ew;
-    const int64_t hard = cap / Ew * Ew;
-    const int64_t lim = (E <= cap) ? E : hard;
+    int64_t Ew = 0;
+    const int64_t lim = window_chunk_limit(st.N, st.d, st.L, E, batch, flags, K_out, &Ew);
+    if (lim == 0 || nb < ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb)) return 0;
     if ((lim + batch - 1) / batch < 4) return 0;
-    if (wplan_bytes(lim, batch, st.N, st.d, st.L) <= ws_bytes) return lim;
+    const bool lim_fits = wplan_bytes(lim, batch, st.N, st.d, st.L) <= ws_bytes;
+    if (lim_fits && lim >= E) return lim;
+    if (region_out && batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED)) {      // (the sorted planner keeps nothing to replay)
+        // several chunks: the largest chunk (whole windows, at least two chunks, at most ARENA_MAX_CHUNKS) whose arena fits, if any
+        // (the log grows with the chunk, the per-node arrays of the regions with the number of chunks: not monotone, and at most
+        // 256 candidates -- a chunk is at most 256 windows)
+        int64_t hi = lim / Ew;                                          // (lim < E: whole windows; else lim = E did not fit)
+        if (hi * Ew >= E) hi = (E - 1) / Ew;
+        int64_t lo = (E + ARENA_MAX_CHUNKS * Ew - 1) / (ARENA_MAX_CHUNKS * Ew);
+        if (lo < 1) lo = 1;
+        if (lo * Ew < 4 * batch) lo = (4 * batch + Ew - 1) / Ew;
+        for (int64_t w = hi; w >= lo; --w)
+            if (arena_bytes(st.N, st.d, st.L, E, w * Ew, batch) <= ws_bytes) {
+                *region_out = arena_region_bytes(st.N, st.d, st.L, w * Ew, batch);
+                return w * Ew;
+            }
+    }
+    if (lim_fits) return lim;
     int64_t lo = 0, hi = (lim + Ew - 1) / Ew;       // in windows; lo fits (0), hi does not
     while (hi - lo > 1) {
         const int64_t mid = (lo + hi) / 2;
@@ -109,6 +149,8 @@ struct PlanBuilt {
     uint32_t flags;
     uint64_t table_sig, stream_sig;
     uint64_t have_readout;
+    int64_t chunk;              // edges per chunk, and
+    uint64_t region;            // bytes per chunk region where the stream is several chunks (0: one chunk)
 };
 static_assert(sizeof(PlanBuilt) <= sizeof(((tpnet_plan_tag*)nullptr)->built), "tpnet_plan_tag::built too small");
 
@@ -116,39 +158,50 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
                                const double* t, int64_t E, int64_t batch, double now_time, double lambda,
                                uint32_t launch_id_base, uint32_t flags, float* out_pos, float* out_neg, void* ws,
                                size_t ws_bytes, int64_t chunk, int Kmax, hipStream_t s, StepTimer* timer,
-                               tpnet_plan_tag* tag) {
+                               tpnet_plan_tag* tag, size_t region) {
     const int NN = 2 * st.L + 2;
     const int NG = (flags & TPNET_FLAG_PACKED) ? NN * (NN + 1) / 2 : NN * NN;
     uint32_t lid = launch_id_base;
-    for (int64_t c0 = 0; c0 < E; c0 += chunk, ++lid) {
+    const bool have_readout = out_pos || out_neg;
+    // a plan may be replayed when the caller vouches (tag) that the stream arrays and the table's per-node state are what the
+    // plan in this workspace was built for, and the workspace still holds the plan of EVERY chunk: the stream is one chunk, or
+    // its chunks' plans lie side by side (`region` bytes each, window_chunk) in front of the one version log they share -- the
+    // table state a later chunk's plan was built on follows from the first one's and the stream
+    char* const arena = reinterpret_cast<char*>((reinterpret_cast<size_t>(ws) + 255) / 256 * 256);
+    const int64_t n_chunks = (E + chunk - 1) / chunk;
+    float* const shared_log = region ? reinterpret_cast<float*>(arena + (size_t)n_chunks * region) : nullptr;
+    PlanBuilt now{};
+    bool replay = false, all_planned_here = true;
+    if (tag && (n_chunks == 1 || region) && tag->table_sig && tag->stream_sig) {
+        now.valid = 1; now.src = src; now.dst = dst; now.t = t; now.ws = ws; now.E = E; now.batch = batch; now.N = st.N;
+        now.ws_bytes = ws_bytes; now.now_time = now_time; now.lambda = lambda; now.d = st.d; now.L = st.L;
+        now.K = window_batches_for(((E < chunk ? E : chunk) + batch - 1) / batch, Kmax);
+        now.flags = flags & ~(uint32_t)TPNET_FLAG_SCHED_WINDOWED;
+        now.table_sig = tag->table_sig; now.stream_sig = tag->stream_sig; now.have_readout = have_readout ? 1 : 0;
+        now.chunk = chunk; now.region = region;
+        replay = memcmp(&now, tag->built, sizeof(PlanBuilt)) == 0;
+    }
+    if (tag) {
+        memset(tag->built, 0, sizeof(tag->built));                  // (invalid unless this call completes every chunk's plan)
+        tag->replayed = replay ? 1 : 0;
+    }
+    for (int64_t c0 = 0, ci = 0; c0 < E; c0 += chunk, ++lid, ++ci) {
         const int64_t Ec = (E - c0 < chunk) ? (E - c0) : chunk;
         const int64_t nb = (Ec + batch - 1) / batch;
         const int K = window_batches_for(nb, Kmax);
         WPlan p{};
-        int rc = wplan_carve(ws, ws_bytes, Ec, batch, st.N, st.d, st.L, K, &p);
+        int rc = region ? wplan_carve(arena + (size_t)ci * region, region, Ec, batch, st.N, st.d, st.L, K, &p, shared_log)
+                        : wplan_carve(ws, ws_bytes, Ec, batch, st.N, st.d, st.L, K, &p);
         if (rc) return rc;
-        const bool have_readout = out_pos || out_neg;
         static const int no3 = TPNET_DEV_INT(NO_PLAN3, 0);
         // the hashed planner costs ~45 us + 0.76 us per batch, the sorted one ~200 us + 0.63 us per batch (C2, profiles/r03_C2.md):
         // 4 % of a long stream's time, paid for having one set of plan kernels (see window_chunk)
         static const int max3 = TPNET_DEV_INT(PLAN3_MAX_BATCHES, 1 << 30);
         const bool dense = !(flags & (TPNET_FLAG_PLAN_SORTED | TPNET_FLAG_PLAN_HASHED)) && wplan_dense_applies(st, p, Ec, batch, K);
         const bool plan3 = !dense && !no3 && !(flags & TPNET_FLAG_PLAN_SORTED) && nb <= max3 && wplan3_applies(st, Ec, batch, K);
-        // a plan may be replayed when the whole stream is ONE chunk and the caller vouches (tag) that the stream arrays and
-        // the table's per-node state are what the plan in this workspace was built for
-        PlanBuilt now{};
-        bool replay = false;
-        if (tag && (plan3 || dense) && Ec == E && tag->table_sig && tag->stream_sig) {
-            now.valid = 1; now.src = src; now.dst = dst; now.t = t; now.ws = ws; now.E = E; now.batch = batch; now.N = st.N;
-            now.ws_bytes = ws_bytes; now.now_time = now_time; now.lambda = lambda; now.d = st.d; now.L = st.L; now.K = K;
-            now.flags = flags & ~(uint32_t)TPNET_FLAG_SCHED_WINDOWED;
-            now.table_sig = tag->table_sig; now.stream_sig = tag->stream_sig; now.have_readout = have_readout ? 1 : 0;
-            replay = memcmp(&now, tag->built, sizeof(PlanBuilt)) == 0;
-        }
-        if (tag) {
-            memset(tag->built, 0, sizeof(tag->built));                  // (invalid unless this call completes its plan)
-            tag->replayed = replay ? 1 : 0;
-        }
+        // (the sorted planner keeps nothing to replay: a stream with such a chunk is planned again every time; a recorded plan had
+        // none, and the same sizes choose the same planners)
+        if (!(plan3 || dense)) all_planned_here = false;
         if (dense)
             rc = wplan_dense_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
                                    c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, replay, s);
@@ -159,7 +212,6 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
             rc = wplan_build(st, p, src + c0, dst + c0, neg ? neg + c0 : nullptr, t + c0, Ec, batch, now_time,
                              c0 > 0 ? t + c0 - 1 : nullptr, lambda, have_readout, s);
         if (rc) return rc;
-        if (now.valid) memcpy(tag->built, &now, sizeof(PlanBuilt));
         StreamArgs a;
         a.src = src + c0;
         a.dst = dst + c0;
@@ -194,6 +246,7 @@ static int run_stream_windowed(const tpnet_state& st, const int64_t* src, const 
             if (rc) return rc;
         }
     }
+    if (now.valid && all_planned_here) memcpy(tag->built, &now, sizeof(PlanBuilt));
     return TPNET_OK;
 }
 
@@ -204,10 +257,11 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
     if (E == 0) return TPNET_OK;
     {
         int Kw = 0;
-        const int64_t wchunk = window_chunk(st, ws_bytes, E, batch, flags, &Kw);
+        size_t region = 0;
+        const int64_t wchunk = window_chunk(st, ws_bytes, E, batch, flags, &Kw, tag ? &region : nullptr);
         if (wchunk > 0)
             return run_stream_windowed(st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos,
-                                       out_neg, ws, ws_bytes, wchunk, Kw, s, timer, tag);
+                                       out_neg, ws, ws_bytes, wchunk, Kw, s, timer, tag, region);
     }
     if (tag) { memset(tag->built, 0, sizeof(tag->built)); tag->replayed = 0; }   // (the per-batch planner overwrites the workspace)
     const int64_t chunk = max_chunk(ws_bytes, E, batch);
@@ -394,6 +448,21 @@ int tpnet_pair_gram_anchored_supported(const tpnet_state* st) {
 
 size_t tpnet_workspace_bytes(int64_t max_edges, int64_t batch) { return plan_bytes(max_edges, batch); }
 
+// bytes for a stream of max_edges on the windowed schedule in chunks of at most chunk_cap edges: one chunk's plan, or -- several
+// chunks -- their plans side by side in front of one version log (the layout a replay needs, window_chunk), up to ARENA_MAX_CHUNKS
+static size_t windowed_workspace_bytes(int64_t N, int d, int L, int64_t max_edges, int64_t batch, int64_t chunk_cap) {
+    int K = 0;
+    int64_t Ew = 0;
+    int64_t lim = window_chunk_limit(N, d, L, max_edges, batch, 0u, &K, &Ew);
+    if (lim == 0) return 0;
+    if (chunk_cap > 0 && lim > chunk_cap) lim = chunk_cap;
+    const size_t one = wplan_bytes(lim, batch, N, d, L);
+    const int64_t c = lim / Ew * Ew;                                    // chunks of a stream that takes several: whole windows
+    if (lim >= max_edges || c < 4 * batch || (max_edges + c - 1) / c > ARENA_MAX_CHUNKS) return one;
+    const size_t all = arena_bytes(N, d, L, max_edges, c, batch);
+    return all > one ? all : one;
+}
+
 size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch) {
     if (max_edges < 1) max_edges = 1;
     if (batch < 1) batch = 1;
@@ -401,22 +470,23 @@ size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max
     // windowed one; longer streams are walked chunk by chunk
     const int64_t cap_a = (2000000 / batch > 0 ? 2000000 / batch : 1) * batch;
     const size_t a = plan_bytes(max_edges < cap_a ? max_edges : cap_a, batch);
-    size_t b = 0;
-    if (wplan_window_batches(batch, d, L) > 0) {
-        const int64_t cap_b = wplan_max_chunk_edges(batch, d, L);
-        b = wplan_bytes(max_edges < cap_b ? max_edges : cap_b, batch, N, d, L);
-    }
+    const size_t b = windowed_workspace_bytes(N, d, L, max_edges, batch, 0);
     return a > b ? a : b;
 }
 
 size_t tpnet_stream_workspace_bytes_capped(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch,
                                            size_t log_cap_bytes) {
     if (log_cap_bytes == 0 || L < 1 || d < 1) return tpnet_stream_workspace_bytes(N, d, L, max_edges, batch);
+    if (max_edges < 1) max_edges = 1;
     if (batch < 1) batch = 1;
     int64_t e = (int64_t)(log_cap_bytes / (2 * (size_t)L * (size_t)d * 4));
     e = e / batch * batch;
     if (e < 4 * batch) e = 4 * batch;                      // (the windowed schedule needs at least four batches per chunk)
-    return tpnet_stream_workspace_bytes(N, d, L, max_edges < e ? max_edges : e, batch);
+    const int64_t cap_a = (2000000 / batch > 0 ? 2000000 / batch : 1) * batch;
+    const int64_t ea = max_edges < e ? max_edges : e;
+    const size_t a = plan_bytes(ea < cap_a ? ea : cap_a, batch);
+    const size_t b = windowed_workspace_bytes(N, d, L, max_edges, batch, e);
+    return a > b ? a : b;
 }
 
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,

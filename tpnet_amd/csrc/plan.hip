@@ -979,13 +979,21 @@ size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L) {
     return plan_bytes(max_edges, batch) + wplan_extra_bytes(max_edges, batch, N, d, L, K);
 }
 
-int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out) {
+size_t wplan_log_bytes(int64_t max_edges, int d, int L) {
+    if (max_edges < 1) max_edges = 1;
+    return align_up(2 * (size_t)max_edges * (size_t)L * (size_t)d * 4, 256);
+}
+
+// `shared_log` (may be null): the version log lives there instead of inside [ws, ws + ws_bytes) -- the plans of the chunks of a
+// multi-chunk stream each keep a region of their own (so that every one of them can be replayed, api.hip) and share ONE log
+int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out, float* shared_log) {
     if (K < 1 || K > WIN_MAX_BATCHES || K > wplan_window_batches(batch, d, L)) return TPNET_ERR_BAD_ARG;
     if (Ec > wplan_max_chunk_edges(batch, d, L)) return TPNET_ERR_BAD_ARG;
     int rc = plan_carve(ws, ws_bytes, Ec, batch, &out->base);
     if (rc) return rc;
     const size_t base_bytes = plan_bytes(Ec, batch);
-    if (base_bytes + wplan_extra_bytes(Ec, batch, N, d, L, K) > ws_bytes) return TPNET_ERR_WORKSPACE;
+    if (base_bytes + wplan_extra_bytes(Ec, batch, N, d, L, K) - (shared_log ? wplan_log_bytes(Ec, d, L) : 0) > ws_bytes)
+        return TPNET_ERR_WORKSPACE;
     char* p = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(ws), 256)) + align_up(base_bytes, 256);
     // (plan_carve aligned the base the same way; plan_bytes includes its slack)
     auto take = [&](size_t bytes) -> void* {
@@ -1004,7 +1012,7 @@ int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N,
     (void)take(256);
     out->e_ref = (uint32_t*)take(3 * (size_t)Ec * 4);
     out->e_g = (float*)take(3 * (size_t)Ec * 4);
-    out->log = (float*)take(nc * (size_t)L * (size_t)d * 4);
+    out->log = shared_log ? shared_log : (float*)take(nc * (size_t)L * (size_t)d * 4);
     out->node_lo = (uint32_t*)take((size_t)N * 4);
     out->node_hi = (uint32_t*)take((size_t)N * 4);
     out->inv = (uint32_t*)take(nc * 4);

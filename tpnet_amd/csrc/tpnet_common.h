@@ -303,7 +303,9 @@ struct WPlan {
 size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L);
 int wplan_window_batches(int64_t batch, int d, int L);                 // 0 = the windowed path does not apply
 int64_t wplan_max_chunk_edges(int64_t batch, int d, int L);            // edges one plan (and its log) may cover
-int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out);   // K <= wplan_window_batches
+int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out,
+                float* shared_log = nullptr);   // K <= wplan_window_batches; shared_log: the version log lives outside the region
+size_t wplan_log_bytes(int64_t max_edges, int d, int L);       // the version log's share of wplan_bytes
 int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                 const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
                 bool want_readout, hipStream_t s);

@@ -95,6 +95,7 @@ class _Stage:
 class RandomProjectionModule(nn.Module):
     # plan-replay bookkeeping (class-level defaults: tpnet_amd/matrix_memory.py builds instances without this constructor)
     _table_sig = 0
+    stream_log_cap_bytes = None     # bound on the windowed schedule's version log per chunk (None: the library's default)
     _sig_counter = 1
     _plan_tag = None
 
@@ -309,19 +310,24 @@ class RandomProjectionModule(nn.Module):
 
     def _workspace(self, max_edges: int, batch: int, stream: bool = False, tail: int = 0, keep_plan: bool = False):
         """Plan workspace.  `stream`: sized for tpnet_run_stream (the windowed schedule's plan + version log where it applies),
-        capped at one chunk of the stream -- the C side walks longer streams chunk by chunk."""
+        capped at one chunk of the stream -- the C side walks longer streams chunk by chunk -- or, up to 64 chunks, the chunks'
+        plans side by side in front of one version log (what lets a multi-chunk stream replay its plan).  `stream_log_cap_bytes`
+        (None: the library's 16 GiB) bounds the version log, i.e. the chunk, for a caller short of memory."""
         eng = self._engine()
         cache = self.__dict__.setdefault("_ws_need", {})
-        need = cache.get((max_edges, batch, stream, tail))
+        cap = int(self.stream_log_cap_bytes or 0) if stream else 0
+        need = cache.get((max_edges, batch, stream, tail, cap))
         if need is None:
-            if stream:
+            if stream and cap:
+                need = _lib.load().tpnet_stream_workspace_bytes_capped(self.node_num, self.dim, self.num_layer, max_edges, batch, cap)
+            elif stream:
                 need = _lib.load().tpnet_stream_workspace_bytes(self.node_num, self.dim, self.num_layer, max_edges, batch)
             else:
                 need = _lib.load().tpnet_workspace_bytes(max_edges, batch)
             need = (need + 255) // 256 * 256 + tail
             if len(cache) > 64:
                 cache.clear()
-            cache[(max_edges, batch, stream, tail)] = need
+            cache[(max_edges, batch, stream, tail, cap)] = need
         if eng["ws"] is None or eng["ws"].numel() < need:
             eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
             self._drop_plan()
