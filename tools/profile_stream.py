@@ -13,12 +13,14 @@ ap.add_argument("--reps", type=int, default=3); ap.add_argument("--batch", type=
 ap.add_argument("--edges", type=int, default=0, help="exact stream length (overrides --batches; -1 = the config's own E)")
 ap.add_argument("--schedule", default=None)
 ap.add_argument("--replay", action="store_true", help="let every repetition after the first replay the stream's plan (a later epoch)")
+ap.add_argument("--pu", type=float, default=2.0, help="degree-law exponent of the users (1.0 = uniform)")
+ap.add_argument("--pi", type=float, default=3.0, help="degree-law exponent of the items (1.0 = uniform)")
 a = ap.parse_args()
 c = dict(CONFIGS[a.config]); c["d"] = a.dim or c["d"]; B = a.batch or c["B"]; E = a.batches * B
 if a.edges:
     E = c["E"] if a.edges < 0 else a.edges
     a.batches = (E + B - 1) // B
-src, dst, t, N = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0)
+src, dst, t, N = synthetic_stream(c["U"], c["I"], E, c["span"] * E / c["E"], 0, a.pu, a.pi)
 print(f"{a.config}: N={N} E={E} d={c['d']} state {(2 * N * 3 + N) * c['d'] * 4 / 1e9:.1f} GB", flush=True)
 neg = synthetic_negatives(c["U"], N, E, B, 1)
 dev = torch.device("cuda:0")
