@@ -271,9 +271,13 @@ def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
             return {"value": nbe * B / el_, "unit": "edges/s", "us_per_batch": el_ / nbe * 1e6,
                     "what": "encoder_level_device as a training step issues it (gradients through self.mlp of every call, Adam step per batch)"}
         if _lib_anchored_ok(rp):
-            res["encoder_level_device"] = device_loop(
+            # (the faster of two passes, as encoder_level above -- a pass is ~3 ms; both passes are listed)
+            passes_ = [device_loop(
                 f"neighbour ids resident on the device: 2 x encoder_pair_features on the batch's host arrays (staged, no copy; device sampler, K = {K}; "
-                f"anchored readout of 4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls")
+                f"anchored readout of 4*B*K = {4 * B * K} pairs; self.mlp fp32) + the decoder-level calls; the faster of two passes of {nbe} batches")
+                for _ in range(2)]
+            res["encoder_level_device"] = min(passes_, key=lambda r_: r_["us_per_batch"])
+            res["encoder_level_device"]["passes_us_per_batch"] = [r_["us_per_batch"] for r_ in passes_]
             try:
                 device_train_loop()
                 tr_ = device_train_loop()

@@ -1060,8 +1060,10 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     np.testing.assert_array_equal(e4[2], c1[2])
 
 
-@pytest.mark.parametrize("d,L,N,B,nb,per", [(64, 3, 2000, 100, 300, 130), (128, 3, 9000, 1000, 70, 30), (64, 2, 3000, 200, 150, 70)])
-def test_plan_replay_of_a_stream_of_several_chunks(d, L, N, B, nb, per):
+@pytest.mark.parametrize("d,L,N,B,nb,per,packed", [(64, 3, 2000, 100, 300, 130, False), (128, 3, 9000, 1000, 70, 30, False),
+                                                   (64, 2, 3000, 200, 150, 70, False),
+                                                   (64, 2, 4000, 1170, 90, 45, True)])      # (packed rows of 21 floats: chunks of whole 16 bytes)
+def test_plan_replay_of_a_stream_of_several_chunks(d, L, N, B, nb, per, packed):
     """A stream longer than one chunk (here: the version log capped at `per` batches' worth, `stream_log_cap_bytes`; without a cap:
     beyond 16 GiB of log or 256 windows) keeps the plan of EVERY chunk -- one region per chunk in front of the one log they share
     (api.hip, window_chunk / run_stream_windowed) -- so the second epoch replays all of them: same bits as the cold one-chunk run,
@@ -1081,7 +1083,7 @@ def test_plan_replay_of_a_stream_of_several_chunks(d, L, N, B, nb, per):
     def epoch(rp, negs, **kw):
         rp.reset_random_projections()
         rp.random_projections[0].data.copy_(torch.from_numpy(P0))
-        fp, fn = rp.run_stream(ds, dd, negs, dt, B, schedule="windowed", **kw)
+        fp, fn = rp.run_stream(ds, dd, negs, dt, B, schedule="windowed", packed=packed, **kw)
         return fp.clone(), fn.clone(), _layers(rp), rp.last_stream_replayed
 
     one = _module(N, d, L, lam, t[0], P0=P0)
