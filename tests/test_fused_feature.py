@@ -448,6 +448,13 @@ def test_encoder_pattern_on_host_arrays_is_recognised(d, K, m):
     gy = torch.randn_like(want)
     _assert_mlp_grads_close(rp.mlp, gram, gy, torch.autograd.grad(got, list(rp.mlp.parameters()), gy),
                             torch.autograd.grad(want, list(rp.mlp.parameters()), gy))
+    # python-style negative ids (ATen indexing, as the reference's P[i][ids]): the one-call path declines, the general path wraps
+    un = u.copy()
+    un[0] = un[n // 2] = -1
+    uw = u.copy()
+    uw[0] = uw[n // 2] = N - 1
+    with torch.no_grad():
+        assert torch.equal(rp.get_pair_wise_feature(un, v), rp.get_pair_wise_feature(uw, v))
     # an id out of range is still an IndexError (the detector declines, the general path reports)
     bad = v.copy()
     bad[3] = N

@@ -95,7 +95,9 @@ class _Stage:
 class RandomProjectionModule(nn.Module):
     # plan-replay bookkeeping (class-level defaults: tpnet_amd/matrix_memory.py builds instances without this constructor)
     _table_sig = 0
-    stream_log_cap_bytes = None     # bound on the windowed schedule's version log per chunk (None: the library's default)
+    # bound on the windowed schedule's version log per chunk when run_stream sizes its workspace (None: the library's 16 GiB); a
+    # workspace that is already larger keeps its chunk length -- the C side takes the longest chunk the workspace holds
+    stream_log_cap_bytes = None
     _sig_counter = 1
     _plan_tag = None
 
