@@ -1132,6 +1132,29 @@ def epoch_update_only(rp, ds, dd, dt, B, P0):
     return rp.last_stream_replayed
 
 
+@pytest.mark.parametrize("d,L,N,B,nb", [(120, 3, 9000, 20, 67), (128, 3, 500, 37, 40), (64, 2, 300, 50, 25), (256, 3, 200, 13, 30)])
+@pytest.mark.parametrize("schedule", ["windowed", "batch"])
+def test_stream_with_no_negatives_at_all(d, L, N, B, nb, schedule):
+    """run_stream(src, dst, None, t): the (src, dst) features and the update alone -- no negative ids exist, the pointer the
+    kernels get is null.  (Found by tools/soak_chunks.py: the pipeline's readout let the lane groups PAST the end of a window's
+    pair list form the address neg[e0] -- a fault at address 0 whenever the window's pairs did not fill its last workgroup.)
+    Same features and state as the run that also reads out the negatives."""
+    _need_gpu()
+    rng = np.random.RandomState(d + B)
+    E = nb * B - B // 2
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    a = _module(N, d, L, 2e-6, t[0], P0=P0)
+    pa, na = a.run_stream(ds, dd, dn, dt, B, schedule=schedule)
+    b = _module(N, d, L, 2e-6, t[0], P0=P0)
+    pb, nb_ = b.run_stream(ds, dd, None, dt, B, schedule=schedule)
+    assert nb_ is None and torch.equal(pa, pb)
+    np.testing.assert_array_equal(_layers(a), _layers(b))
+    b.check_device_errors()
+
+
 @pytest.mark.parametrize("nb,d,N,B", [(15, 64, 500, 100), (16, 64, 500, 100), (60, 64, 500, 100),
                                       (20, 128, 9228, 1000)])     # (the driver's timed shape: C2, 20 batches)
 def test_auto_schedule_on_both_sides_of_its_threshold(nb, d, N, B):

@@ -816,7 +816,7 @@ __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpip
             const bool valid = pw < npairs;
             // (src,dst) and (src,neg) of one edge sit in adjacent lane groups: the src rows are fetched by the same instructions
             const int64_t idx = valid ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
-            const bool isneg = both ? (pw & 1) != 0 : (pw >= npos);
+            const bool isneg = valid && (both ? (pw & 1) != 0 : (pw >= npos));      // (a lane group past the list reads dst[e0]: `neg` may be null)
             const int64_t e = e0 + idx;
             int64_t ids[2] = {a.src[e], isneg ? a.neg[e] : a.dst[e]};
             const int which[2] = {0, isneg ? 2 : 1};
