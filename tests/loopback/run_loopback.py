@@ -57,6 +57,16 @@ def main():
     cfgs = [(211, 128, 3, 700, 100, 2e-6), (150, 64, 2, 333, 50, 1e-6), (3000, 128, 3, 900, 60, 2e-6)]
     if os.environ.get("TPNET_LOOPBACK_ONE"):
         cfgs = cfgs[:1]
+    if os.environ.get("TPNET_LOOPBACK_RANDOM"):            # "cases,seed": random shapes instead (a development soak, not the test)
+        ncase, seed = (int(x) for x in os.environ["TPNET_LOOPBACK_RANDOM"].split(","))
+        rg = np.random.RandomState(seed)
+        cfgs = []
+        for _ in range(ncase):
+            B = int(rg.choice([1, 3, 16, 50, 100, 257]))
+            nbr = int(rg.randint(1, 30))
+            cfgs.append((int(rg.choice([60, 211, 1000, 5000])), int(rg.choice([32, 64, 128, 256, 120])), int(rg.choice([1, 2, 3, 3, 4])),
+                         max(1, nbr * B - int(rg.randint(0, B))), B, float(rg.choice([1e-6, 2e-6, 1e-7]))))
+        print("random shapes:", cfgs, flush=True)
     lib = _lib.load()
     so = os.path.join(HERE, "librccl_loopback.so").encode()
     loop = C.CDLL(so.decode())
@@ -112,7 +122,7 @@ def main():
         torch.cuda.synchronize()
         assert loop.tpnet_loopback_pending() == 0, "unmatched sends / receives left behind"
         cnt = [loop.tpnet_loopback_count(k) - before[k] for k in range(4)]
-        assert cnt[0] == cnt[1] == cnt[2] and cnt[0] > 0 and cnt[3] == 0, cnt
+        assert cnt[0] == cnt[1] == cnt[2] and (cnt[0] > 0 or os.environ.get("TPNET_LOOPBACK_RANDOM")) and cnt[3] == 0, cnt   # (a one-edge stream may send nothing)
         for r in range(2):
             runs[r].rp.check_device_errors()
             assert lib.tpnet_rccl_comm_destroy(comms[r]) == 0
@@ -160,7 +170,10 @@ def main():
         scale = float(rl[1:].abs().max())
         e_f = max(float((fpA - rfp).abs().max()), float((fnA - rfn).abs().max()))
         e_s = float((layA[1:] - rl[1:]).abs().max()) / scale
-        assert e_f < 2e-4 and e_s < 1e-5 and torch.equal(layA[0], rl[0]), (e_f, e_s)
+        # (a feature is log(1 + G) of a Gram entry whose f32 sum carries ~1e-6 |R_a| |R_b| whatever its order: the random shapes of
+        # the soak have hubs whose rows are long)
+        tol_f = 2e-4 if not os.environ.get("TPNET_LOOPBACK_RANDOM") else 2e-4 + 2e-6 * float(rl.norm(dim=2).max()) ** 2
+        assert e_f < tol_f and e_s < 1e-5 and torch.equal(layA[0], rl[0]), (e_f, tol_f, e_s)
         assert float(runs[0].rp.now_time.item()) == float(t[-1])
         summary.append((N, d, L, nb, cnt[0], e_f, e_s))
     print("LOOPBACK OK " + "; ".join(f"N={a} d={b_} L={c} batches={n}: {s_} messages, features {ef:.1e}, state {es:.1e} from one GPU"
