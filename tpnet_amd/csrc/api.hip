@@ -120,7 +120,23 @@ static int64_t window_chunk(const tpnet_state& st, size_t ws_bytes, int64_t E, i
         const int64_t mid = (lo + hi) / 2;
         if (wplan_bytes(mid * Ew, batch, st.N, st.d, st.L) <= ws_bytes) lo = mid; else hi = mid;
     }
-    return lo * Ew;
+    if (lo > 0) return lo * Ew;
+    // not even one window of Kmax batches (a caller who capped the version log below that): chunks of fewer batches -- the window
+    // length is chosen per chunk (window_batches_for) -- down to what the pipeline still wins at; a replayable layout first
+    const int K = *K_out;
+    const int64_t u = Ew / K;                                              // one batch (packed rows: whole 16 bytes of output)
+    const int64_t n_min = ((flags & TPNET_FLAG_SCHED_WINDOWED) ? 4 : min_nb) * batch;
+    if (region_out && batch <= PLAN_ONE_MAX && !(flags & TPNET_FLAG_PLAN_SORTED))
+        for (int64_t n = K - 1; n >= 1 && n * u >= n_min; --n) {
+            const int64_t c = n * u;
+            if (c < E && (E + c - 1) / c <= ARENA_MAX_CHUNKS && arena_bytes(st.N, st.d, st.L, E, c, batch) <= ws_bytes) {
+                *region_out = arena_region_bytes(st.N, st.d, st.L, c, batch);
+                return c;
+            }
+        }
+    for (int64_t n = K - 1; n >= 1 && n * u >= n_min; --n)
+        if (n * u < E && wplan_bytes(n * u, batch, st.N, st.d, st.L) <= ws_bytes) return n * u;
+    return 0;
 }
 
 // Batches per window of a chunk of nb batches.  A pipeline of nw windows is nw + L dependent launches, each a fixed floor
@@ -457,7 +473,8 @@ static size_t windowed_workspace_bytes(int64_t N, int d, int L, int64_t max_edge
     if (lim == 0) return 0;
     if (chunk_cap > 0 && lim > chunk_cap) lim = chunk_cap;
     const size_t one = wplan_bytes(lim, batch, N, d, L);
-    const int64_t c = lim / Ew * Ew;                                    // chunks of a stream that takes several: whole windows
+    int64_t c = lim / Ew * Ew;                                          // chunks of a stream that takes several: whole windows,
+    if (c == 0) c = lim / (Ew / K) * (Ew / K);                          // or, under a cap below one window of K batches, whole batches
     if (lim >= max_edges || c < 4 * batch || (max_edges + c - 1) / c > ARENA_MAX_CHUNKS) return one;
     const size_t all = arena_bytes(N, d, L, max_edges, c, batch);
     return all > one ? all : one;
