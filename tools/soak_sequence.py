@@ -13,6 +13,11 @@ nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 DEV = "cuda:0"
 replays = 0
+# TPNET_SOAK_STREAM=1: every call under a stream of its own instead of the default one (the library takes torch's current stream)
+side = torch.cuda.Stream() if os.environ.get("TPNET_SOAK_STREAM") else None
+if side is not None:
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(side)
 for seq in range(nseq):
     d = int(rng.choice([32, 64, 128, 256])); L = int(rng.choice([2, 3, 3, 4])); N = int(rng.choice([90, 400, 3000]))
     B = int(rng.choice([16, 50, 100, 400])); nbt = int(rng.randint(40, 120)); E = nbt * B
