@@ -83,30 +83,66 @@ def _cpu_model():
     return None
 
 
-def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3):
+def _physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo; logical CPUs / 2 as a fallback)."""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3, quick=False):
     """the torch-CPU port of the reference ops (oracle/torch_port.py, eager dense decay included) on
-    this box's host cores, on a bounded prefix of the same workload: 2 warm-up batches, `reps` repetitions, median; all
-    (up to 16) cores and the reference's own 3 intra-op threads (train_link_prediction.py:124); update-only, readout-only
-    and combined rates, with and without rp.mlp."""
-    threads = min(os.cpu_count() or 1, 16)
+    this box's host cores, on a bounded prefix of the same workload: 2 warm-up batches, `reps` repetitions, median.  Settings: ALL
+    physical cores this process may use (`cores` = the threads actually used), 16 threads, and the
+    reference's own 3 intra-op threads (train_link_prediction.py:124); update-only, readout-only and combined rates, with and
+    without rp.mlp.  `value` = the all-cores figure (more threads are not faster on these small ops: the 3-thread figure beats
+    both on a 2 x 64-core host -- all three are reported).  quick: one repetition, no mlp leg (the N > 1 line)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    threads_all = max(1, min(_physical_cores(), usable))
+    threads16 = min(usable, 16)
     B = cfg["B"]
-    nb = max(3, min(len(src) // B - 2, max(3, 400000 // B)))     # ~400 000 edges per repetition: 9 repetitions = 10-15 s of CPU work
+    nb = max(3, min(len(src) // B - 2, max(3, (150000 if quick else 400000) // B)))   # ~400 000 edges per repetition
     med = lambda xs: float(np.median(xs))
+    settings = [("all", threads_all, False), ("16thr", threads16, False), ("3thr", 3, False)]
+    if not quick:
+        settings.append(("all_mlp", threads_all, True))
     out = {}
-    for name, th, mlp in (("all", threads, False), ("3thr", 3, False), ("all_mlp", threads, True)):
+    for name, th, mlp in settings:
+        if name == "16thr" and th == threads_all:
+            out[name] = out["all"]
+            continue
         runs = [_cpu_port_times(cfg, src, dst, neg, t, P0, th, nb, mlp) for _ in range(reps)]
         n = nb * B
         out[name] = {"combined": n / med([a + b for a, b in runs]), "readout_only": n / med([a for a, _ in runs]),
                      "update_only": n / med([b for _, b in runs])}
-    torch.set_num_threads(threads)
-    return {"value": out["all"]["combined"], "unit": "edges/s", "cores": threads, "cpu_model": _cpu_model(),
-            "host_logical_cpus": os.cpu_count(), "kind": "port",
-            "readout_only": out["all"]["readout_only"], "update_only": out["all"]["update_only"],
-            "with_mlp": out["all_mlp"]["combined"], "value_3_threads": out["3thr"]["combined"],
-            "readout_only_3_threads": out["3thr"]["readout_only"], "update_only_3_threads": out["3thr"]["update_only"],
-            "repetitions": reps,
-            "sample": f"{nb} batches of {B} edges after 2 warm-up batches, median of {reps} repetitions per setting; torch-CPU "
-                      f"port of the reference ops incl. its eager dense decay; pre-mlp features unless with_mlp"}
+    torch.set_num_threads(threads16)
+    res = {"value": out["all"]["combined"], "unit": "edges/s", "cores": threads_all, "cpu_model": _cpu_model(),
+           "host_logical_cpus": os.cpu_count(), "host_physical_cores": _physical_cores(), "kind": "port",
+           "readout_only": out["all"]["readout_only"], "update_only": out["all"]["update_only"],
+           "value_16_threads": out["16thr"]["combined"], "value_3_threads": out["3thr"]["combined"],
+           "readout_only_3_threads": out["3thr"]["readout_only"], "update_only_3_threads": out["3thr"]["update_only"],
+           "repetitions": reps,
+           "sample": f"{nb} batches of {B} edges after 2 warm-up batches, median of {reps} repetitions per setting; torch-CPU "
+                     f"port of the reference ops incl. its eager dense decay; pre-mlp features unless with_mlp"}
+    if "all_mlp" in out:
+        res["with_mlp"] = out["all_mlp"]["combined"]
+    return res
 
 
 def dropin_rate(cfg, rp, src, dst, neg, t, nb=30):
@@ -320,9 +356,111 @@ def copy_bandwidth_gbs(dev):
     return 5 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+METRIC = "temporal edges/sec (proj-update + pairwise readout)"
+
+
+def _error_line(n_gpus, msg, **extra):
+    line = {"metric": METRIC, "value": None, "unit": "edges/s", "n_gpus": n_gpus, "error": msg}
+    line.update(extra)
+    return json.dumps(line)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launcher_command(n, argv, port, python=None, script=None):
+    """The child `python bench.py --gpus N ...` starts when nobody launched its ranks: the driver's own launch line
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>),
+    one rank per GPU.  Returns (argv list, environment)."""
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["TPNET_BENCH_LAUNCHED_BY"] = str(os.getpid())
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return cmd, env
+
+
+def pick_result_line(stdout_text):
+    """Rank 0's JSON line among whatever the ranks and the launcher printed (the last line that parses and names the metric)."""
+    found = None
+    for ln in stdout_text.splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                obj = json.loads(ln)
+            except ValueError:
+                continue
+            if isinstance(obj, dict) and "metric" in obj:
+                found = obj
+    return found
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks as a CHILD process -- this parent has
+    touched no GPU and never replaces itself -- relay rank 0's single JSON line, and fail unless all N ranks reported.  Returns
+    the exit code."""
+    import subprocess
+    backend = os.environ.get("TPNET_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()           # (counts devices without creating a context on this image)
+    if ndev < 1:
+        print(_error_line(n, "bench.py needs a GPU (no CPU fallback): no HIP device visible"), flush=True)
+        return 2
+    if backend == "nccl" and n > ndev:
+        print(_error_line(n, f"--gpus {n} but only {ndev} GPU(s) visible: one rank per GPU over RCCL (TPNET_BENCH_BACKEND=gloo "
+                             f"rehearses the N > 1 path with the ranks sharing a GPU)", gpus_visible=ndev), flush=True)
+        return 2
+    cmd, env = launcher_command(n, argv, free_port())
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True,
+                              timeout=float(os.environ.get("TPNET_BENCH_LAUNCH_TIMEOUT", "1500")))
+        out, rc = proc.stdout, proc.returncode
+    except subprocess.TimeoutExpired as ex:
+        out, rc = (ex.stdout or ""), 124
+        if isinstance(out, bytes):
+            out = out.decode(errors="replace")
+    line = pick_result_line(out)
+    for ln in out.splitlines():                      # whatever else the ranks printed goes to stderr: stdout carries ONE line
+        if not (ln.strip().startswith("{") and "metric" in ln):
+            print(ln, file=sys.stderr)
+    if line is None:
+        print(_error_line(n, f"the {n} ranks printed no result line (launcher exit code {rc})"), flush=True)
+        return rc or 1
+    print(json.dumps(line), flush=True)
+    if rc != 0:
+        return rc
+    if line.get("value") is None or line.get("n_gpus") != n or line.get("ranks_seen") != n:
+        print(f"bench.py: expected {n} ranks, the line says n_gpus={line.get('n_gpus')} ranks_seen={line.get('ranks_seen')}",
+              file=sys.stderr)
+        return 1
+    return 0
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources (tpnet_amd/csrc/*.hip|hpp|h|c + include/*.h, names and contents): what a committed PMC entry
+    is stamped with, and what bench.py recomputes at run time -- .git does not travel to the GPU box, file contents do."""
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for dname in (os.path.join(ROOT, "tpnet_amd", "csrc"), os.path.join(ROOT, "include")):
+        for fn in sorted(os.listdir(dname)):
+            if fn.endswith((".hip", ".hpp", ".h", ".c")):
+                files.append(os.path.join(dname, fn))
+    for fp in files:
+        h.update(os.path.basename(fp).encode() + b"\0")
+        h.update(open(fp, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="C2")
@@ -330,9 +468,19 @@ def main():
     ap.add_argument("--no-dropin", action="store_true")
     args = ap.parse_args()
 
+    # --gpus N with nobody having launched the ranks (the way the driver runs --gpus 1): this process starts them as a child
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if args.gpus is not None and args.gpus != world:
+        # never a silent n_gpus: 1 -- the flag and the launch must agree
+        if rank == 0:
+            print(_error_line(world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                                     f"(or run `python bench.py --gpus {args.gpus}` without a launcher)"), flush=True)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # TPNET_BENCH_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU (development only)
@@ -357,9 +505,8 @@ def main():
 
         def _give_up():
             if rank == 0:
-                print(json.dumps({"metric": "temporal edges/sec (proj-update + pairwise readout)", "value": None,
-                                  "unit": "edges/s", "n_gpus": world, "error": "multi-GPU run did not finish in time "
-                                  "(watchdog); set TPNET_ROWS_C_LOOP=0 to route the exchange through torch.distributed, TPNET_BENCH_EXCHANGE=allgather for the all-gather variant"}),
+                print(_error_line(world, "multi-GPU run did not finish in time (watchdog); set TPNET_ROWS_C_LOOP=0 to route the "
+                                         "exchange through torch.distributed, TPNET_BENCH_EXCHANGE=allgather for the all-gather variant"),
                       flush=True)
             os._exit(3)
         _wd = threading.Timer(float(os.environ.get("TPNET_BENCH_WATCHDOG", "420")), _give_up)
@@ -372,6 +519,7 @@ def main():
     cfg = CONFIGS[args.config]
     B, d, L = cfg["B"], cfg["d"], 3
     K, W = args.steps, args.warmup
+    lib_ = _lib.load()
 
     # N = 1: configs[1] as is.  N > 1: the SAME graph and table cut over the ranks, weak scaling: the global batch is N*B
     # edges per step (B per GPU), every rank holds the whole edge stream (32 bytes per edge).
@@ -412,6 +560,7 @@ def main():
 
 
     warm_windowed = False
+    rp = None
 
     def time_leg(run, k_steps, prep=None):
         """W untimed steps, then exactly k_steps timed ones between barrier + synchronize; max over ranks.  `prep(a, b)` (optional)
@@ -444,25 +593,181 @@ def main():
             el = float(tt.item())
         return el
 
-    def rows_leg(k_steps):
+    CSRC_SHA = csrc_fingerprint()
+
+    def pmc_traffic(cfg_name, kernel_short, edges_per_launch):
+        """Memory-side bytes per launch of this kernel from the NEWEST committed rocprofv3 PMC passes of the config
+        (tools/prof_round.sh -> profiles/r*_<config>_pmc.json), accepted only for the same kernel at the same work per launch
+        (+-10 %) AND only when the entry was taken on exactly these kernel sources (`csrc_sha` = csrc_fingerprint(): .git does not
+        travel to the GPU box, file contents do).  Otherwise traffic is None and traffic_source says why."""
+        import glob
+        import re
+        if cfg_name is None:
+            return None, {"stale": True, "reason": "no PMC pass for this workload"}
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{cfg_name}_pmc.json")),
+                       key=lambda q: int(re.search(r"r(\d+)_", os.path.basename(q)).group(1)), reverse=True)
+        why = "no committed PMC file for this config"
+        for path in paths:
+            try:
+                ents = json.load(open(path)).get("kernels", [])
+            except Exception:
+                continue
+            for ent in ents:
+                if ent.get("kernel") != kernel_short or not ent.get("traffic_bytes_per_launch") or \
+                        abs(ent.get("edges_per_launch", 0) - edges_per_launch) > 0.1 * edges_per_launch:
+                    continue
+                src_ = {"file": os.path.relpath(path, ROOT), "commit": ent.get("commit"), "csrc_sha": ent.get("csrc_sha"),
+                        "command": ent.get("command"), "edges_per_launch": ent.get("edges_per_launch")}
+                if ent.get("csrc_sha") == CSRC_SHA:
+                    src_["stale"] = False
+                    return ent["traffic_bytes_per_launch"], src_
+                why = (f"newest matching entry ({src_['file']}, commit {src_['commit']}) was taken on other kernel sources "
+                       f"(csrc_sha {ent.get('csrc_sha')} != {CSRC_SHA}): re-run tools/prof_round.sh")
+            if why.startswith("newest"):
+                break
+        return None, {"stale": True, "reason": why, "csrc_sha_now": CSRC_SHA}
+
+    def roof_pass(a_src, a_dst, a_neg, a_t, n_edges_in, t_now, t_last, o_pos, o_neg, flags=0, rp_=None, B_=None, d_=None, N_=None,
+                  cfg_name="__main__"):
+        rp_ = rp if rp_ is None else rp_
+        B_ = B if B_ is None else B_
+        d_ = d if d_ is None else d_
+        N_ = N if N_ is None else N_
+        cfg_name = args.config if cfg_name == "__main__" else cfg_name
+        lib = _lib.load()
+        st = rp_._state()
+        ws = rp_._workspace(n_edges_in, B_, stream=True)
+        total_ms, kern_ms = C.c_float(0), C.c_float(0)
+        n_launch, n_edges = C.c_int64(0), C.c_int64(0)
+        nbat = (n_edges_in + B_ - 1) // B_
+        lid = rp_._next_launch_ids(3 * nbat + 8)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.tpnet_time_stream(C.byref(st), a_src.data_ptr(), a_dst.data_ptr(), a_neg.data_ptr(),
+                                         a_t.data_ptr(), n_edges_in, B_, t_now, float(rp_.time_decay_weight), lid, flags,
+                                         o_pos.data_ptr(), o_neg.data_ptr(), ws.data_ptr(), ws.numel(), 1,
+                                         C.byref(total_ms), C.byref(kern_ms), C.byref(n_launch), C.byref(n_edges), stream),
+                   "time_stream")
+        rp_._now_host = t_last
+        rp_._params_valid = False
+        rp_._now_dirty = True
+        rp_._table_written()
+        bpe = bytes_per_edge(d_, L)
+        windowed = n_launch.value > 0 and n_launch.value < nbat                     # fewer launches than batches
+        bytes_per_launch = bpe * n_edges.value / max(1, n_launch.value)
+        achieved = bytes_per_launch / (kern_ms.value * 1e-3) / 1e9 if kern_ms.value > 0 else 0.0
+        kshort = "k_wpipe" if windowed else "k_step"
+        traffic, traffic_src = pmc_traffic(cfg_name, kshort, n_edges.value / max(1, n_launch.value))
+        kname = ("k_wpipe (windowed schedule: one launch per pipeline step = layer i of window j-i+1, i=1..L, + the readouts of "
+                 "window j-L)") if windowed else "k_step (fused readout + update of one batch; one launch per step)"
+        # (cache-resident configs: the algorithmic rate can exceed what the memory side delivers; the memory-side rate from the
+        # committed counters -- bytes that really crossed the Infinity Cache / HBM boundary per launch -- is the one to hold
+        # against the 8 TB/s peak there)
+        mem_gbs = traffic / (kern_ms.value * 1e-3) / 1e9 if (traffic and kern_ms.value > 0) else None
+        # A table that sits in the 256 MB Infinity Cache is not served by HBM: where the section-8(d) byte count over time exceeds
+        # the HBM peak (the fused kernel moves fewer bytes than the unfused count at such shapes), the line says bound = "cache" and
+        # `frac` is the memory-side fraction (PMC bytes over time over 8 TB/s; null without counters) -- never a fraction above 1
+        # under bound = "hbm".  The algorithmic figure stays beside it.
+        frac_alg = achieved / HBM_PEAK_GBS
+        cache_bound = (28.0 * N_ * d_ < 256e6) and frac_alg > 1.0
+        return {"bound": "cache" if cache_bound else "hbm", "kernel": kname, "kernel_short": kshort, "windowed": windowed,
+                "achieved": (mem_gbs if cache_bound else achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ((mem_gbs / HBM_PEAK_GBS) if mem_gbs else None) if cache_bound else frac_alg,
+                "algorithmic_gbs": achieved, "algorithmic_frac": frac_alg,
+                "traffic": traffic, "traffic_source": traffic_src, "steps": nbat,
+                "memory_side_gbs": mem_gbs, "memory_side_frac": (mem_gbs / HBM_PEAK_GBS) if mem_gbs else None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "launches": n_launch.value,
+                "edges_per_launch": n_edges.value / max(1, n_launch.value),
+                "avg_launch_period_us": kern_ms.value * 1e3,
+                "stream_ms_events": total_ms.value,
+                "end_to_end_frac": (bpe * n_edges_in / (total_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS) if total_ms.value > 0 else None}
+
+    def sharded_rows(N_, d_, lam_, E_cfg, Bg_, arrs, t_host, k_steps, draw_on_device=False):
+        """The row-sharded runner (tpnet_amd/sharded.py: ShardedStreamRunner, targeted exchange) over the resident stream `arrs` =
+        (src, dst, neg, t) in global batches of Bg_: W warm-up steps, k_steps timed ones (time_leg), then an extra pass over the SAME
+        timed batches with HIP events on the launch stream around every step (every rank: the exchange is collective).  Returns
+        the elapsed seconds, the bytes of table a rank holds, and the kernel / exchange figures of THIS rank."""
         from tpnet_amd.sharded import ShardedStreamRunner
-        runner = ShardedStreamRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L, time_decay_weight=cfg["lam"],
-                                            device=dev, beginning_time=np.float64(0.0), halo_rows=3 * Bg)
+        a_src, a_dst, a_neg, a_t = arrs
+        runner = ShardedStreamRunner.create(node_num=N_, edge_num=E_cfg, dim=d_, num_layer=L, time_decay_weight=lam_,
+                                            device=dev, beginning_time=np.float64(0.0), halo_rows=3 * Bg_,
+                                            draw_on_device=draw_on_device)
         # targeted exchange (every row only to the ranks that read it, received in place, grouped ncclSend / ncclRecv from C);
         # TPNET_BENCH_EXCHANGE=allgather: one all-gather of every touched row per step
         runner.exchange = os.environ.get("TPNET_BENCH_EXCHANGE", "targeted")
-        runner.rp._workspace(max(k_steps, W) * Bg, Bg)
+        rp_ = runner.rp
+        rp_._ensure_engine()
+        NG_ = rp_.pair_wise_feature_dim
+        n_max = max(k_steps, W) * Bg_
+        # outputs and workspaces exist, and were touched, before any clock starts (as on the single-GPU path)
+        o_pos = torch.zeros((n_max, NG_), dtype=torch.float32, device=dev)
+        o_neg = torch.zeros((n_max, NG_), dtype=torch.float32, device=dev)
+        single_sched = runner.G == 1 and runner.single_rank_pipeline          # (a forced one-rank run: the module's own schedules)
+        if single_sched:
+            rp_.reserve_stream(n_max, Bg_)
+            rp_._eng["ws"].zero_()
+            ws_b = rp_._eng["ws"].numel()
+            will_window = bool(lib_.tpnet_stream_schedule(rp_.node_num, d_, L, k_steps * Bg_, Bg_, 0, ws_b) == 1)
+        else:
+            rp_._workspace(n_max, Bg_)
+            will_window = False
 
-        def run(a, b_):
-            sl_ = slice(a * Bg, b_ * Bg)
-            t_last = t[np.minimum(np.arange(a + 1, b_ + 1) * Bg, len(t)) - 1]
+        def run(a, b_, timing=None):
+            sl_ = slice(a * Bg_, b_ * Bg_)
+            n_ = (b_ - a) * Bg_
+            t_last = t_host[np.minimum(np.arange(a + 1, b_ + 1) * Bg_, len(t_host)) - 1]
+            # (a warm-up call of >= 4 batches runs the schedule the timed call will run: its kernels are loaded before the clock starts)
+            runner.schedule = "windowed" if (will_window and b_ <= W and b_ - a >= 4) else None
             # features stay sharded by the owner of the pair's src node (a sharded decoder consumes them in place)
-            runner.run_stream(d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], Bg, t_host_last=t_last, merge_outputs=False)
+            runner.run_stream(a_src[sl_], a_dst[sl_], a_neg[sl_], a_t[sl_], Bg_, t_host_last=t_last, merge_outputs=False,
+                              out_pos=o_pos[:n_], out_neg=o_neg[:n_], timing=timing)
+        nonlocal warm_windowed
+        warm_windowed = will_window
         el = time_leg(run, k_steps)
-        runner.rp.check_device_errors()
+        warm_windowed = False
+        rp_.check_device_errors()
         tb = runner.table_bytes()
+        # ---- the kernel those steps ran on, timed live: an extra pass over the same batches
+        bpe_ = bytes_per_edge(d_, L)
+        info = {}
+        if single_sched:
+            runner.rp.reset_random_projections()
+            sl_ = slice(W * Bg_, (W + k_steps) * Bg_)
+            info["roof"] = roof_pass(a_src[sl_], a_dst[sl_], a_neg[sl_], a_t[sl_], k_steps * Bg_, 0.0, float(t_host[(W + k_steps) * Bg_ - 1]),
+                                     o_pos[:k_steps * Bg_], o_neg[:k_steps * Bg_], rp_=rp_, B_=Bg_, d_=d_, N_=rp_.node_num,
+                                     cfg_name=None)
+        else:
+            tm = {}
+            run(W, W + k_steps, timing=tm)
+            per_launch_edges = Bg_ / world                      # this rank's share of a step: the pairs / targets it owns
+            ach = bpe_ * per_launch_edges / (tm["step_ms"] * 1e-3) / 1e9 if tm.get("step_ms") else 0.0
+            xc = runner.__dict__.get("_xplan_cache")
+            R_ = xc[1] if xc else None
+            rows_s = float(np.mean(R_["stot"])) if R_ is not None else 0.0
+            rows_r = float(np.mean(R_["rtot"])) if R_ is not None else 0.0
+            row_b = (L + 1) * d_ * 4
+            info["roof"] = {"bound": "hbm", "kernel": "k_step (fused readout + update of one batch, restricted to the pairs / targets this rank "
+                            "owns; one launch per step behind the step's exchange)", "kernel_short": "k_step", "windowed": False,
+                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                            "traffic_source": {"stale": True, "reason": "no PMC pass of the sharded step exists (one-GPU builder pool)"},
+                            "algorithmic_bytes_per_launch": bpe_ * per_launch_edges, "edges_per_launch": per_launch_edges,
+                            "launches": tm.get("batches"), "steps": tm.get("batches"),
+                            "avg_launch_period_us": tm.get("step_ms", 0.0) * 1e3, "stream_ms_events": tm.get("total_ms"),
+                            "rank": rank,
+                            "duration_note": "HIP events on the launch stream around every step launch of rank 0 (tpnet_time_rows_stream_targeted), "
+                                             "an extra pass over the timed batches; achieved = section-8(d) bytes per edge x this rank's "
+                                             "share of the global batch (1 / N of it) / the average step duration",
+                            "exchange": {"what": "per step: one pack launch + ONE grouped ncclSend / ncclRecv (rows received in place in the halo)",
+                                         "avg_us_per_step": tm.get("exchange_ms", 0.0) * 1e3,
+                                         "rows_sent_per_step": rows_s, "rows_received_per_step": rows_r,
+                                         "bytes_sent_per_step": rows_s * row_b, "bytes_received_per_step": rows_r * row_b,
+                                         "bytes_per_step_per_peer": (rows_s * row_b / (world - 1)) if world > 1 else 0.0,
+                                         "row_bytes": row_b, "transport": ("rccl (C loop)" if (R_ is not None and backend == "nccl") else backend)}}
         runner.close()
-        return el, tb
+        del o_pos, o_neg
+        return el, tb, info
+
+    def rows_leg(k_steps):
+        return sharded_rows(N, d, cfg["lam"], cfg["E"], Bg, (d_src, d_dst, d_neg, d_t), t, k_steps)
 
     def cols_leg(k_steps):
         from tpnet_amd.sharded import ColumnShardedRunner
@@ -477,7 +782,6 @@ def main():
         crun.rp.check_device_errors()
         return el
 
-    rp = None
     out_pos = out_neg = None
     regions = []
     if shard == "single":
@@ -498,7 +802,8 @@ def main():
         # the warm-up steps run the schedule the timed steps will run ("auto" picks the windowed pipeline from 16 batches of
         # <= 2048 edges, 56 larger ones; a warm-up call shorter than that would otherwise leave the pipeline's kernels to be
         # loaded inside the timed region: HIP resolves every kernel at its first launch, ~0.3 ms each)
-        timed_windowed = d % 4 == 0 and ((K >= 16 and Bg <= 2048) or (K >= 56 and Bg <= 4096))
+        # (asked of the library -- tpnet_stream_schedule -- not restated here: when the C side's threshold moves, this follows)
+        timed_windowed = lib_.tpnet_stream_schedule(N, d, L, K * Bg, Bg, 0, rp._eng["ws"].numel()) == 1
         warm_windowed = timed_windowed
 
         def prep(a, b_):
@@ -527,7 +832,7 @@ def main():
     elif shard == "cols":
         elapsed = cols_leg(K)
     else:
-        elapsed, row_bytes = rows_leg(K)
+        elapsed, row_bytes, rows_info = rows_leg(K)
 
     par = {"single": "single GPU",
            "cols": f"columns sharded over {world} GPUs ({d // world} of {d} per GPU), global batch {Bg} = {B} per GPU, no "
@@ -539,7 +844,7 @@ def main():
 
     def emit(row_info=None, roof=None, cpu=None, dropin=None, extra=None):
         line = {
-            "metric": "temporal edges/sec (proj-update + pairwise readout)",
+            "metric": METRIC,
             "value": K * Bg / elapsed, "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -591,68 +896,6 @@ def main():
     # region -- so `roofline` describes the kernel `value` was produced by (k_step below 16 batches, k_wpipe from there).
     roof = None
     extra = {}
-
-    def pmc_traffic(kernel_short, edges_per_launch):
-        """Memory-side bytes per launch of this kernel from this round's committed rocprofv3 PMC passes (tools/pmc.sh ->
-        profiles/r04_<config>_pmc.json), accepted only for the same kernel at the same work per launch (+-10 %)."""
-        path = os.path.join(ROOT, "profiles", f"r04_{args.config}_pmc.json")
-        try:
-            for ent in json.load(open(path)).get("kernels", []):
-                if ent.get("kernel") == kernel_short and ent.get("traffic_bytes_per_launch") and \
-                        abs(ent.get("edges_per_launch", 0) - edges_per_launch) <= 0.1 * edges_per_launch:
-                    return ent["traffic_bytes_per_launch"], {"file": os.path.relpath(path, ROOT), "commit": ent.get("commit"),
-                                                             "command": ent.get("command"), "edges_per_launch": ent.get("edges_per_launch")}
-        except Exception:
-            pass
-        return None, None
-
-    def roof_pass(a_src, a_dst, a_neg, a_t, n_edges_in, t_now, t_last, o_pos, o_neg, flags=0):
-        lib = _lib.load()
-        st = rp._state()
-        ws = rp._workspace(n_edges_in, B, stream=True)
-        total_ms, kern_ms = C.c_float(0), C.c_float(0)
-        n_launch, n_edges = C.c_int64(0), C.c_int64(0)
-        nbat = (n_edges_in + B - 1) // B
-        lid = rp._next_launch_ids(3 * nbat + 8)
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.tpnet_time_stream(C.byref(st), a_src.data_ptr(), a_dst.data_ptr(), a_neg.data_ptr(),
-                                         a_t.data_ptr(), n_edges_in, B, t_now, cfg["lam"], lid, flags,
-                                         o_pos.data_ptr(), o_neg.data_ptr(), ws.data_ptr(), ws.numel(), 1,
-                                         C.byref(total_ms), C.byref(kern_ms), C.byref(n_launch), C.byref(n_edges), stream),
-                   "time_stream")
-        rp._now_host = t_last
-        rp._params_valid = False
-        rp._now_dirty = True
-        rp._table_written()
-        bpe = bytes_per_edge(d, L)
-        windowed = n_launch.value > 0 and n_launch.value < nbat                     # fewer launches than batches
-        bytes_per_launch = bpe * n_edges.value / max(1, n_launch.value)
-        achieved = bytes_per_launch / (kern_ms.value * 1e-3) / 1e9 if kern_ms.value > 0 else 0.0
-        kshort = "k_wpipe" if windowed else "k_step"
-        traffic, traffic_src = pmc_traffic(kshort, n_edges.value / max(1, n_launch.value))
-        kname = ("k_wpipe (windowed schedule: one launch per pipeline step = layer i of window j-i+1, i=1..L, + the readouts of "
-                 "window j-L)") if windowed else "k_step (fused readout + update of one batch; one launch per step)"
-        # (cache-resident configs: the algorithmic rate can exceed what the memory side delivers; the memory-side rate from the
-        # committed counters -- bytes that really crossed the Infinity Cache / HBM boundary per launch -- is the one to hold
-        # against the 8 TB/s peak there)
-        mem_gbs = traffic / (kern_ms.value * 1e-3) / 1e9 if (traffic and kern_ms.value > 0) else None
-        # A table that sits in the 256 MB Infinity Cache is not served by HBM: where the section-8(d) byte count over time exceeds
-        # the HBM peak (the fused kernel moves fewer bytes than the unfused count at such shapes), the line says bound = "cache" and
-        # `frac` is the memory-side fraction (PMC bytes over time over 8 TB/s; null without counters) -- never a fraction above 1
-        # under bound = "hbm".  The algorithmic figure stays beside it.
-        frac_alg = achieved / HBM_PEAK_GBS
-        cache_bound = (28.0 * N * d < 256e6) and frac_alg > 1.0
-        return {"bound": "cache" if cache_bound else "hbm", "kernel": kname, "kernel_short": kshort, "windowed": windowed,
-                "achieved": (mem_gbs if cache_bound else achieved), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ((mem_gbs / HBM_PEAK_GBS) if mem_gbs else None) if cache_bound else frac_alg,
-                "algorithmic_gbs": achieved, "algorithmic_frac": frac_alg,
-                "traffic": traffic, "traffic_source": traffic_src, "steps": nbat,
-                "memory_side_gbs": mem_gbs, "memory_side_frac": (mem_gbs / HBM_PEAK_GBS) if mem_gbs else None,
-                "algorithmic_bytes_per_launch": bytes_per_launch, "launches": n_launch.value,
-                "edges_per_launch": n_edges.value / max(1, n_launch.value),
-                "avg_launch_period_us": kern_ms.value * 1e3,
-                "stream_ms_events": total_ms.value,
-                "end_to_end_frac": (bpe * n_edges_in / (total_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS) if total_ms.value > 0 else None}
 
     resident = 28.0 * N * d < 256e6
     if rank == 0 and shard == "single":
@@ -808,15 +1051,56 @@ def main():
             extra["long_stream"] = lr
             del o_pos, o_neg
 
+    # ---- N > 1 (or a forced one-rank run of that path): who took part, the kernel / exchange figures, and C4's law through the
+    # same runner -- the config BASELINE.json names for 8 GPUs (10 000 001 rows x d = 256 cut over the ranks, 10 000 edges per
+    # GPU and step) -- beside the C2 `value`
+    if dist is not None:
+        ids = torch.tensor([rank, dev.index if dev.index is not None else 0, os.getpid()], dtype=torch.int64, device=dev)
+        got = [torch.empty_like(ids) for _ in range(world)]
+        dist.all_gather(got, ids)
+        seen = sorted({int(g_[0]) for g_ in got})
+        extra["ranks_seen"] = len(seen)
+        extra["devices_seen"] = [int(g_[1]) for g_ in got]
+        extra["distinct_processes"] = len({int(g_[2]) for g_ in got})
+        extra["backend"] = backend
+    if shard == "rows":
+        roof = rows_info.get("roof")
+        if os.environ.get("TPNET_BENCH_C4_LEG", "1") != "0" and (world > 1 or os.environ.get("TPNET_BENCH_C4_LEG") == "1"):
+            try:
+                c4 = CONFIGS["C4"]
+                B4 = int(os.environ.get("TPNET_BENCH_C4_BATCH", c4["B"]))
+                Bg4 = B4 * world
+                cfg4 = dict(c4, B=Bg4)
+                s4, d4, n4, t4, N4 = make_workload(cfg4, W + K, 0)
+                arrs4 = tuple(to_dev(x) for x in (s4, d4, n4, t4))
+                torch.cuda.synchronize()
+                el4, tb4, info4 = sharded_rows(N4, c4["d"], c4["lam"], c4["E"], Bg4, arrs4, t4, K, draw_on_device=True)
+                extra["c4_rows"] = {"value": K * Bg4 / el4, "unit": "edges/s", "steps": K, "warmup": W, "ms_per_step": el4 * 1e3 / K,
+                                    "config": {"workload": f"C4: {c4['desc']}, L=3, S(5000000,5000000,E,span) stream of {(W + K) * Bg4} edges",
+                                               "nodes": N4, "dim": c4["d"], "batch": Bg4, "batch_per_gpu": B4,
+                                               "rows_per_gpu": (N4 + world - 1) // world, "halo_rows": 3 * Bg4,
+                                               "table_bytes_per_gpu": tb4},
+                                    "roofline": info4.get("roof")}
+                del arrs4
+            except Exception as ex:               # noqa: BLE001 -- a secondary leg must not cost the main line
+                extra["c4_rows"] = {"error": f"{type(ex).__name__}: {ex}"[:400]}
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        dist = None
     if rank == 0:
         cpu = dropin = None
         if shard == "single" and not args.no_dropin:
             dropin = dropin_rate(cfg, rp, src, dst, neg, t)
-        if not args.no_cpu_baseline and shard == "single":
-            cpu = cpu_baseline(cfg, src, dst, neg, t, N, P0.numpy())
+        if not args.no_cpu_baseline:
+            if shard == "single":
+                cpu = cpu_baseline(cfg, src, dst, neg, t, N, P0.numpy())
+            else:
+                # rank 0's host cores, after the collectives are done: a bounded sample of the SAME (global-batch) workload
+                torch.manual_seed(0)
+                cpu = cpu_baseline(cfg_run, src, dst, neg, t, N, torch.normal(0, 1 / np.sqrt(d), (N, d)).numpy(), reps=1, quick=True)
         emit(row_info, roof, cpu, dropin, extra)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TPNET_ABI_VERSION 6 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
+#define TPNET_ABI_VERSION 7 /* 2: + tpnet_gather_elems, tpnet_gram_finish, tpnet_gram_unpack, tpnet_decoder_bf16, TPNET_FLAG_PACKED;
                                3: + tpnet_stream_workspace_bytes (windowed schedule of tpnet_run_stream);
                                4: + tpnet_pair_feature (readout + self.mlp in one launch), host-array entry points
                                     (tpnet_stage_*, tpnet_host_pair_feature, tpnet_host_update), tpnet_pair_gram_anchored;
@@ -40,7 +40,9 @@ extern "C" {
                                     exchange's plan on the device (tpnet_xplan_targeted);
                                6: + tpnet_mlp::wimg / tpnet_mlp_prepare_image (the encoder's readout and self.mlp in ONE launch on the matrix
                                     cores), TPNET_FLAG_NO_MFMA_READOUT, tpnet_rows_stream_targeted, tpnet_mlp64_bwd_f32, tpnet_host_anchored_features;
-                                    tpnet_run_stream_tagged replays streams of up to 64 chunks */
+                                    tpnet_run_stream_tagged replays streams of up to 64 chunks;
+                               7: + tpnet_stream_schedule (which schedule tpnet_run_stream would take); tpnet_xplan_targeted serves G = 1;
+                                    the side-by-side plans of a multi-chunk stream are bounded (TPNET_ARENA_MAX_RATIO) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
 typedef enum tpnet_status {
@@ -259,6 +261,17 @@ size_t tpnet_stream_workspace_bytes(int64_t N, int32_t d, int32_t L, int64_t max
  * plan (everything but the log) resident: what tpnet_run_stream_tagged needs to replay such a stream. */
 size_t tpnet_stream_workspace_bytes_capped(int64_t N, int32_t d, int32_t L, int64_t max_edges, int64_t batch,
                                            size_t log_cap_bytes);
+
+/* The room tpnet_stream_workspace_bytes(_capped) adds so that a stream of several chunks can be replayed (every chunk's plan kept
+ * side by side in front of one version log) is bounded: it is granted only while the whole workspace stays within
+ * TPNET_ARENA_MAX_RATIO times the workspace of ONE chunk; beyond that the functions return the one-chunk size (the stream then
+ * runs chunk by chunk and is planned again every time).  A 100 M-edge C2 stream asks for 21 GB, not 108. */
+#define TPNET_ARENA_MAX_RATIO 3
+
+/* Which schedule tpnet_run_stream / tpnet_run_stream_tagged would take for a stream of E edges in batches of `batch` on a table of
+ * N x d x L with these flags and a workspace of ws_bytes: 1 = the windowed pipeline (k_wpipe: one launch per window of batches),
+ * 0 = one launch per batch (k_step).  Host-side arithmetic only; lets a caller warm up the kernels the real call will run. */
+int tpnet_stream_schedule(int64_t N, int32_t d, int32_t L, int64_t E, int64_t batch, uint32_t flags, size_t ws_bytes);
 
 /* update (models/TPNet.py:67-99) for one batch: src, dst device int64[B], t device double[B] (absolute times,
  * chronological; t[B-1] is the new now_time).  now_time = the module's clock before the call; launch_id = a

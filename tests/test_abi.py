@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound(hip_lib):
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/tpnet_hip.h but not exported"
     assert sorted(_lib.SIGNATURES.keys()) == syms
-    assert hip_lib.tpnet_abi_version() == 6
+    assert hip_lib.tpnet_abi_version() == 7
     assert hip_lib.tpnet_strerror(-4) == b"node id out of range"
 
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "tpnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "tpnet_stream_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "tpnet_stream_workspace_bytes_capped": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_size_t]),
+    "tpnet_stream_schedule": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_uint32, C.c_size_t]),
     "tpnet_update": (C.c_int, [_SP, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _P,
                                C.c_size_t, _P]),
     "tpnet_run_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
@@ -146,6 +147,10 @@ DEV_SIGNATURES = {
     "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                     C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
+    "tpnet_time_rows_stream_targeted": (C.c_int, [_SP, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P,
+                                                  C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_uint32, C.c_uint32,
+                                                  C.c_int32, _P, _P, _P, C.c_size_t, _P, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                                  C.POINTER(C.c_float)]),
 }
 
 _lib = None

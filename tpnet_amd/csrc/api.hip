@@ -477,6 +477,9 @@ static size_t windowed_workspace_bytes(int64_t N, int d, int L, int64_t max_edge
     if (c == 0) c = lim / (Ew / K) * (Ew / K);                          // or, under a cap below one window of K batches, whole batches
     if (lim >= max_edges || c < 4 * batch || (max_edges + c - 1) / c > ARENA_MAX_CHUNKS) return one;
     const size_t all = arena_bytes(N, d, L, max_edges, c, batch);
+    // bounded (include/tpnet_hip.h: TPNET_ARENA_MAX_RATIO): the chunks' plans side by side are ~0.9 KB per edge of the WHOLE stream --
+    // without a bound a 100 M-edge C2 stream asked for 108 GB, a 64-chunk one for more than the GPU has
+    if (all > (size_t)TPNET_ARENA_MAX_RATIO * one) return one;
     return all > one ? all : one;
 }
 
@@ -504,6 +507,15 @@ size_t tpnet_stream_workspace_bytes_capped(int64_t N, int32_t d, int32_t L, int6
     const size_t a = plan_bytes(ea < cap_a ? ea : cap_a, batch);
     const size_t b = windowed_workspace_bytes(N, d, L, max_edges, batch, e);
     return a > b ? a : b;
+}
+
+int tpnet_stream_schedule(int64_t N, int32_t d, int32_t L, int64_t E, int64_t batch, uint32_t flags, size_t ws_bytes) {
+    if (N < 1 || d < 1 || L < 1 || L > TPNET_MAX_LAYERS || E < 0 || batch < 1) return TPNET_ERR_BAD_ARG;
+    if (E == 0) return 0;
+    tpnet_state st{};
+    st.N = N; st.d = d; st.L = L;
+    int K = 0;
+    return window_chunk(st, ws_bytes, E, batch, flags, &K) > 0 ? 1 : 0;
 }
 
 int tpnet_update(const tpnet_state* st, const int64_t* src, const int64_t* dst, const double* t, int64_t B,

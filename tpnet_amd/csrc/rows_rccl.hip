@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 #include <cstring>
+#include <vector>
 
 namespace tpnet {
 
@@ -122,6 +123,46 @@ int tpnet_pack_split(const tpnet_state* st, const int64_t* ids, int64_t n, doubl
     return launch_pack_split(*st, ids, n, now_time, lambda, out_p0, out_q, halo0, n_halo, (hipStream_t)stream);
 }
 
+// the exchange of one batch (pack -> grouped ncclSend / ncclRecv into the halo rows); nothing to do without peers
+static int rows_exchange_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, float* send_p0, float* send_q,
+                                  const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G, int32_t me, double now_time,
+                                  double lambda, int32_t n_owned, hipStream_t s) {
+    if (!(comm && G > 1)) return TPNET_OK;
+    if (!g_rccl.handle || !send_cnt || !recv_cnt) return TPNET_ERR_BAD_ARG;
+    int64_t ns = 0, nr = 0;
+    for (int r = 0; r < G; ++r) {
+        if (send_cnt[r] < 0 || recv_cnt[r] < 0 || (r == me && (send_cnt[r] || recv_cnt[r]))) return TPNET_ERR_BAD_ARG;
+        ns += send_cnt[r];
+        nr += recv_cnt[r];
+    }
+    if (n_owned + nr > st->N) return TPNET_ERR_WORKSPACE;            // more rows to receive than the shard has halo rows
+    if (ns > 0 && (!pack_ids || !send_p0 || !send_q)) return TPNET_ERR_BAD_ARG;
+    int rc = launch_pack_split(*st, pack_ids, ns, now_time, lambda, send_p0, send_q, n_owned, nr, s);
+    if (rc) return rc;
+    // every row travels only to the ranks that read it, and lands where the step kernel reads it: the halo rows of p0 and
+    // of copy 0 of q (halo rows are never targets, so their current copy stays 0)
+    const size_t d = (size_t)st->d, Ld = (size_t)st->L * d;
+    float* halo_p0 = st->p0 + (size_t)n_owned * d;
+    float* halo_q = st->q + (size_t)n_owned * Ld;
+    int bad = 0;
+    bad |= g_rccl.group_start();
+    size_t so = 0, ro = 0;
+    for (int r = 0; r < G; ++r) {
+        if (send_cnt[r]) {
+            bad |= g_rccl.send(send_p0 + so * d, (size_t)send_cnt[r] * d, kNcclFloat32, r, comm, s);
+            bad |= g_rccl.send(send_q + so * Ld, (size_t)send_cnt[r] * Ld, kNcclFloat32, r, comm, s);
+            so += (size_t)send_cnt[r];
+        }
+        if (recv_cnt[r]) {
+            bad |= g_rccl.recv(halo_p0 + ro * d, (size_t)recv_cnt[r] * d, kNcclFloat32, r, comm, s);
+            bad |= g_rccl.recv(halo_q + ro * Ld, (size_t)recv_cnt[r] * Ld, kNcclFloat32, r, comm, s);
+            ro += (size_t)recv_cnt[r];
+        }
+    }
+    bad |= g_rccl.group_end();
+    return bad ? TPNET_ERR_HIP : TPNET_OK;
+}
+
 int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, float* send_p0, float* send_q,
                              const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G, int32_t me, double now_time,
                              const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
@@ -130,44 +171,42 @@ int tpnet_rows_step_targeted(const tpnet_state* st, void* comm, const int64_t* p
     if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
         return TPNET_ERR_BAD_ARG;
     if (G < 1 || me < 0 || me >= G || n_owned < 0 || n_owned > st->N) return TPNET_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    if (comm && G > 1) {
-        if (!g_rccl.handle || !send_cnt || !recv_cnt) return TPNET_ERR_BAD_ARG;
-        int64_t ns = 0, nr = 0;
-        for (int r = 0; r < G; ++r) {
-            if (send_cnt[r] < 0 || recv_cnt[r] < 0 || (r == me && (send_cnt[r] || recv_cnt[r]))) return TPNET_ERR_BAD_ARG;
-            ns += send_cnt[r];
-            nr += recv_cnt[r];
-        }
-        if (n_owned + nr > st->N) return TPNET_ERR_WORKSPACE;            // more rows to receive than the shard has halo rows
-        if (ns > 0 && (!pack_ids || !send_p0 || !send_q)) return TPNET_ERR_BAD_ARG;
-        int rc = launch_pack_split(*st, pack_ids, ns, now_time, lambda, send_p0, send_q, n_owned, nr, s);
-        if (rc) return rc;
-        // every row travels only to the ranks that read it, and lands where the step kernel reads it: the halo rows of p0 and
-        // of copy 0 of q (halo rows are never targets, so their current copy stays 0)
-        const size_t d = (size_t)st->d, Ld = (size_t)st->L * d;
-        float* halo_p0 = st->p0 + (size_t)n_owned * d;
-        float* halo_q = st->q + (size_t)n_owned * Ld;
-        int bad = 0;
-        bad |= g_rccl.group_start();
-        size_t so = 0, ro = 0;
-        for (int r = 0; r < G; ++r) {
-            if (send_cnt[r]) {
-                bad |= g_rccl.send(send_p0 + so * d, (size_t)send_cnt[r] * d, kNcclFloat32, r, comm, s);
-                bad |= g_rccl.send(send_q + so * Ld, (size_t)send_cnt[r] * Ld, kNcclFloat32, r, comm, s);
-                so += (size_t)send_cnt[r];
-            }
-            if (recv_cnt[r]) {
-                bad |= g_rccl.recv(halo_p0 + ro * d, (size_t)recv_cnt[r] * d, kNcclFloat32, r, comm, s);
-                bad |= g_rccl.recv(halo_q + ro * Ld, (size_t)recv_cnt[r] * Ld, kNcclFloat32, r, comm, s);
-                ro += (size_t)recv_cnt[r];
-            }
-        }
-        bad |= g_rccl.group_end();
-        if (bad) return TPNET_ERR_HIP;
-    }
+    const int rc = rows_exchange_targeted(st, comm, pack_ids, send_p0, send_q, send_cnt, recv_cnt, G, me, now_time, lambda, n_owned,
+                                          (hipStream_t)stream);
+    if (rc) return rc;
     return tpnet_step_batch(st, src, dst, neg, t, E, batch, b, lambda, launch_id, flags, 0, n_owned, out_pos, out_neg,
                             workspace, ws_bytes, stream);
+}
+
+// batches [b0, b1) of a prepared stream; ev (optional): 3 events per batch -- before the exchange, before the step, behind it
+static int rows_stream_loop(const tpnet_state* st, void* comm, const int64_t* pack_ids, const int64_t* pack_start, float* send_p0,
+                            float* send_q, const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G, int32_t me, double now_time,
+                            const double* t_last, const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t,
+                            int64_t E, int64_t batch, int64_t b0, int64_t b1, double lambda, uint32_t launch_id_base, uint32_t flags,
+                            int32_t n_owned, float* out_pos, float* out_neg, void* workspace, size_t ws_bytes, void* stream,
+                            hipEvent_t* ev) {
+    const int64_t nb = batch > 0 ? (E + batch - 1) / batch : 0;
+    if (batch < 1 || b0 < 0 || b1 > nb || b0 > b1 || !t_last || !send_cnt || !recv_cnt || !pack_start || G < 1) return TPNET_ERR_BAD_ARG;
+    if (launch_id_base == 0 || (uint64_t)launch_id_base + (uint64_t)nb >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
+    if (!st || !st->p0 || !st->q || !st->meta || !st->err || st->N < 1 || st->d < 1 || st->L < 1 || st->L > TPNET_MAX_LAYERS)
+        return TPNET_ERR_BAD_ARG;
+    if (me < 0 || me >= G || n_owned < 0 || n_owned > st->N) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int64_t b = b0; b < b1; ++b) {
+        // the clock a batch's rows are packed at is the one the previous batch left (models/TPNet.py:99)
+        const double now = b == 0 ? now_time : t_last[b - 1];
+        if (ev) (void)hipEventRecord(ev[3 * (b - b0)], s);
+        int rc = rows_exchange_targeted(st, comm, pack_ids ? pack_ids + pack_start[b] : nullptr, send_p0, send_q,
+                                        send_cnt + (size_t)G * (size_t)b, recv_cnt + (size_t)G * (size_t)b, G, me, now, lambda,
+                                        n_owned, s);
+        if (rc) return rc;
+        if (ev) (void)hipEventRecord(ev[3 * (b - b0) + 1], s);
+        rc = tpnet_step_batch(st, src, dst, neg, t, E, batch, b, lambda, launch_id_base + (uint32_t)b, flags, 0, n_owned, out_pos,
+                              out_neg, workspace, ws_bytes, stream);
+        if (rc) return rc;
+        if (ev) (void)hipEventRecord(ev[3 * (b - b0) + 2], s);
+    }
+    return TPNET_OK;
 }
 
 int tpnet_rows_stream_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, const int64_t* pack_start,
@@ -176,19 +215,43 @@ int tpnet_rows_stream_targeted(const tpnet_state* st, void* comm, const int64_t*
                                const int64_t* neg, const double* t, int64_t E, int64_t batch, int64_t b0, int64_t b1,
                                double lambda, uint32_t launch_id_base, uint32_t flags, int32_t n_owned, float* out_pos,
                                float* out_neg, void* workspace, size_t ws_bytes, void* stream) {
-    const int64_t nb = batch > 0 ? (E + batch - 1) / batch : 0;
-    if (batch < 1 || b0 < 0 || b1 > nb || b0 > b1 || !t_last || !send_cnt || !recv_cnt || !pack_start || G < 1) return TPNET_ERR_BAD_ARG;
-    if (launch_id_base == 0 || (uint64_t)launch_id_base + (uint64_t)nb >= 0x7FFFFFFFull) return TPNET_ERR_BAD_ARG;
-    for (int64_t b = b0; b < b1; ++b) {
-        // the clock a batch's rows are packed at is the one the previous batch left (models/TPNet.py:99)
-        const double now = b == 0 ? now_time : t_last[b - 1];
-        const int rc = tpnet_rows_step_targeted(st, comm, pack_ids ? pack_ids + pack_start[b] : nullptr, send_p0, send_q,
-                                                send_cnt + (size_t)G * (size_t)b, recv_cnt + (size_t)G * (size_t)b, G, me, now, src, dst,
-                                                neg, t, E, batch, b, lambda, launch_id_base + (uint32_t)b, flags, n_owned, out_pos,
-                                                out_neg, workspace, ws_bytes, stream);
-        if (rc) return rc;
+    return rows_stream_loop(st, comm, pack_ids, pack_start, send_p0, send_q, send_cnt, recv_cnt, G, me, now_time, t_last, src, dst, neg,
+                            t, E, batch, b0, b1, lambda, launch_id_base, flags, n_owned, out_pos, out_neg, workspace, ws_bytes, stream,
+                            nullptr);
+}
+
+// measurement aid (tpnet_dev.h): the same loop with HIP events on `stream` around every batch's exchange and step
+int tpnet_time_rows_stream_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, const int64_t* pack_start,
+                                    float* send_p0, float* send_q, const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G,
+                                    int32_t me, double now_time, const double* t_last, const int64_t* src, const int64_t* dst,
+                                    const int64_t* neg, const double* t, int64_t E, int64_t batch, int64_t b0, int64_t b1,
+                                    double lambda, uint32_t launch_id_base, uint32_t flags, int32_t n_owned, float* out_pos,
+                                    float* out_neg, void* workspace, size_t ws_bytes, void* stream, float* total_ms_out,
+                                    float* step_ms_out, float* exchange_ms_out) {
+    if (b1 <= b0 || b1 - b0 > 4096) return TPNET_ERR_BAD_ARG;
+    const size_t n = (size_t)(b1 - b0);
+    std::vector<hipEvent_t> ev(3 * n);
+    for (auto& e : ev) TPNET_HIP_TRY(hipEventCreate(&e));
+    int rc = rows_stream_loop(st, comm, pack_ids, pack_start, send_p0, send_q, send_cnt, recv_cnt, G, me, now_time, t_last, src, dst,
+                              neg, t, E, batch, b0, b1, lambda, launch_id_base, flags, n_owned, out_pos, out_neg, workspace, ws_bytes,
+                              stream, ev.data());
+    if (rc == TPNET_OK) {
+        TPNET_HIP_TRY(hipEventSynchronize(ev[3 * n - 1]));
+        double step = 0.0, xch = 0.0;
+        float ms = 0.f;
+        for (size_t i = 0; i < n; ++i) {
+            TPNET_HIP_TRY(hipEventElapsedTime(&ms, ev[3 * i], ev[3 * i + 1]));
+            xch += ms;
+            TPNET_HIP_TRY(hipEventElapsedTime(&ms, ev[3 * i + 1], ev[3 * i + 2]));
+            step += ms;
+        }
+        TPNET_HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3 * n - 1]));
+        if (total_ms_out) *total_ms_out = ms;
+        if (step_ms_out) *step_ms_out = (float)(step / (double)n);
+        if (exchange_ms_out) *exchange_ms_out = (float)(xch / (double)n);
     }
-    return TPNET_OK;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 }  // extern "C"

@@ -20,6 +20,18 @@ int tpnet_time_stream(const tpnet_state* st, const int64_t* src, const int64_t* 
                       void* workspace, size_t ws_bytes, int reps, float* total_ms_out, float* kernel_ms_out,
                       int64_t* launches_out, int64_t* edges_out, void* stream);
 
+/* tpnet_rows_stream_targeted (same arguments) with three HIP events per batch on `stream` -- before the batch's exchange (pack +
+ * grouped send / recv), before its step kernel, behind it -- and one synchronise at the end: total_ms_out = first event to last,
+ * step_ms_out / exchange_ms_out = the average per batch of the step launch / of pack + exchange.  bench.py's `roofline` at N > 1
+ * (every rank calls it: the exchange is collective).  At most 4096 batches. */
+int tpnet_time_rows_stream_targeted(const tpnet_state* st, void* comm, const int64_t* pack_ids, const int64_t* pack_start,
+                                    float* send_p0, float* send_q, const int64_t* send_cnt, const int64_t* recv_cnt, int32_t G,
+                                    int32_t me, double now_time, const double* t_last, const int64_t* src, const int64_t* dst,
+                                    const int64_t* neg, const double* t, int64_t E, int64_t batch, int64_t b0, int64_t b1,
+                                    double lambda, uint32_t launch_id_base, uint32_t flags, int32_t n_owned, float* out_pos,
+                                    float* out_neg, void* workspace, size_t ws_bytes, void* stream, float* total_ms_out,
+                                    float* step_ms_out, float* exchange_ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,7 +163,7 @@ int64_t tpnet_xplan_capacity(void) { return XNC; }
 int tpnet_xplan_targeted(const int64_t* src, const int64_t* dst, const int64_t* neg, int64_t E, int64_t batch, int64_t N, int32_t G,
                          int32_t me, int32_t n_owned, uint32_t* recv_keys, int64_t* pack_ids, int64_t* cnt, uint32_t* status,
                          int64_t* local_src, int64_t* local_dst, int64_t* local_neg, void* stream) {
-    if (!src || !dst || E < 0 || batch < 1 || N < 1 || G < 2 || G > 64 || me < 0 || me >= G || n_owned < 0) return TPNET_ERR_BAD_ARG;
+    if (!src || !dst || E < 0 || batch < 1 || N < 1 || G < 1 || G > 64 || me < 0 || me >= G || n_owned < 0) return TPNET_ERR_BAD_ARG;
     if (!recv_keys || !pack_ids || !cnt || !status || !local_src || !local_dst || (neg && !local_neg)) return TPNET_ERR_BAD_ARG;
     if (E == 0) return TPNET_OK;
     int nbits = 1, gbits = 1;

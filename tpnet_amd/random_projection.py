@@ -331,7 +331,26 @@ class RandomProjectionModule(nn.Module):
                 cache.clear()
             cache[(max_edges, batch, stream, tail, cap)] = need
         if eng["ws"] is None or eng["ws"].numel() < need:
-            eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
+            try:
+                eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
+            except torch.OutOfMemoryError:
+                if not stream:
+                    raise
+                # a GPU short of memory: halve the version log's cap (shorter chunks, more pipeline fills and drains, and beyond
+                # TPNET_ARENA_MAX_RATIO no replay) until the workspace fits -- the C side takes whatever chunk it is given
+                eng["ws"] = None
+                lib, row = _lib.load(), 2 * self.num_layer * self.dim * 4
+                cap_try = (cap or (16 << 30)) // 2
+                while True:
+                    need = (lib.tpnet_stream_workspace_bytes_capped(self.node_num, self.dim, self.num_layer, max_edges, batch,
+                                                                    cap_try) + 255) // 256 * 256 + tail
+                    try:
+                        eng["ws"] = torch.empty(need, dtype=torch.uint8, device=eng["dev"])
+                        break
+                    except torch.OutOfMemoryError:
+                        if cap_try < 8 * batch * row:
+                            raise
+                        cap_try //= 2
             self._drop_plan()
         if not keep_plan:
             self._drop_plan()              # (whoever asks for the workspace may write it: only run_stream keeps its plan)
@@ -352,6 +371,7 @@ class RandomProjectionModule(nn.Module):
         tag = self.__dict__.get("_plan_tag")
         if tag is not None:
             C.memset(C.byref(tag), 0, C.sizeof(tag))
+        self.__dict__["_rows_plan_sig"] = None          # (the row-sharded runner's per-batch plan of a stream: tpnet_amd/sharded.py)
 
     def _layer_ptrs(self):
         arr = (C.c_void_p * self.num_layer)()

@@ -279,12 +279,14 @@ class ShardedStreamRunner:
                     pack_ids=(nodes // G).contiguous(), src=local(src), dst=local(dst),
                     neg=local(neg) if neg is not None else None)
 
-    def run_stream(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
+    def run_stream(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True, timing=None,
+                   out_pos=None, out_neg=None):
         """Same contract as RandomProjectionModule.run_stream (global node ids in, per-edge features out), over all ranks.
         Returns (feat_pos, feat_neg): complete on every rank if merge_outputs (one all-reduce of disjoint rows at the end),
-        otherwise each rank holds the rows of the pairs whose src node it owns and zeros elsewhere."""
+        otherwise each rank holds the rows of the pairs whose src node it owns and zeros elsewhere (a caller's own out_pos /
+        out_neg, targeted exchange only: the other rows keep what they held)."""
         if self.exchange == "targeted":
-            return self.run_stream_targeted(src, dst, neg, t, batch_size, t_host_last, merge_outputs)
+            return self.run_stream_targeted(src, dst, neg, t, batch_size, t_host_last, merge_outputs, timing, out_pos, out_neg)
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
@@ -414,13 +416,33 @@ class ShardedStreamRunner:
 
     device_plan = True         # the targeted exchange's plan by tpnet_xplan_targeted (two launches, one read-back) where it applies
 
+    @staticmethod
+    def _stream_sig(src, dst, neg, t, E, B):
+        """Identifies the CONTENTS of a call's stream tensors the way RandomProjectionModule.run_stream does (storage + torch's
+        in-place version counters): an equal value = the same arrays, unchanged -- what lets a runner keep a stream's exchange plan
+        and its kernels' plan across calls (every epoch of train_link_prediction.py:234-253 runs the same stream again)."""
+        parts = [E, B]
+        for x in (src, dst, neg, t):
+            parts += [None, 0] if x is None else [x.data_ptr(), x._version]
+        return tuple(parts)
+
+    def _pinned(self, n_int64: int):
+        """A pinned host buffer (+ the event of its last copy) for the one read-back of a cold exchange plan: `tensor.cpu()` was a
+        pageable allocation + a blocking copy per call."""
+        pin = self.__dict__.get("_pin")
+        if pin is None or pin[0].numel() < n_int64:
+            pin = (torch.empty(max(n_int64, 1024), dtype=torch.int64).pin_memory(), torch.cuda.Event())
+            self.__dict__["_pin"] = pin
+        return pin
+
     def relabel_targeted_device(self, src, dst, neg, batch_size: int):
         """relabel_targeted on the device (csrc/xplan.hip: one workgroup per batch sorts the batch's receive and send lists, one
         thread per endpoint relabels) -- None where it does not apply (ids not on a GPU, 32-bit keys too narrow for N and G, a
-        batch whose lists exceed the kernel's capacity): the caller then takes the torch plan.  Same lists, same order."""
+        batch whose lists exceed the kernel's capacity): the caller then takes the torch plan.  Same lists, same order.  One rank
+        (G = 1) is served too: no lists, every id its own local row -- the path a forced single-rank run measures."""
         G, me, N, n_cap = self.G, self.me, self.N, self.n_cap
         E, B = int(src.numel()), int(batch_size)
-        if G < 2 or G > 64 or not src.is_cuda or E == 0:
+        if G < 1 or G > 64 or not src.is_cuda or E == 0:
             return None
         if max(N - 1, 1).bit_length() + max(G - 1, 1).bit_length() > 31:
             return None
@@ -431,36 +453,61 @@ class ShardedStreamRunner:
         nb = (E + B - 1) // B
         dev = src.device
         cap = int(lib.tpnet_xplan_capacity())
-        recv_keys = torch.empty((nb, cap), dtype=torch.int32, device=dev)
-        pack_ids = torch.empty((nb, cap), dtype=torch.int64, device=dev)
-        tail = torch.empty(nb * 2 * G + 1, dtype=torch.int64, device=dev)       # counts, then the two status words
+        # scratch of one plan, kept across calls (a stream of the same shape reuses it; torch.empty per call was five allocations)
+        key = (nb, cap, G, E, neg is not None, dev)
+        sc = self.__dict__.get("_xplan_scratch")
+        if sc is None or sc[0] != key:
+            sc = (key, torch.empty((nb, cap), dtype=torch.int32, device=dev), torch.empty((nb, cap), dtype=torch.int64, device=dev),
+                  torch.empty(nb * 2 * G + 1, dtype=torch.int64, device=dev), torch.empty(E, dtype=torch.int64, device=dev),
+                  torch.empty(E, dtype=torch.int64, device=dev), torch.empty(E, dtype=torch.int64, device=dev) if neg is not None else None)
+            self.__dict__["_xplan_scratch"] = sc
+        _, recv_keys, pack_ids, tail, lsrc, ldst, lneg = sc
         cnt, status = tail[: nb * 2 * G], tail[nb * 2 * G:]
-        lsrc, ldst = torch.empty_like(src), torch.empty_like(dst)
-        lneg = torch.empty_like(neg) if neg is not None else None
         rc = lib.tpnet_xplan_targeted(src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, E, B, N, G, me,
                                       n_cap, recv_keys.data_ptr(), pack_ids.data_ptr(), cnt.data_ptr(), status.data_ptr(),
                                       lsrc.data_ptr(), ldst.data_ptr(), lneg.data_ptr() if lneg is not None else None,
                                       self.rp._stream())
         if rc:
             return None
-        host = tail.cpu().numpy()                                                # ONE read-back: message sizes + status
+        # ONE read-back (message sizes + status) through a pinned buffer: an asynchronous copy + an event, no pageable staging
+        n_tail = nb * 2 * G + 1
+        pin, ev = self._pinned(n_tail)
+        pin[:n_tail].copy_(tail, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        ev.synchronize()
+        host = pin[:n_tail].numpy()
         st = host[nb * 2 * G:].view(np.uint32)
         if int(st[0]):
             raise IndexError(f"node id out of range for {N} nodes")
         if int(st[1]):
             return None
         c = host[: nb * 2 * G].reshape(nb, 2, G)
-        recv_cnt, send_cnt = np.ascontiguousarray(c[:, 0, :]), np.ascontiguousarray(c[:, 1, :])
+        recv_cnt, send_cnt = np.ascontiguousarray(c[:, 0, :]), np.ascontiguousarray(c[:, 1, :])      # (copies: the pinned buffer is reused)
         rtot = recv_cnt.sum(axis=1)
         if nb and int(rtot.max()) > self.H:
             raise ValueError(f"a batch reads {int(rtot.max())} rows of other ranks but the shard has {self.H} halo rows")
         return dict(src=lsrc, dst=ldst, neg=lneg, send_cnt=send_cnt, recv_cnt=recv_cnt, rtot=rtot, pack_ids=pack_ids.view(-1),
                     sstart=np.arange(nb, dtype=np.int64) * cap, recv_keys_dev=recv_keys)
 
-    def prepare_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, comm="auto"):
+    # a stream that is run again (same tensors, unchanged: _stream_sig) keeps its exchange plan, its relabelled ids and -- while
+    # nothing else used the module's workspace and the clock it starts from is the same -- the plan of its kernels
+    reuse_plans = True
+
+    def _send_buffers(self, d, L, smax, dev):
+        """The pack launch's two send buffers, kept across calls (torch.zeros of both per call sat inside every timed region)."""
+        b = self.__dict__.get("_send_bufs")
+        if b is None or b[0].shape[0] < smax or b[0].device != dev:
+            b = (torch.zeros((smax, d), dtype=torch.float32, device=dev), torch.zeros((smax, L * d), dtype=torch.float32, device=dev))
+            self.__dict__["_send_bufs"] = b
+        return b
+
+    def prepare_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, comm="auto", out_pos=None, out_neg=None,
+                         zero_outputs: bool = True):
         """Everything a stream's per-batch calls need (exchange plan, relabelled ids, per-batch plan of the local kernels, send
         buffers, outputs).  comm: "auto" = the C-side RCCL communicator of this shard's process group (None if it is not on
-        RCCL); or a communicator handle the caller made (tests/loopback)."""
+        RCCL); or a communicator handle the caller made (tests/loopback).  out_pos / out_neg: the caller's [E, (2L+2)^2] buffers
+        (default: fresh zeroed ones); zero_outputs=False leaves a caller's buffers as they are -- the rows of pairs whose src
+        another rank owns then keep what they held (enough where the outputs stay sharded; a merge sums disjoint rows over zeros)."""
         rp, G, me = self.rp, self.G, self.me
         rp._ensure_engine()
         lib = _lib.load()
@@ -470,65 +517,122 @@ class ShardedStreamRunner:
         L, d = rp.num_layer, rp.dim
         NG = rp.pair_wise_feature_dim
         lam = float(rp.time_decay_weight)
-        out_pos = torch.zeros((E, NG), dtype=torch.float32, device=dev)
-        out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev) if neg is not None else None
-        ctx = dict(E=E, B=B, nb=nb, out_pos=out_pos, out_neg=out_neg, now=rp._now_host)
         if E == 0:
-            return ctx
-        R = self.relabel_targeted_device(src, dst, neg, B) if self.device_plan else None   # (checks the ids' range itself)
+            z = torch.zeros((0, NG), dtype=torch.float32, device=dev)
+            return dict(E=0, B=B, nb=0, out_pos=z, out_neg=z.clone() if neg is not None else None, now=rp._now_host)
+        sig = self._stream_sig(src, dst, neg, t, E, B) if self.reuse_plans else None
+        xc = self.__dict__.get("_xplan_cache")
+        R = xc[1] if (sig is not None and xc is not None and xc[0] == sig) else None
         if R is None:
-            ends = [src, dst] + ([neg] if neg is not None else [])  # (the lists key on batch * N + node: a bad id would alias)
-            if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
-                raise IndexError(f"node id out of range for {self.N} nodes")
-            R = self.relabel_targeted(src, dst, neg, B)
-        last_idx = torch.clamp(torch.arange(1, nb + 1, device=dev) * B, max=E) - 1
-        t_last = t[last_idx].cpu().numpy() if t_host_last is None else np.asarray(t_host_last, dtype=np.float64)
-        ws = rp._workspace(E, B)
-        st = rp._state()
-        stream = rp._stream()
+            R = self.relabel_targeted_device(src, dst, neg, B) if self.device_plan else None   # (checks the ids' range itself)
+            if R is None:
+                ends = [src, dst] + ([neg] if neg is not None else [])  # (the lists key on batch * N + node: a bad id would alias)
+                if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
+                    raise IndexError(f"node id out of range for {self.N} nodes")
+                R = self.relabel_targeted(src, dst, neg, B)
+            elif sig is not None:
+                # (the device plan's lists live in scratch the NEXT cold plan overwrites: a kept plan owns copies of what the
+                # per-batch calls read -- made once, when a stream is first seen)
+                R = dict(R, src=R["src"].clone(), dst=R["dst"].clone(), neg=R["neg"].clone() if R["neg"] is not None else None,
+                         pack_ids=R["pack_ids"].clone() if G > 1 else R["pack_ids"])
+            R["scnt"] = np.ascontiguousarray(R["send_cnt"], dtype=np.int64)
+            R["rcnt"] = np.ascontiguousarray(R["recv_cnt"], dtype=np.int64)
+            R["stot"] = R["scnt"].sum(axis=1)
+            R["sstart_"] = np.ascontiguousarray(R["sstart"] if "sstart" in R else
+                                                np.concatenate([[0], np.cumsum(R["stot"])[:-1]]), dtype=np.int64)
+            R["smax"] = max(int(R["stot"].max()), 1)
+            if sig is not None:
+                self.__dict__["_xplan_cache"] = (sig, R)
+            # a plan the module's workspace still holds was built on OTHER relabelled arrays (a freed tensor's address can come back
+            # with the same version counter: nothing may be replayed across a cold exchange plan)
+            rp._drop_plan()
+        if t_host_last is None:
+            last_idx = torch.clamp(torch.arange(1, nb + 1, device=dev) * B, max=E) - 1
+            t_last = t[last_idx].cpu().numpy()
+        else:
+            t_last = np.asarray(t_host_last, dtype=np.float64)
+        for name, o in (("out_pos", out_pos), ("out_neg", out_neg)):
+            if o is not None and (o.dtype != torch.float32 or o.device != dev or not o.is_contiguous() or tuple(o.shape) != (E, NG)):
+                raise ValueError(f"{name} must be a contiguous float32 tensor of shape ({E}, {NG}) on {dev}")
+        if out_pos is None:
+            out_pos = torch.zeros((E, NG), dtype=torch.float32, device=dev)
+        elif zero_outputs:
+            out_pos.zero_()
+        if neg is None:
+            out_neg = None
+        elif out_neg is None:
+            out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev)
+        elif zero_outputs:
+            out_neg.zero_()
+        send_p0, send_q = self._send_buffers(d, L, R["smax"], dev)
+        ctx = dict(E=E, B=B, nb=nb, out_pos=out_pos, out_neg=out_neg, now=rp._now_host)
         flags = _lib.FLAG_NOT_SCALE if rp.not_scale else 0
         ls, ld, ln = R["src"], R["dst"], R["neg"]
-        _lib.check(lib.tpnet_plan_stream(C.byref(st), ls.data_ptr(), ld.data_ptr(), t.data_ptr(), E, B, rp._now_host,
-                                         lam, flags, ws.data_ptr(), ws.numel(), stream), "plan_stream")
-        scnt, rcnt = np.ascontiguousarray(R["send_cnt"], dtype=np.int64), np.ascontiguousarray(R["recv_cnt"], dtype=np.int64)
-        stot = scnt.sum(axis=1)
-        sstart = R["sstart"] if "sstart" in R else np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
-        # the rows a peer reads leave as two messages (layer 0; layers 1..L) and arrive STRAIGHT in the reader's halo rows of p0 and
-        # of copy 0 of q: pack -> grouped send / recv -> step, no unpack launch (halo rows are never targets: their copy stays 0)
-        smax = max(int(stot.max()), 1)
         if comm == "auto":
             nccl = G > 1 and not self.detached and dist.get_backend(self.group) == "nccl"
             comm = self._c_comm() if nccl else None
         else:
             nccl = comm is not None
-        ctx.update(R=R, t_last=np.ascontiguousarray(t_last, dtype=np.float64), ws=ws, st=st, stream=stream, flags=flags, lam=lam,
-                   ls=ls, ld=ld, ln=ln, t=t, scnt=scnt, rcnt=rcnt, stot=stot, rtot=R["rtot"],
-                   sstart=np.ascontiguousarray(sstart, dtype=np.int64), lid0=rp._next_launch_ids(nb),
-                   send_p0=torch.zeros((smax, d), dtype=torch.float32, device=dev),
-                   send_q=torch.zeros((smax, L * d), dtype=torch.float32, device=dev), comm=comm, nccl=nccl)
+        ctx.update(R=R, t_last=np.ascontiguousarray(t_last, dtype=np.float64), flags=flags, lam=lam, ls=ls, ld=ld, ln=ln, t=t,
+                   scnt=R["scnt"], rcnt=R["rcnt"], stot=R["stot"], rtot=R["rtot"], sstart=R["sstart_"], send_p0=send_p0, send_q=send_q,
+                   comm=comm, nccl=nccl, windowed=False)
+        if G == 1 and self.single_rank_pipeline and not rp.exact:
+            # ONE rank: no halo, no exchange -- the stream takes the module's own schedules (the windowed pipeline from 16 batches on)
+            # on the relabelled ids: RandomProjectionModule.run_stream in steps_targeted
+            ctx["windowed"] = True
+            return ctx
+        ws = rp._workspace(E, B, keep_plan=True)
+        st = rp._state()
+        stream = rp._stream()
+        psig = (sig, rp._now_host, lam, flags, ws.data_ptr(), ws.numel()) if sig is not None else None
+        if psig is None or rp.__dict__.get("_rows_plan_sig") != psig:
+            rp._drop_plan()
+            _lib.check(lib.tpnet_plan_stream(C.byref(st), ls.data_ptr(), ld.data_ptr(), t.data_ptr(), E, B, rp._now_host,
+                                             lam, flags, ws.data_ptr(), ws.numel(), stream), "plan_stream")
+            rp.__dict__["_rows_plan_sig"] = psig
+        ctx.update(ws=ws, st=st, stream=stream, lid0=rp._next_launch_ids(nb))
         return ctx
 
-    def steps_targeted(self, ctx, b0: int, b1: int):
+    single_rank_pipeline = True     # G = 1: the stream runs on the module's own schedules (no halo rows, no exchange)
+    schedule = None                 # ... this one (RandomProjectionModule.run_stream's `schedule`; None: the module's default, "auto")
+
+    def steps_targeted(self, ctx, b0: int, b1: int, timing=None):
         """Batches [b0, b1) of a prepared stream in ONE FFI call: per batch pack + grouped ncclSend / ncclRecv (comm; none with one
-        rank) + step, all enqueued on the current stream (tpnet_rows_stream_targeted)."""
+        rank) + step, all enqueued on the current stream (tpnet_rows_stream_targeted).  `timing` (a dict, measurement only): the
+        same loop with HIP events around every batch's exchange and step (tpnet_time_rows_stream_targeted; synchronises) -- filled
+        with total_ms, step_ms, exchange_ms."""
         if ctx["E"] == 0 or b0 >= b1:
+            return
+        if ctx.get("windowed"):
+            if (b0, b1) != (0, ctx["nb"]):
+                raise ValueError("a single-rank stream on the module's own schedule runs whole: steps_targeted(ctx, 0, nb)")
+            rp = self.rp
+            rp.run_stream(ctx["ls"], ctx["ld"], ctx["ln"], ctx["t"], ctx["B"], out_pos=ctx["out_pos"], out_neg=ctx["out_neg"],
+                          want_neg=ctx["ln"] is not None, t_end=float(ctx["t_last"][-1]), schedule=self.schedule,
+                          replay=None if self.reuse_plans else False)
             return
         lib = _lib.load()
         ln, on = ctx["ln"], ctx["out_neg"]
-        rc = lib.tpnet_rows_stream_targeted(C.byref(ctx["st"]), ctx["comm"], ctx["R"]["pack_ids"].data_ptr(), ctx["sstart"].ctypes.data,
-                                            ctx["send_p0"].data_ptr(), ctx["send_q"].data_ptr(), ctx["scnt"].ctypes.data,
-                                            ctx["rcnt"].ctypes.data, self.G, self.me, ctx["now"], ctx["t_last"].ctypes.data,
-                                            ctx["ls"].data_ptr(), ctx["ld"].data_ptr(), ln.data_ptr() if ln is not None else None,
-                                            ctx["t"].data_ptr(), ctx["E"], ctx["B"], int(b0), int(b1), ctx["lam"], ctx["lid0"],
-                                            ctx["flags"], self.n_cap, ctx["out_pos"].data_ptr(),
-                                            on.data_ptr() if on is not None else None, ctx["ws"].data_ptr(), ctx["ws"].numel(),
-                                            self.rp._stream())
+        args = (C.byref(ctx["st"]), ctx["comm"], ctx["R"]["pack_ids"].data_ptr(), ctx["sstart"].ctypes.data,
+                ctx["send_p0"].data_ptr(), ctx["send_q"].data_ptr(), ctx["scnt"].ctypes.data,
+                ctx["rcnt"].ctypes.data, self.G, self.me, ctx["now"], ctx["t_last"].ctypes.data,
+                ctx["ls"].data_ptr(), ctx["ld"].data_ptr(), ln.data_ptr() if ln is not None else None,
+                ctx["t"].data_ptr(), ctx["E"], ctx["B"], int(b0), int(b1), ctx["lam"], ctx["lid0"],
+                ctx["flags"], self.n_cap, ctx["out_pos"].data_ptr(),
+                on.data_ptr() if on is not None else None, ctx["ws"].data_ptr(), ctx["ws"].numel(),
+                self.rp._stream())
+        if timing is not None:
+            tot, stp, xch = C.c_float(0), C.c_float(0), C.c_float(0)
+            rc = lib.tpnet_time_rows_stream_targeted(*args, C.byref(tot), C.byref(stp), C.byref(xch))
+            timing.update(total_ms=tot.value, step_ms=stp.value, exchange_ms=xch.value, batches=int(b1 - b0))
+        else:
+            rc = lib.tpnet_rows_stream_targeted(*args)
         if rc:
             _lib.check(rc, "rows_stream_targeted")
 
     def finish_targeted(self, ctx, merge_outputs: bool = True):
         rp = self.rp
-        if ctx["E"]:
+        if ctx["E"] and not ctx.get("windowed"):
             rp._now_host = float(ctx["t_last"][-1])
             rp._params_valid = False
             rp._now_dirty = True
@@ -540,7 +644,8 @@ class ShardedStreamRunner:
                 dist.all_reduce(out_neg, group=self.group)
         return out_pos, out_neg
 
-    def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True):
+    def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True, timing=None,
+                            out_pos=None, out_neg=None):
         """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
         grouped ncclSend / ncclRecv issued from C (tpnet_rows_step_targeted) whose receives land straight in the halo rows of
         the local table, step -- two launches per batch, ONE FFI call per stream (tpnet_rows_stream_targeted).  (Without the C
@@ -548,11 +653,12 @@ class ShardedStreamRunner:
         all-gather of the send buffers from which every rank takes its parts.)  Same results as the all-gather variant; each
         rank receives only what it reads."""
         rp, G, me = self.rp, self.G, self.me
-        ctx = self.prepare_targeted(src, dst, neg, t, batch_size, t_host_last)
+        ctx = self.prepare_targeted(src, dst, neg, t, batch_size, t_host_last, out_pos=out_pos, out_neg=out_neg,
+                                    zero_outputs=merge_outputs and G > 1)
         if ctx["E"] == 0:
             return ctx["out_pos"], ctx["out_neg"]
         if ctx["comm"] is not None or G == 1:
-            self.steps_targeted(ctx, 0, ctx["nb"])
+            self.steps_targeted(ctx, 0, ctx["nb"], timing=timing)
             return self.finish_targeted(ctx, merge_outputs)
         # another transport (torch.distributed all_to_all on RCCL without the C communicator; gloo in the tests): the same
         # pack launch, the rows moved into the same halo rows, the same step
