@@ -106,10 +106,10 @@ def _physical_cores():
 def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3, quick=False):
     """the torch-CPU port of the reference ops (oracle/torch_port.py, eager dense decay included) on
     this box's host cores, on a bounded prefix of the same workload: 2 warm-up batches, `reps` repetitions, median.  Settings: ALL
-    physical cores this process may use (`cores` = the threads actually used), 16 threads, and the
-    reference's own 3 intra-op threads (train_link_prediction.py:124); update-only, readout-only and combined rates, with and
-    without rp.mlp.  `value` = the all-cores figure (more threads are not faster on these small ops: the 3-thread figure beats
-    both on a 2 x 64-core host -- all three are reported).  quick: one repetition, no mlp leg (the N > 1 line)."""
+    physical cores this process may use, 16 threads, and the reference's own 3 intra-op threads
+    (train_link_prediction.py:124); update-only, readout-only and combined rates, with and without rp.mlp.  `value` = the FASTEST
+    of the three, `cores` = the threads it used (more threads are not faster on these small ops: 128 threads of a 2 x 64-core host
+    run 30x slower than 16 -- all three are reported).  quick: one repetition, no mlp leg (the N > 1 line)."""
     try:
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
@@ -118,30 +118,38 @@ def cpu_baseline(cfg, src, dst, neg, t, N, P0, reps=3, quick=False):
     threads16 = min(usable, 16)
     B = cfg["B"]
     nb = max(3, min(len(src) // B - 2, max(3, (150000 if quick else 400000) // B)))   # ~400 000 edges per repetition
+    # (the all-cores setting on a shorter sample, once: 128 threads on these small ops run at ~0.013 M edges/s -- 30x slower than
+    # 16 -- and the full sample would take minutes)
+    nb_all = max(3, min(nb, 24000 // B))
     med = lambda xs: float(np.median(xs))
-    settings = [("all", threads_all, False), ("16thr", threads16, False), ("3thr", 3, False)]
+    settings = [("16thr", threads16, False, nb, reps), ("3thr", 3, False, nb, reps)]
+    if threads_all != threads16:
+        settings.append(("all", threads_all, False, nb_all, 1))
     if not quick:
-        settings.append(("all_mlp", threads_all, True))
+        settings.append(("16thr_mlp", threads16, True, nb, reps))
     out = {}
-    for name, th, mlp in settings:
-        if name == "16thr" and th == threads_all:
-            out[name] = out["all"]
-            continue
-        runs = [_cpu_port_times(cfg, src, dst, neg, t, P0, th, nb, mlp) for _ in range(reps)]
-        n = nb * B
+    for name, th, mlp, nb_, reps_ in settings:
+        runs = [_cpu_port_times(cfg, src, dst, neg, t, P0, th, nb_, mlp) for _ in range(reps_)]
+        n = nb_ * B
         out[name] = {"combined": n / med([a + b for a, b in runs]), "readout_only": n / med([a for a, _ in runs]),
-                     "update_only": n / med([b for _, b in runs])}
+                     "update_only": n / med([b for _, b in runs]), "threads": th, "batches": nb_, "repetitions": reps_}
+    if "all" not in out:
+        out["all"] = out["16thr"]
     torch.set_num_threads(threads16)
-    res = {"value": out["all"]["combined"], "unit": "edges/s", "cores": threads_all, "cpu_model": _cpu_model(),
+    best = max(("16thr", "3thr", "all"), key=lambda k: out[k]["combined"])
+    res = {"value": out[best]["combined"], "unit": "edges/s", "cores": out[best]["threads"], "cpu_model": _cpu_model(),
            "host_logical_cpus": os.cpu_count(), "host_physical_cores": _physical_cores(), "kind": "port",
-           "readout_only": out["all"]["readout_only"], "update_only": out["all"]["update_only"],
+           "value_is": f"the fastest of the three thread settings ({best})",
+           "readout_only": out[best]["readout_only"], "update_only": out[best]["update_only"],
+           "value_all_physical_cores": out["all"]["combined"], "threads_all_physical_cores": out["all"]["threads"],
            "value_16_threads": out["16thr"]["combined"], "value_3_threads": out["3thr"]["combined"],
            "readout_only_3_threads": out["3thr"]["readout_only"], "update_only_3_threads": out["3thr"]["update_only"],
            "repetitions": reps,
-           "sample": f"{nb} batches of {B} edges after 2 warm-up batches, median of {reps} repetitions per setting; torch-CPU "
-                     f"port of the reference ops incl. its eager dense decay; pre-mlp features unless with_mlp"}
-    if "all_mlp" in out:
-        res["with_mlp"] = out["all_mlp"]["combined"]
+           "sample": f"{nb} batches of {B} edges after 2 warm-up batches, median of {reps} repetitions per setting (all physical cores: "
+                     f"{out['all']['batches']} batches, once); torch-CPU port of the reference ops incl. its eager dense decay; pre-mlp "
+                     f"features unless with_mlp"}
+    if "16thr_mlp" in out:
+        res["with_mlp"] = out["16thr_mlp"]["combined"]
     return res
 
 
@@ -491,8 +499,17 @@ def main():
     dist = None
     # TPNET_BENCH_FORCE_DIST=1 (development): take the N>1 code path, collectives included, with a single rank
     force_dist = os.environ.get("TPNET_BENCH_FORCE_DIST") == "1"
+    result_fd = None
     if world > 1 or force_dist:
+        # stdout carries ONE line: whatever the communication library prints there (RCCL's version banner goes to stdout) is sent
+        # to stderr for the life of the process; the result line is written to the original stdout
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
+        if env_world is None:                  # (the forced one-rank run: a rendezvous of its own)
+            os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                               "MASTER_PORT": str(free_port())})
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -505,9 +522,9 @@ def main():
 
         def _give_up():
             if rank == 0:
-                print(_error_line(world, "multi-GPU run did not finish in time (watchdog); set TPNET_ROWS_C_LOOP=0 to route the "
-                                         "exchange through torch.distributed, TPNET_BENCH_EXCHANGE=allgather for the all-gather variant"),
-                      flush=True)
+                os.write(result_fd if result_fd is not None else 1,
+                         (_error_line(world, "multi-GPU run did not finish in time (watchdog); set TPNET_ROWS_C_LOOP=0 to route the "
+                                      "exchange through torch.distributed, TPNET_BENCH_EXCHANGE=allgather for the all-gather variant") + "\n").encode())
             os._exit(3)
         _wd = threading.Timer(float(os.environ.get("TPNET_BENCH_WATCHDOG", "420")), _give_up)
         _wd.daemon = True
@@ -553,6 +570,13 @@ def main():
         m.random_projections[0].data = P0.clone()
         return m.to(dev)
 
+    def write_line(text):
+        if result_fd is None:
+            print(text, flush=True)
+        else:
+            sys.stdout.flush()
+            os.write(result_fd, (text + "\n").encode())
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -585,8 +609,12 @@ def main():
             run(W, W + k_steps, pre)
         else:
             run(W, W + k_steps)
-        barrier()
+        # the clock of a rank stops when ITS k_steps are done (synchronize); the barrier behind it closes the bracket, and the
+        # figure is the MAX over the ranks -- a collective barrier inside every rank's clock was ~100-200 us of RCCL latency on top
+        # of a 150-us region, and measured the barrier, not the steps (the ranks of a sharded stream meet at every step's exchange)
+        torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        barrier()
         if dist is not None:
             tt = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -724,7 +752,7 @@ def main():
         warm_windowed = will_window
         el = time_leg(run, k_steps)
         warm_windowed = False
-        rp_.check_device_errors()
+        runner.check_device_errors()
         tb = runner.table_bytes()
         # ---- the kernel those steps ran on, timed live: an extra pass over the same batches
         bpe_ = bytes_per_edge(d_, L)
@@ -864,7 +892,7 @@ def main():
                                      "first_region": {"value": K * Bg / regions[0], "ms_per_step": regions[0] * 1e3 / K}}
         if extra:
             line.update(extra)
-        print(json.dumps(line), flush=True)
+        write_line(json.dumps(line))
 
     # second leg at N > 1: the column-sharded layout (ablation) on the same workload, behind a watchdog (a collective that
     # never returns must not cost the main line)

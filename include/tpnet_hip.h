@@ -42,6 +42,7 @@ extern "C" {
                                     cores), TPNET_FLAG_NO_MFMA_READOUT, tpnet_rows_stream_targeted, tpnet_mlp64_bwd_f32, tpnet_host_anchored_features;
                                     tpnet_run_stream_tagged replays streams of up to 64 chunks;
                                7: + tpnet_stream_schedule (which schedule tpnet_run_stream would take); tpnet_xplan_targeted serves G = 1;
+                                    tpnet_xplan_targeted_large (batches beyond one workgroup's lists);
                                     the side-by-side plans of a multi-chunk stream are bounded (TPNET_ARENA_MAX_RATIO) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
@@ -416,6 +417,19 @@ int64_t tpnet_xplan_capacity(void);
 int tpnet_xplan_targeted(const int64_t* src, const int64_t* dst, const int64_t* neg, int64_t E, int64_t batch, int64_t N, int32_t G,
                          int32_t me, int32_t n_owned, uint32_t* recv_keys, int64_t* pack_ids, int64_t* cnt, uint32_t* status,
                          int64_t* local_src, int64_t* local_dst, int64_t* local_neg, void* stream);
+
+/* The same plan for batches whose lists exceed tpnet_xplan_capacity() (C4's law over 8 ranks: ~25 000 rows received per batch of
+ * 80 000 edges): one device-wide radix sort of the call's (list, batch, peer, node) keys instead of a workgroup per batch.  The
+ * lists are COMPACT: pack_ids holds the local rows to send, all batches back to back in (batch, reader, node) order (at most 3 E;
+ * batch b starts at the sum of the earlier batches' send counts), and a remote node's halo row is n_owned + its place in its
+ * batch's receive list ((owner, node) order) -- both as tpnet_rows_stream_targeted consumes them.  cnt / status / local_* as
+ * above.  scratch: tpnet_xplan_large_bytes(E, batch, G) device bytes.  Synchronises `stream` ONCE in the middle (the number of
+ * keys sizes the sort); the caller reads cnt / status back afterwards as for tpnet_xplan_targeted. */
+size_t tpnet_xplan_large_bytes(int64_t E, int64_t batch, int32_t G);
+int tpnet_xplan_targeted_large(const int64_t* src, const int64_t* dst, const int64_t* neg, int64_t E, int64_t batch, int64_t N,
+                               int32_t G, int32_t me, int32_t n_owned, void* scratch, size_t scratch_bytes, int64_t* pack_ids,
+                               int64_t* cnt, uint32_t* status, int64_t* local_src, int64_t* local_dst, int64_t* local_neg,
+                               void* stream);
 
 /* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
  * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,

@@ -647,12 +647,17 @@ def test_row_sharded_c4_table_two_ranks_on_one_gpu(exchange):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,N,E,B,with_neg", [(2, 211, 700, 100, True), (3, 3000, 905, 60, True), (8, 9000, 8000 * 3 - 17, 8000, True),
-                                              (4, 150, 333, 50, False), (8, 1 << 20, 5000, 1000, True)])
-def test_device_exchange_plan_equals_torch_plan(G, N, E, B, with_neg):
+@pytest.mark.parametrize("G,N,E,B,with_neg,large", [(2, 211, 700, 100, True, False), (3, 3000, 905, 60, True, False),
+                                                    (8, 9000, 8000 * 3 - 17, 8000, True, False), (4, 150, 333, 50, False, False),
+                                                    (8, 1 << 20, 5000, 1000, True, False),
+                                                    (2, 211, 700, 100, True, True), (4, 150, 333, 50, False, True), (1, 97, 250, 40, True, True),
+                                                    (8, 3_000_000, 40000 * 3 - 17, 40000, True, False), (1, 97, 250, 40, True, False)])
+def test_device_exchange_plan_equals_torch_plan(G, N, E, B, with_neg, large):
     """tpnet_xplan_targeted (csrc/xplan.hip: the targeted exchange's plan in two launches) against plan_targeted + the torch
     relabelling, for every rank of G: the same message sizes, the same pack order, the same halo slot for every endpoint --
-    hubs, ragged last batch, a global batch of 8 000 edges (24 000 items per batch) and a table of 2^20 nodes included."""
+    hubs, ragged last batch, a global batch of 8 000 edges (24 000 items per batch) and a table of 2^20 nodes included.  `large`
+    (and batches of 40 000 edges on their own): tpnet_xplan_targeted_large, one device-wide sort of the call's keys -- the plan of
+    C4-sized global batches, whose lists exceed one workgroup's LDS.  One rank: empty lists, every id its own row."""
     if not torch.cuda.is_available():
         pytest.fail("needs a GPU")
     from tpnet_amd import _lib
@@ -670,6 +675,7 @@ def test_device_exchange_plan_equals_torch_plan(G, N, E, B, with_neg):
     for me in range(G):
         r = object.__new__(ShardedStreamRunner)
         r.G, r.me, r.N, r.n_cap, r.H, r.rp, r.group = G, me, N, (N + G - 1) // G, 3 * B, _Rp(), None
+        r.xplan_force_large = large
         want = r.relabel_targeted(ds, dd, dn, B)
         got = r.relabel_targeted_device(ds, dd, dn, B)
         assert got is not None
@@ -680,15 +686,18 @@ def test_device_exchange_plan_equals_torch_plan(G, N, E, B, with_neg):
         stot = want["send_cnt"].sum(axis=1)
         s0 = np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64)
         gp, wp = got["pack_ids"].cpu().numpy(), want["pack_ids"].cpu().numpy()
+        g0 = got["sstart"]
         for b in range(len(stot)):
-            np.testing.assert_array_equal(gp[b * cap: b * cap + stot[b]], wp[s0[b]: s0[b] + stot[b]])
+            np.testing.assert_array_equal(gp[g0[b]: g0[b] + stot[b]], wp[s0[b]: s0[b] + stot[b]])
     # an id outside [0, N) is an IndexError, as on the torch path
     bad = ds.clone()
     bad[5] = N
     r = object.__new__(ShardedStreamRunner)
     r.G, r.me, r.N, r.n_cap, r.H, r.rp, r.group = G, 0, N, (N + G - 1) // G, 3 * B, _Rp(), None
+    r.xplan_force_large = large
     with pytest.raises(IndexError):
         r.relabel_targeted_device(bad, dd, dn, B)
+        r._check_pending_status()               # (one rank: the status words are read back asynchronously)
 
 
 @pytest.mark.gpu

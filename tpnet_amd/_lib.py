@@ -138,6 +138,9 @@ SIGNATURES = {
     "tpnet_xplan_capacity": (C.c_int64, []),
     "tpnet_xplan_targeted": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
                                        _P, _P, _P]),
+    "tpnet_xplan_large_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "tpnet_xplan_targeted_large": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
+                                             _P, _P, _P, _P, _P, _P, _P]),
     "tpnet_host_encoder_features": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_double,
                                               C.c_double, C.c_uint32, C.POINTER(Mlp), _P, C.c_size_t, _P, _P, _P]),
 }

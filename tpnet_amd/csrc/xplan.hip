@@ -13,6 +13,8 @@
 #include "tpnet_common.h"
 
 #include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace tpnet {
 
@@ -152,6 +154,150 @@ __global__ void k_xrelabel(XArgs a, int32_t n_cap, int64_t* __restrict__ lsrc, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same plan for batches whose lists do not fit one workgroup's LDS (C4's law over 8 ranks: 25 000 rows received per
+// batch of 80 000 edges): the (list, batch, peer, node) keys of the whole call appended to one array (wave-aggregated
+// atomics; the order is restored by the sort), ONE device-wide radix sort, head flags + scan + compaction = the distinct keys,
+// counts and batch starts by binary search, relabelling by binary search in the batch's segment.  list 0 = what this rank
+// receives, ordered (batch, owner, node); list 1 = what it sends, ordered (batch, reader, node): the same orders as k_xplan's.
+// ---------------------------------------------------------------------------------------------------------------------
+struct XLArgs {
+    const int64_t* src;
+    const int64_t* dst;
+    const int64_t* neg;
+    int64_t E, B, N, nb;
+    int32_t G, me, nbits, gbits, bbits;
+    unsigned long long* keys;        // [cap] appended keys
+    unsigned long long* sorted;      // [cap]
+    uint32_t* heads;                 // [cap] head flags, then (in place) their exclusive scan
+    unsigned long long* uniq;        // [cap] distinct keys
+    uint32_t* counter;               // [0] appended keys; [1] distinct keys
+    uint32_t* off;                   // [2 * nb * G + 1] first distinct key of every (list, batch, peer)
+    uint32_t* status;
+};
+
+__device__ __forceinline__ unsigned long long xl_key(const XLArgs& a, int list, int64_t b, int32_t minor, int64_t node) {
+    return ((unsigned long long)list << (a.bbits + a.gbits + a.nbits)) | ((unsigned long long)b << (a.gbits + a.nbits)) |
+           ((unsigned long long)minor << a.nbits) | (unsigned long long)node;
+}
+
+__global__ __launch_bounds__(256) void k_xl_keys(XLArgs a) {
+    const int nk = a.neg ? 3 : 2;
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < nk * a.E; i0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = i0 + threadIdx.x;
+        unsigned long long k0 = 0, k1 = 0;
+        bool h0 = false, h1 = false;
+        if (i < nk * a.E) {
+            const int kind = (int)(i / a.E);
+            const int64_t e = i - (int64_t)kind * a.E;
+            const int64_t s = a.src[e], d = a.dst[e];
+            const int64_t g = (kind == 2) ? a.neg[e] : 0;
+            const bool ok = (uint64_t)s < (uint64_t)a.N && (uint64_t)d < (uint64_t)a.N && (uint64_t)g < (uint64_t)a.N;
+            if (!ok) {
+                if (kind != 1) atomicAdd(a.status, 1u);                  // (an edge's src / dst once, its negative once)
+            } else {
+                const int64_t rn = (kind == 1) ? d : s;                  // the node whose owner reads ...
+                const int64_t nd = (kind == 0) ? d : (kind == 1 ? s : g);    // ... this node
+                const int32_t reader = (int32_t)(rn % a.G), owner = (int32_t)(nd % a.G);
+                const int64_t b = e / a.B;
+                h0 = reader == a.me && owner != a.me;
+                h1 = owner == a.me && reader != a.me;
+                if (h0) k0 = xl_key(a, 0, b, owner, nd);
+                if (h1) k1 = xl_key(a, 1, b, reader, nd);
+            }
+        }
+        // one atomic per wave and list
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1);
+        const uint32_t n0 = (uint32_t)__popcll(m0), n1 = (uint32_t)__popcll(m1);
+        uint32_t base = 0;
+        if (lane == 0 && n0 + n1) base = atomicAdd(a.counter, n0 + n1);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (h0) a.keys[base + (uint32_t)__popcll(m0 & ((1ull << lane) - 1ull))] = k0;
+        if (h1) a.keys[base + n0 + (uint32_t)__popcll(m1 & ((1ull << lane) - 1ull))] = k1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xl_heads(XLArgs a, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        a.heads[i] = (i == 0 || a.sorted[i - 1] != a.sorted[i]) ? 1u : 0u;
+}
+
+// heads[] holds the exclusive scan of the flags now: element i is distinct iff it is the last one or heads[i + 1] != heads[i]
+__global__ __launch_bounds__(256) void k_xl_compact(XLArgs a, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const bool head = i == 0 || a.sorted[i - 1] != a.sorted[i];
+        if (head) a.uniq[a.heads[i]] = a.sorted[i];
+        if (i == n - 1) a.counter[1] = a.heads[i] + (head ? 1u : 0u);
+    }
+}
+
+__device__ __forceinline__ uint32_t xl_lower(const unsigned long long* __restrict__ u, uint32_t lo, uint32_t hi, unsigned long long key) {
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (u[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_xl_offsets(XLArgs a) {
+    const uint32_t nu = a.counter[1];
+    const int64_t nq = 2 * a.nb * a.G;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q <= nq; q += (int64_t)gridDim.x * blockDim.x) {
+        if (q == nq) { a.off[q] = nu; continue; }
+        const int list = (int)(q / (a.nb * a.G));
+        const int64_t r = q - (int64_t)list * a.nb * a.G;
+        a.off[q] = xl_lower(a.uniq, 0u, nu, xl_key(a, list, r / a.G, (int32_t)(r % a.G), 0));
+    }
+}
+
+// counts [nb][2][G], the rows to pack (list 1, in order), every endpoint relabelled
+__global__ __launch_bounds__(256) void k_xl_finish(XLArgs a, int32_t n_cap, int64_t* __restrict__ cnt, int64_t* __restrict__ pack_ids,
+                                                   int64_t* __restrict__ lsrc, int64_t* __restrict__ ldst, int64_t* __restrict__ lneg) {
+    const int nk = a.neg ? 3 : 2;
+    const int64_t nq = 2 * a.nb * a.G;
+    const uint32_t send0 = a.off[a.nb * a.G], nu = a.off[nq];
+    const unsigned long long nmask = (1ull << a.nbits) - 1ull;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = gid; q < nq; q += gsz) {
+        const int list = (int)(q / (a.nb * a.G));
+        const int64_t r = q - (int64_t)list * a.nb * a.G;
+        cnt[((r / a.G) * 2 + list) * a.G + (r % a.G)] = (int64_t)(a.off[q + 1] - a.off[q]);
+    }
+    for (int64_t j = gid; j < (int64_t)(nu - send0); j += gsz) pack_ids[j] = (int64_t)((a.uniq[send0 + j] & nmask) / (unsigned)a.G);
+    for (int64_t i = gid; i < nk * a.E; i += gsz) {
+        const int kind = (int)(i / a.E);
+        const int64_t e = i - (int64_t)kind * a.E;
+        const int64_t nd = kind == 0 ? a.src[e] : (kind == 1 ? a.dst[e] : a.neg[e]);
+        int64_t loc = n_cap;
+        if ((uint64_t)nd < (uint64_t)a.N) {
+            const int32_t owner = (int32_t)(nd % a.G);
+            if (owner == a.me) {
+                loc = nd / a.G;
+            } else {
+                const int64_t b = e / a.B;
+                const uint32_t lo = a.off[b * a.G], hi = a.off[(b + 1) * a.G];      // the batch's receive list
+                const unsigned long long key = xl_key(a, 0, b, owner, nd);
+                const uint32_t pos = xl_lower(a.uniq, lo, hi, key);
+                if (pos < hi && a.uniq[pos] == key) loc = n_cap + (int64_t)(pos - lo);
+            }
+        }
+        (kind == 0 ? lsrc : (kind == 1 ? ldst : lneg))[e] = loc;
+    }
+}
+
+static size_t xl_align(size_t x) { return (x + 255) / 256 * 256; }
+static size_t xl_sort_tmp(size_t cap) {
+    size_t bytes = 0;
+    unsigned long long* k = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, k, k, cap, 0u, 64u, (hipStream_t)0, false);
+    size_t b2 = 0;
+    uint32_t* h = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, b2, h, h, 0u, cap, rocprim::plus<uint32_t>(), (hipStream_t)0, false);
+    return xl_align(bytes > b2 ? bytes : b2);
+}
+
 }  // namespace tpnet
 
 using namespace tpnet;
@@ -180,6 +326,74 @@ int tpnet_xplan_targeted(const int64_t* src, const int64_t* dst, const int64_t* 
     int grid = (int)((items + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_xrelabel, dim3(grid), dim3(256), 0, s, a, n_owned, local_src, local_dst, local_neg);
+    TPNET_HIP_TRY(hipGetLastError());
+    return TPNET_OK;
+}
+
+size_t tpnet_xplan_large_bytes(int64_t E, int64_t batch, int32_t G) {
+    if (E < 1 || batch < 1 || G < 1) return 0;
+    const size_t cap = 6 * (size_t)E;                           // (an item is at most one key of each list)
+    const size_t nb = (size_t)((E + batch - 1) / batch);
+    return 3 * xl_align(cap * 8) + xl_align(cap * 4) + xl_align((2 * nb * (size_t)G + 1) * 4) + 256 + xl_sort_tmp(cap) + 256;
+}
+
+int tpnet_xplan_targeted_large(const int64_t* src, const int64_t* dst, const int64_t* neg, int64_t E, int64_t batch, int64_t N,
+                               int32_t G, int32_t me, int32_t n_owned, void* scratch, size_t scratch_bytes, int64_t* pack_ids,
+                               int64_t* cnt, uint32_t* status, int64_t* local_src, int64_t* local_dst, int64_t* local_neg,
+                               void* stream) {
+    if (!src || !dst || E < 0 || batch < 1 || N < 1 || G < 1 || G > 64 || me < 0 || me >= G || n_owned < 0) return TPNET_ERR_BAD_ARG;
+    if (!scratch || !pack_ids || !cnt || !status || !local_src || !local_dst || (neg && !local_neg)) return TPNET_ERR_BAD_ARG;
+    if (E == 0) return TPNET_OK;
+    if (6 * E >= ((int64_t)1 << 32)) return TPNET_ERR_BAD_ARG;                   // 32-bit positions
+    if (scratch_bytes < tpnet_xplan_large_bytes(E, batch, G)) return TPNET_ERR_WORKSPACE;
+    const int64_t nb = (E + batch - 1) / batch;
+    int nbits = 1, gbits = 1, bbits = 1;
+    while (nbits < 62 && (1ll << nbits) < N) ++nbits;
+    while ((1 << gbits) < G) ++gbits;
+    while (bbits < 62 && (1ll << bbits) < nb) ++bbits;
+    if (nbits + gbits + bbits + 1 > 63) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t cap = 6 * (size_t)E;
+    char* c = reinterpret_cast<char*>((reinterpret_cast<size_t>(scratch) + 255) / 256 * 256);
+    auto take = [&](size_t bytes) { void* r = c; c += xl_align(bytes); return r; };
+    XLArgs a{};
+    a.src = src; a.dst = dst; a.neg = neg; a.E = E; a.B = batch; a.N = N; a.nb = nb;
+    a.G = G; a.me = me; a.nbits = nbits; a.gbits = gbits; a.bbits = bbits;
+    a.keys = (unsigned long long*)take(cap * 8);
+    a.sorted = (unsigned long long*)take(cap * 8);
+    a.uniq = (unsigned long long*)take(cap * 8);
+    a.heads = (uint32_t*)take(cap * 4);
+    a.off = (uint32_t*)take((2 * (size_t)nb * (size_t)G + 1) * 4);
+    a.counter = (uint32_t*)take(8);
+    a.status = status;
+    void* tmp = c;
+    size_t tmp_bytes = xl_sort_tmp(cap);
+    TPNET_HIP_TRY(hipMemsetAsync(status, 0, 2 * sizeof(uint32_t), s));
+    TPNET_HIP_TRY(hipMemsetAsync(a.counter, 0, 8, s));
+    const int64_t items = (neg ? 3 : 2) * E;
+    int grid = (int)((items + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_xl_keys, dim3(grid), dim3(256), 0, s, a);
+    // how many keys there are decides the size of the sort: ONE small read-back (the caller reads the counts back afterwards anyway)
+    uint32_t n_keys = 0;
+    TPNET_HIP_TRY(hipMemcpyAsync(&n_keys, a.counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    TPNET_HIP_TRY(hipStreamSynchronize(s));
+    if (n_keys > cap) return TPNET_ERR_WORKSPACE;
+    if (n_keys > 0) {
+        size_t tb = tmp_bytes;
+        TPNET_HIP_TRY(rocprim::radix_sort_keys(tmp, tb, a.keys, a.sorted, (size_t)n_keys, 0u, (unsigned)(nbits + gbits + bbits + 1), s, false));
+        int g2 = (int)((n_keys + 255) / 256);
+        if (g2 > 8192) g2 = 8192;
+        hipLaunchKernelGGL(k_xl_heads, dim3(g2), dim3(256), 0, s, a, n_keys);
+        tb = tmp_bytes;
+        TPNET_HIP_TRY(rocprim::exclusive_scan(tmp, tb, a.heads, a.heads, 0u, (size_t)n_keys, rocprim::plus<uint32_t>(), s, false));
+        hipLaunchKernelGGL(k_xl_compact, dim3(g2), dim3(256), 0, s, a, n_keys);
+    }
+    const int64_t nq = 2 * nb * G + 1;
+    int g3 = (int)((nq + 255) / 256);
+    if (g3 > 4096) g3 = 4096;
+    hipLaunchKernelGGL(k_xl_offsets, dim3(g3), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_xl_finish, dim3(grid), dim3(256), 0, s, a, n_owned, cnt, pack_ids, local_src, local_dst, local_neg);
     TPNET_HIP_TRY(hipGetLastError());
     return TPNET_OK;
 }

@@ -415,6 +415,7 @@ class ShardedStreamRunner:
         return P
 
     device_plan = True         # the targeted exchange's plan by tpnet_xplan_targeted (two launches, one read-back) where it applies
+    xplan_force_large = False  # tests: take tpnet_xplan_targeted_large (one device-wide sort) whatever the batch size
 
     @staticmethod
     def _stream_sig(src, dst, neg, t, E, B):
@@ -435,6 +436,21 @@ class ShardedStreamRunner:
             self.__dict__["_pin"] = pin
         return pin
 
+    def _check_pending_status(self):
+        """The status words of a one-rank exchange plan whose read-back was left in flight (relabel_targeted_device, G = 1)."""
+        ps = self.__dict__.pop("_pending_status", None)
+        if ps is not None:
+            pin, ev, off = ps
+            ev.synchronize()
+            if int(pin[off:off + 1].numpy().view(np.uint32)[0]):
+                self.__dict__["_xplan_cache"] = None
+                raise IndexError(f"node id out of range for {self.N} nodes")
+
+    def check_device_errors(self):
+        """Raise IndexError if a call met a node id outside [0, node_num) since the last check (the shard's module included)."""
+        self._check_pending_status()
+        self.rp.check_device_errors()
+
     def relabel_targeted_device(self, src, dst, neg, batch_size: int):
         """relabel_targeted on the device (csrc/xplan.hip: one workgroup per batch sorts the batch's receive and send lists, one
         thread per endpoint relabels) -- None where it does not apply (ids not on a GPU, 32-bit keys too narrow for N and G, a
@@ -453,41 +469,84 @@ class ShardedStreamRunner:
         nb = (E + B - 1) // B
         dev = src.device
         cap = int(lib.tpnet_xplan_capacity())
-        # scratch of one plan, kept across calls (a stream of the same shape reuses it; torch.empty per call was five allocations)
-        key = (nb, cap, G, E, neg is not None, dev)
-        sc = self.__dict__.get("_xplan_scratch")
+        n_tail = nb * 2 * G + 1
+
+        def read_back(tail):
+            """ONE read-back (message sizes + status) through a pinned buffer: an asynchronous copy + an event, no pageable staging"""
+            pin, ev = self._pinned(n_tail)
+            pin[:n_tail].copy_(tail, non_blocking=True)
+            ev.record(torch.cuda.current_stream(dev))
+            ev.synchronize()
+            host = pin[:n_tail].numpy()
+            st = host[nb * 2 * G:].view(np.uint32)
+            if int(st[0]):
+                raise IndexError(f"node id out of range for {N} nodes")
+            c = host[: nb * 2 * G].reshape(nb, 2, G)
+            return int(st[1]), np.ascontiguousarray(c[:, 0, :]), np.ascontiguousarray(c[:, 1, :])   # (copies: the buffer is reused)
+
+        def result(lsrc, ldst, lneg, recv_cnt, send_cnt, pack_ids, sstart):
+            rtot = recv_cnt.sum(axis=1)
+            if nb and int(rtot.max()) > self.H:
+                raise ValueError(f"a batch reads {int(rtot.max())} rows of other ranks but the shard has {self.H} halo rows")
+            return dict(src=lsrc, dst=ldst, neg=lneg, send_cnt=send_cnt, recv_cnt=recv_cnt, rtot=rtot, pack_ids=pack_ids, sstart=sstart)
+
+        # a workgroup per batch while a batch's lists can fit its LDS (at most 3 B items per list); else -- or when a batch
+        # overflowed after all -- ONE device-wide sort of the call's keys (tpnet_xplan_targeted_large)
+        small = not self.xplan_force_large and 3 * B <= 4 * cap
+        if small:
+            # scratch of one plan, kept across calls and only ever grown (torch.empty per call was five allocations -- and a call
+            # longer than the ones before it paid them inside its timed region)
+            sc = self.__dict__.get("_xplan_scratch")
+            if sc is None or sc["dev"] != dev or sc["nb"] < nb or sc["E"] < E or sc["G"] != G or (neg is not None and sc["lneg"] is None):
+                nb_, E_ = max(nb, sc["nb"] if sc else 0), max(E, sc["E"] if sc else 0)
+                sc = dict(dev=dev, nb=nb_, E=E_, G=G, recv_keys=torch.empty((nb_, cap), dtype=torch.int32, device=dev),
+                          pack_ids=torch.empty((nb_, cap), dtype=torch.int64, device=dev),
+                          tail=torch.empty(nb_ * 2 * G + 1, dtype=torch.int64, device=dev),
+                          lsrc=torch.empty(E_, dtype=torch.int64, device=dev), ldst=torch.empty(E_, dtype=torch.int64, device=dev),
+                          lneg=torch.empty(E_, dtype=torch.int64, device=dev) if neg is not None else None)
+                self.__dict__["_xplan_scratch"] = sc
+            recv_keys, pack_ids, tail = sc["recv_keys"], sc["pack_ids"], sc["tail"][:n_tail]
+            lsrc, ldst, lneg = sc["lsrc"][:E], sc["ldst"][:E], (sc["lneg"][:E] if neg is not None else None)
+            cnt, status = tail[: nb * 2 * G], tail[nb * 2 * G:]
+            rc = lib.tpnet_xplan_targeted(src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, E, B, N, G, me,
+                                          n_cap, recv_keys.data_ptr(), pack_ids.data_ptr(), cnt.data_ptr(), status.data_ptr(),
+                                          lsrc.data_ptr(), ldst.data_ptr(), lneg.data_ptr() if lneg is not None else None,
+                                          self.rp._stream())
+            if rc:
+                return None
+            if G == 1:
+                # ONE rank: no message sizes to wait for -- the status words (ids out of range) are read back asynchronously and
+                # looked at by check_device_errors() / the next call; a bad id was relabelled to a halo row, never dereferenced wildly
+                pin, ev = self._pinned(n_tail)
+                pin[:n_tail].copy_(tail, non_blocking=True)
+                ev.record(torch.cuda.current_stream(dev))
+                self.__dict__["_pending_status"] = (pin, ev, nb * 2 * G)
+                z = np.zeros((nb, 1), dtype=np.int64)
+                return result(lsrc, ldst, lneg, z, z.copy(), pack_ids.view(-1), np.arange(nb, dtype=np.int64) * cap)
+            over, recv_cnt, send_cnt = read_back(tail)
+            if not over:
+                return result(lsrc, ldst, lneg, recv_cnt, send_cnt, pack_ids.view(-1), np.arange(nb, dtype=np.int64) * cap)
+        if 6 * E >= (1 << 32):
+            return None
+        need = int(lib.tpnet_xplan_large_bytes(E, B, G))
+        key = ("l", nb, G, E, neg is not None, dev)
+        sc = self.__dict__.get("_xplan_scratch_l")
         if sc is None or sc[0] != key:
-            sc = (key, torch.empty((nb, cap), dtype=torch.int32, device=dev), torch.empty((nb, cap), dtype=torch.int64, device=dev),
-                  torch.empty(nb * 2 * G + 1, dtype=torch.int64, device=dev), torch.empty(E, dtype=torch.int64, device=dev),
+            sc = (key, torch.empty(need, dtype=torch.uint8, device=dev), torch.empty(3 * E, dtype=torch.int64, device=dev),
+                  torch.empty(n_tail, dtype=torch.int64, device=dev), torch.empty(E, dtype=torch.int64, device=dev),
                   torch.empty(E, dtype=torch.int64, device=dev), torch.empty(E, dtype=torch.int64, device=dev) if neg is not None else None)
-            self.__dict__["_xplan_scratch"] = sc
-        _, recv_keys, pack_ids, tail, lsrc, ldst, lneg = sc
+            self.__dict__["_xplan_scratch_l"] = sc
+        _, scratch, pack_ids, tail, lsrc, ldst, lneg = sc
         cnt, status = tail[: nb * 2 * G], tail[nb * 2 * G:]
-        rc = lib.tpnet_xplan_targeted(src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, E, B, N, G, me,
-                                      n_cap, recv_keys.data_ptr(), pack_ids.data_ptr(), cnt.data_ptr(), status.data_ptr(),
-                                      lsrc.data_ptr(), ldst.data_ptr(), lneg.data_ptr() if lneg is not None else None,
-                                      self.rp._stream())
+        rc = lib.tpnet_xplan_targeted_large(src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, E, B, N, G, me,
+                                            n_cap, scratch.data_ptr(), scratch.numel(), pack_ids.data_ptr(), cnt.data_ptr(),
+                                            status.data_ptr(), lsrc.data_ptr(), ldst.data_ptr(),
+                                            lneg.data_ptr() if lneg is not None else None, self.rp._stream())
         if rc:
             return None
-        # ONE read-back (message sizes + status) through a pinned buffer: an asynchronous copy + an event, no pageable staging
-        n_tail = nb * 2 * G + 1
-        pin, ev = self._pinned(n_tail)
-        pin[:n_tail].copy_(tail, non_blocking=True)
-        ev.record(torch.cuda.current_stream(dev))
-        ev.synchronize()
-        host = pin[:n_tail].numpy()
-        st = host[nb * 2 * G:].view(np.uint32)
-        if int(st[0]):
-            raise IndexError(f"node id out of range for {N} nodes")
-        if int(st[1]):
-            return None
-        c = host[: nb * 2 * G].reshape(nb, 2, G)
-        recv_cnt, send_cnt = np.ascontiguousarray(c[:, 0, :]), np.ascontiguousarray(c[:, 1, :])      # (copies: the pinned buffer is reused)
-        rtot = recv_cnt.sum(axis=1)
-        if nb and int(rtot.max()) > self.H:
-            raise ValueError(f"a batch reads {int(rtot.max())} rows of other ranks but the shard has {self.H} halo rows")
-        return dict(src=lsrc, dst=ldst, neg=lneg, send_cnt=send_cnt, recv_cnt=recv_cnt, rtot=rtot, pack_ids=pack_ids.view(-1),
-                    sstart=np.arange(nb, dtype=np.int64) * cap, recv_keys_dev=recv_keys)
+        _, recv_cnt, send_cnt = read_back(tail)
+        stot = send_cnt.sum(axis=1)
+        return result(lsrc, ldst, lneg, recv_cnt, send_cnt, pack_ids, np.concatenate([[0], np.cumsum(stot)[:-1]]).astype(np.int64))
 
     # a stream that is run again (same tensors, unchanged: _stream_sig) keeps its exchange plan, its relabelled ids and -- while
     # nothing else used the module's workspace and the clock it starts from is the same -- the plan of its kernels
@@ -520,6 +579,7 @@ class ShardedStreamRunner:
         if E == 0:
             z = torch.zeros((0, NG), dtype=torch.float32, device=dev)
             return dict(E=0, B=B, nb=0, out_pos=z, out_neg=z.clone() if neg is not None else None, now=rp._now_host)
+        self._check_pending_status()
         sig = self._stream_sig(src, dst, neg, t, E, B) if self.reuse_plans else None
         xc = self.__dict__.get("_xplan_cache")
         R = xc[1] if (sig is not None and xc is not None and xc[0] == sig) else None
@@ -530,11 +590,8 @@ class ShardedStreamRunner:
                 if int(torch.stack([x.min() for x in ends]).min()) < 0 or int(torch.stack([x.max() for x in ends]).max()) >= self.N:
                     raise IndexError(f"node id out of range for {self.N} nodes")
                 R = self.relabel_targeted(src, dst, neg, B)
-            elif sig is not None:
-                # (the device plan's lists live in scratch the NEXT cold plan overwrites: a kept plan owns copies of what the
-                # per-batch calls read -- made once, when a stream is first seen)
-                R = dict(R, src=R["src"].clone(), dst=R["dst"].clone(), neg=R["neg"].clone() if R["neg"] is not None else None,
-                         pack_ids=R["pack_ids"].clone() if G > 1 else R["pack_ids"])
+            # (the device plan's lists live in the runner's scratch, which the NEXT cold plan overwrites -- and that plan replaces
+            # this one in the one-entry cache at the same time; the module's own plan is dropped below for the same reason)
             R["scnt"] = np.ascontiguousarray(R["send_cnt"], dtype=np.int64)
             R["rcnt"] = np.ascontiguousarray(R["recv_cnt"], dtype=np.int64)
             R["stot"] = R["scnt"].sum(axis=1)
@@ -688,8 +745,12 @@ class ShardedStreamRunner:
             g_q = [torch.empty((gmax, L * d), dtype=torch.float32, device=dev) for _ in range(G)]
             pad_p0 = torch.zeros((gmax, d), dtype=torch.float32, device=dev)
             pad_q = torch.zeros((gmax, L * d), dtype=torch.float32, device=dev)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nb)] if timing is not None else None
+        cur = torch.cuda.current_stream(dev)
         for b in range(nb):
             ns, nr = int(stot[b]), int(rtot[b])
+            if evs:
+                evs[b][0].record(cur)
             _lib.check(lib.tpnet_pack_split(stp, pack_ptr + 8 * int(sstart[b]), ns, now, lam, send_p0.data_ptr(),
                                             send_q.data_ptr(), n_cap, nr, stream), "pack_split")
             if nccl:
@@ -709,9 +770,18 @@ class ShardedStreamRunner:
                         p0_t[n_cap + o:n_cap + o + c].copy_(g_p0[s_][a0:a0 + c])
                         q_t[0, n_cap + o:n_cap + o + c].copy_(g_q[s_][a0:a0 + c])
                         o += c
+            if evs:
+                evs[b][1].record(cur)
             _lib.check(lib.tpnet_step_batch(stp, ls_p, ld_p, ln_p, t_p, E, B, b, lam, lid0 + b, flags, 0, n_cap, op_p, on_p,
                                             ws_p, ws_n, stream), "step_batch")
+            if evs:
+                evs[b][2].record(cur)
             now = t_last_l[b]
+        if evs:
+            evs[-1][2].synchronize()
+            timing.update(total_ms=evs[0][0].elapsed_time(evs[-1][2]), batches=nb,
+                          step_ms=sum(e[1].elapsed_time(e[2]) for e in evs) / nb,
+                          exchange_ms=sum(e[0].elapsed_time(e[1]) for e in evs) / nb)
         return self.finish_targeted(ctx, merge_outputs)
 
     def gather_full_layers(self):
