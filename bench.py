@@ -730,13 +730,12 @@ def main():
         o_pos = torch.zeros((n_max, NG_), dtype=torch.float32, device=dev)
         o_neg = torch.zeros((n_max, NG_), dtype=torch.float32, device=dev)
         single_sched = runner.G == 1 and runner.single_rank_pipeline          # (a forced one-rank run: the module's own schedules)
+        runner.reserve_stream(n_max, Bg_)
         if single_sched:
-            rp_.reserve_stream(n_max, Bg_)
             rp_._eng["ws"].zero_()
             ws_b = rp_._eng["ws"].numel()
             will_window = bool(lib_.tpnet_stream_schedule(rp_.node_num, d_, L, k_steps * Bg_, Bg_, 0, ws_b) == 1)
         else:
-            rp_._workspace(n_max, Bg_)
             will_window = False
 
         def run(a, b_, timing=None):
@@ -750,7 +749,14 @@ def main():
                               out_pos=o_pos[:n_], out_neg=o_neg[:n_], timing=timing)
         nonlocal warm_windowed
         warm_windowed = will_window
-        el = time_leg(run, k_steps)
+        # (as on the single-GPU path: a short region is measured five times in this process, each from a reset table, and the
+        # figure is the median; the first region -- the second call of its shape in the process: 1.5-3x slower -- stays beside it)
+        regs = []
+        for r_ in range(5 if k_steps <= 64 else 1):
+            if r_ > 0:
+                rp_.reset_random_projections()
+            regs.append(time_leg(run, k_steps))
+        el = float(np.median(regs))
         warm_windowed = False
         runner.check_device_errors()
         tb = runner.table_bytes()
@@ -790,6 +796,7 @@ def main():
                                          "bytes_sent_per_step": rows_s * row_b, "bytes_received_per_step": rows_r * row_b,
                                          "bytes_per_step_per_peer": (rows_s * row_b / (world - 1)) if world > 1 else 0.0,
                                          "row_bytes": row_b, "transport": ("rccl (C loop)" if (R_ is not None and backend == "nccl") else backend)}}
+        info["regions"] = {"n": len(regs), "value_is": "median", "wall_us": [x * 1e6 for x in regs]}
         runner.close()
         del o_pos, o_neg
         return el, tb, info
@@ -885,6 +892,7 @@ def main():
             line["col_sharded"] = row_info
         if shard == "rows":
             line["config"]["table_bytes_per_gpu"] = row_bytes
+            line["timed_regions"] = rows_info.get("regions")
         if dropin is not None:
             line["dropin"] = dropin
         if shard == "single" and len(regions) > 1:
@@ -1108,7 +1116,7 @@ def main():
                                                "nodes": N4, "dim": c4["d"], "batch": Bg4, "batch_per_gpu": B4,
                                                "rows_per_gpu": (N4 + world - 1) // world, "halo_rows": 3 * Bg4,
                                                "table_bytes_per_gpu": tb4},
-                                    "roofline": info4.get("roof")}
+                                    "roofline": info4.get("roof"), "timed_regions": info4.get("regions")}
                 del arrs4
             except Exception as ex:               # noqa: BLE001 -- a secondary leg must not cost the main line
                 extra["c4_rows"] = {"error": f"{type(ex).__name__}: {ex}"[:400]}

@@ -9,6 +9,11 @@ from tpnet_amd.sharded import ShardedStreamRunner
 from tpnet_amd.stream import CONFIGS, synthetic_stream, synthetic_negatives
 
 cfg = CONFIGS["C2"]; B = cfg["B"]; nbt = 20; W = 5
+DIST = os.environ.get("PROBE_DIST") == "1"        # with a one-rank RCCL process group and a barrier in front of every call, as bench.py's forced run
+if DIST:
+    import torch.distributed as dist
+    os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
 src, dst, t, N = synthetic_stream(cfg["U"], cfg["I"], (W + nbt) * 40 * B, cfg["span"] * 0.3, seed=0)
 neg = synthetic_negatives(cfg["U"], N, len(src), B)
 dev = torch.device("cuda:0")
@@ -24,6 +29,8 @@ def call(k):
     a = k * nbt * B
     sl = slice(a, a + nbt * B)
     tl = t[np.arange(1, nbt + 1) * B + a - 1]
+    if DIST:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     r.run_stream(D[0][sl], D[1][sl], D[2][sl], D[3][sl], B, t_host_last=tl, merge_outputs=False, out_pos=op, out_neg=on)

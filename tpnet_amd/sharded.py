@@ -436,6 +436,39 @@ class ShardedStreamRunner:
             self.__dict__["_pin"] = pin
         return pin
 
+    def _small_scratch(self, nb, E, have_neg, dev, cap):
+        """Scratch of one exchange plan of the workgroup-per-batch kernel, kept across calls and only ever grown (torch.empty per call
+        was five allocations -- and a call longer than the ones before it paid them inside its timed region)."""
+        G = self.G
+        sc = self.__dict__.get("_xplan_scratch")
+        if sc is None or sc["dev"] != dev or sc["nb"] < nb or sc["E"] < E or sc["G"] != G or (have_neg and sc["lneg"] is None):
+            nb_, E_ = max(nb, sc["nb"] if sc else 0), max(E, sc["E"] if sc else 0)
+            sc = dict(dev=dev, nb=nb_, E=E_, G=G, recv_keys=torch.empty((nb_, cap), dtype=torch.int32, device=dev),
+                      pack_ids=torch.empty((nb_, cap), dtype=torch.int64, device=dev),
+                      tail=torch.empty(nb_ * 2 * G + 1, dtype=torch.int64, device=dev),
+                      lsrc=torch.empty(E_, dtype=torch.int64, device=dev), ldst=torch.empty(E_, dtype=torch.int64, device=dev),
+                      lneg=torch.empty(E_, dtype=torch.int64, device=dev) if (have_neg or (sc and sc["lneg"] is not None)) else None)
+            self.__dict__["_xplan_scratch"] = sc
+        return sc
+
+    def reserve_stream(self, max_edges: int, batch_size: int, have_neg: bool = True):
+        """Size the runner's scratch (exchange plan, read-back buffer) and the module's workspace for run_stream calls of up to
+        max_edges edges in batches of batch_size now, so that the first call of that size allocates nothing."""
+        rp = self.rp
+        rp._ensure_engine()
+        E, B = int(max_edges), int(batch_size)
+        nb = (E + B - 1) // B
+        dev = rp._dev()
+        lib = _lib.load()
+        cap = int(lib.tpnet_xplan_capacity())
+        if not self.xplan_force_large and 3 * B <= 4 * cap:
+            self._small_scratch(nb, E, have_neg, dev, cap)
+        self._pinned(nb * 2 * self.G + 1)
+        if self.G == 1 and self.single_rank_pipeline and not rp.exact:
+            rp.reserve_stream(E, B)
+        else:
+            rp._workspace(E, B, keep_plan=True)
+
     def _check_pending_status(self):
         """The status words of a one-rank exchange plan whose read-back was left in flight (relabel_targeted_device, G = 1)."""
         ps = self.__dict__.pop("_pending_status", None)
@@ -494,17 +527,7 @@ class ShardedStreamRunner:
         # overflowed after all -- ONE device-wide sort of the call's keys (tpnet_xplan_targeted_large)
         small = not self.xplan_force_large and 3 * B <= 4 * cap
         if small:
-            # scratch of one plan, kept across calls and only ever grown (torch.empty per call was five allocations -- and a call
-            # longer than the ones before it paid them inside its timed region)
-            sc = self.__dict__.get("_xplan_scratch")
-            if sc is None or sc["dev"] != dev or sc["nb"] < nb or sc["E"] < E or sc["G"] != G or (neg is not None and sc["lneg"] is None):
-                nb_, E_ = max(nb, sc["nb"] if sc else 0), max(E, sc["E"] if sc else 0)
-                sc = dict(dev=dev, nb=nb_, E=E_, G=G, recv_keys=torch.empty((nb_, cap), dtype=torch.int32, device=dev),
-                          pack_ids=torch.empty((nb_, cap), dtype=torch.int64, device=dev),
-                          tail=torch.empty(nb_ * 2 * G + 1, dtype=torch.int64, device=dev),
-                          lsrc=torch.empty(E_, dtype=torch.int64, device=dev), ldst=torch.empty(E_, dtype=torch.int64, device=dev),
-                          lneg=torch.empty(E_, dtype=torch.int64, device=dev) if neg is not None else None)
-                self.__dict__["_xplan_scratch"] = sc
+            sc = self._small_scratch(nb, E, neg is not None, dev, cap)
             recv_keys, pack_ids, tail = sc["recv_keys"], sc["pack_ids"], sc["tail"][:n_tail]
             lsrc, ldst, lneg = sc["lsrc"][:E], sc["ldst"][:E], (sc["lneg"][:E] if neg is not None else None)
             cnt, status = tail[: nb * 2 * G], tail[nb * 2 * G:]
