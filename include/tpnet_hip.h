@@ -42,7 +42,7 @@ extern "C" {
                                     cores), TPNET_FLAG_NO_MFMA_READOUT, tpnet_rows_stream_targeted, tpnet_mlp64_bwd_f32, tpnet_host_anchored_features;
                                     tpnet_run_stream_tagged replays streams of up to 64 chunks;
                                7: + tpnet_stream_schedule (which schedule tpnet_run_stream would take); tpnet_xplan_targeted serves G = 1;
-                                    tpnet_xplan_targeted_large (batches beyond one workgroup's lists);
+                                    tpnet_xplan_targeted_large (batches beyond one workgroup's lists); tpnet_wshard_* (a row shard on the windowed pipeline);
                                     the side-by-side plans of a multi-chunk stream are bounded (TPNET_ARENA_MAX_RATIO) */
 #define TPNET_MAX_LAYERS 4 /* num_layer L in 1..4 (reference default 3, utils/load_configs.py:70) */
 
@@ -430,6 +430,39 @@ int tpnet_xplan_targeted_large(const int64_t* src, const int64_t* dst, const int
                                int32_t G, int32_t me, int32_t n_owned, void* scratch, size_t scratch_bytes, int64_t* pack_ids,
                                int64_t* cnt, uint32_t* status, int64_t* local_src, int64_t* local_dst, int64_t* local_neg,
                                void* stream);
+
+/* ---- a row shard on the WINDOWED pipeline (ABI 7; csrc/wshard.hip) -------------------------------------------
+ * The per-batch shard above exchanges rows and launches a kernel per batch.  Here one chunk of the stream (the whole call) runs as
+ * the software pipeline of tpnet_run_stream's windowed schedule -- one launch per window of batches -- and the ranks meet once per
+ * launch: every node the chunk touches gets ONE halo row for the whole chunk (filled at its start with the owner's pre-chunk row),
+ * every rank plans from the whole stream and derives, without a request round, which of its runs' results another rank reads; after
+ * each launch those rows are packed, exchanged with ONE grouped ncclSend / ncclRecv, and unpacked into the version log.  A log slot
+ * travels bit for bit: G shards compute what one GPU computes on the windowed schedule.
+ *   st: the rank's LOCAL table (n_owned rows + halo rows: tpnet_state::N = n_owned + halo capacity); src / dst / neg: GLOBAL ids.
+ *   tpnet_wshard_plan returns TPNET_OK and *out, or 1 = this call is not served (batches beyond 8 192 edges, fewer than 4 batches,
+ *   more remote nodes in the chunk than halo rows, a table too large for the dense planner, exact / packed modes ...): the caller
+ *   takes tpnet_rows_stream_targeted.  It synchronises `stream` twice (halo counts, message counts).  A tpnet_wshard is a HOST object
+ *   (counts and views into the caller's workspace; the second thing besides tpnet_stage this library allocates); device memory is
+ *   the caller's: workspace (tpnet_wshard_workspace_bytes) and the exchange buffers (tpnet_wshard_info -> tpnet_wshard_set_buffers).
+ *   phases of begin / step (bit mask): 1 = launch the pipeline step, 2 = pack, 4 = exchange over `comm` (tpnet_rccl_comm_create),
+ *   8 = unpack; a caller with another transport runs 2, moves the rows itself (sendbuf rows [sum of send_cnt[j][:r], +send_cnt[j][r])
+ *   go to peer r's recvbuf rows [sum of ITS recv_cnt[j][:me], ...); the chunk's halo rows: send_p0 / send_q of owner o to halo rows
+ *   [n_owned + hstart(o), ...) of p0 and of copy 0 of q, hstart(o) = sum of chunk_cnt[o'] over o' < o, o' != me), then 8. */
+typedef struct tpnet_wshard tpnet_wshard;
+size_t tpnet_wshard_workspace_bytes(int64_t n_local, int32_t d, int32_t L, int64_t E, int64_t batch, int32_t G, int32_t n_owned);
+int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
+                      int64_t batch, int64_t N_global, int32_t G, int32_t me, int32_t n_owned, double now_time, double lambda,
+                      uint32_t flags, int32_t want_pos, int32_t want_neg, void* workspace, size_t ws_bytes, void* stream,
+                      tpnet_wshard** out);
+int tpnet_wshard_info(const tpnet_wshard* w, int64_t* n_steps, int64_t* halo_rows, int64_t* max_send_rows, int64_t* max_recv_rows,
+                      const int64_t** chunk_cnt, const int64_t** send_cnt, const int64_t** recv_cnt);
+int tpnet_wshard_set_buffers(tpnet_wshard* w, float* send_p0, float* send_q, float* sendbuf, float* recvbuf);
+int tpnet_wshard_begin(tpnet_wshard* w, void* comm, uint32_t phases, void* stream);
+int tpnet_wshard_step(tpnet_wshard* w, void* comm, int64_t j, uint32_t phases, float* out_pos, float* out_neg, void* stream);
+int tpnet_wshard_finish(tpnet_wshard* w, uint32_t launch_id, void* stream);
+/* begin + every step + finish in one call (comm may be NULL with one rank) */
+int tpnet_wshard_run(tpnet_wshard* w, void* comm, float* out_pos, float* out_neg, uint32_t launch_id, void* stream);
+void tpnet_wshard_destroy(tpnet_wshard* w);
 
 /* ---- the step in front of the path: 'recent' historical-neighbour sampling on the device ----------
  * Replaces NeighborSampler('recent') + get_neighbor_sampler (utils/utils.py:82-224, 293-312): undirected adjacency,

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""TEST DRIVER (run in a process of its own by tests/test_sharded.py::test_windowed_shard_*): G row shards of one table in ONE
+process on one GPU on the WINDOWED pipeline (csrc/wshard.hip).  Transports: "copy" = pack launches, plain copies between the
+shards' buffers, unpack launches (the phases of tpnet_wshard_begin / tpnet_wshard_step one by one); "loopback" = every shard a host
+thread with its own stream, tpnet_wshard_run with a communicator of the in-process RCCL stand-in (tests/loopback/
+librccl_loopback.so).  Checks: the shards' features and tables equal the SINGLE-GPU run on the windowed schedule BIT FOR BIT (a log
+slot travels as it is; the table starts from a reset, so the chunk's halo rows need no decay), and the two transports equal each
+other.  Prints 'WSHARD OK ...' or raises."""
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import tpnet_amd                                           # noqa: E402
+from tpnet_amd import _lib                                 # noqa: E402
+from tpnet_amd.sharded import ShardedStreamRunner          # noqa: E402
+
+PH_LAUNCH, PH_PACK, PH_EXCHANGE, PH_UNPACK = 1, 2, 4, 8
+
+
+def stream_of(seed, N, E, hubs=True):
+    rng = np.random.RandomState(seed)
+    src = rng.randint(1, N, E).astype(np.int64)
+    dst = rng.randint(1, N, E).astype(np.int64)
+    if hubs:
+        src[rng.rand(E) < 0.15] = 3                        # hubs: long chains, rows every window sends both ways
+        dst[rng.rand(E) < 0.10] = 4
+        dst[rng.rand(E) < 0.05] = 3
+    neg = rng.randint(0, N, E).astype(np.int64)
+    t = np.sort(rng.uniform(0.0, 4.0e5, E))
+    return src, dst, neg, t
+
+
+def make_shards(G, N, d, L, E, B, lam, t0, P0, dev, halo):
+    out = []
+    for r in range(G):
+        run = ShardedStreamRunner.create(node_num=N, edge_num=E, dim=d, num_layer=L, time_decay_weight=lam, device=dev,
+                                         beginning_time=np.float64(t0), halo_rows=halo, seed=r, world=G, rank=r)
+        run.set_full_p0(P0)
+        out.append(run)
+    return out
+
+
+def full_layers(runs, N, L, d):
+    dev = runs[0].rp._dev()
+    G = len(runs)
+    full = torch.empty((L + 1, N, d), dtype=torch.float32, device=dev)
+    for r, run in enumerate(runs):
+        rows = torch.stack(run.rp.get_random_projections(torch.arange(run.n_cap, dtype=torch.int64, device=dev)))
+        n_own = (N - r + G - 1) // G
+        full[:, r::G] = rows[:, :n_own]
+    return full
+
+
+def run_copy(runs, D, B, lib):
+    """All shards in one thread, the rows moved by plain copies."""
+    G = len(runs)
+    ds, dd, dn, dt = D
+    plans = [runs[r].plan_windowed(ds, dd, dn, dt, B) for r in range(G)]
+    assert all(p is not None for p in plans), "the windowed shard declined"
+    E = plans[0]["E"]
+    outs = []
+    for r in range(G):
+        outs.append((torch.zeros((E, 64 if runs[r].rp.num_layer == 3 else (2 * runs[r].rp.num_layer + 2) ** 2), device=ds.device),
+                     torch.zeros((E, 64 if runs[r].rp.num_layer == 3 else (2 * runs[r].rp.num_layer + 2) ** 2), device=ds.device)))
+    L, d = runs[0].rp.num_layer, runs[0].rp.dim
+    for r in range(G):
+        _lib.check(lib.tpnet_wshard_begin(plans[r]["handle"], None, PH_PACK, runs[r].rp._stream()), "begin")
+    for r in range(G):                                     # shard r's halo rows <- every owner's packed rows
+        rp = runs[r].rp
+        p0_t = rp._plist()[0].data
+        q_t = rp._eng["q"].view(2, rp.node_num, L * d)
+        for o in range(G):
+            c = int(plans[r]["chunk_cnt"][o])
+            assert c == int(plans[o]["chunk_cnt"][o])
+            if o != r and c:
+                a0 = runs[r].n_cap + int(plans[r]["hstart"][o])
+                p0_t[a0:a0 + c].copy_(plans[o]["bufs"]["send_p0"][:c])
+                q_t[0, a0:a0 + c].copy_(plans[o]["bufs"]["send_q"][:c])
+    moved = 0
+    for j in range(plans[0]["nsteps"]):
+        for r in range(G):
+            _lib.check(lib.tpnet_wshard_step(plans[r]["handle"], None, j, PH_LAUNCH | PH_PACK, outs[r][0].data_ptr(), outs[r][1].data_ptr(),
+                                             runs[r].rp._stream()), "step")
+        for r in range(G):
+            ro = 0
+            for o in range(G):
+                c = int(plans[r]["recv_cnt"][j][o])
+                assert c == int(plans[o]["send_cnt"][j][r]), (j, r, o, c, int(plans[o]["send_cnt"][j][r]))
+                if c:
+                    a0 = int(plans[o]["send_cnt"][j][:r].sum())
+                    plans[r]["bufs"]["recvbuf"][ro:ro + c].copy_(plans[o]["bufs"]["sendbuf"][a0:a0 + c])
+                    moved += c
+                ro += c
+        for r in range(G):
+            _lib.check(lib.tpnet_wshard_step(plans[r]["handle"], None, j, PH_UNPACK, outs[r][0].data_ptr(), outs[r][1].data_ptr(),
+                                             runs[r].rp._stream()), "step")
+    for r in range(G):
+        _lib.check(lib.tpnet_wshard_finish(plans[r]["handle"], runs[r].rp._next_launch_ids(1), runs[r].rp._stream()), "finish")
+        lib.tpnet_wshard_destroy(plans[r]["handle"])
+        rp = runs[r].rp
+        rp._now_host = float(dt[-1].item()); rp._params_valid = False; rp._now_dirty = True; rp._table_written()
+    torch.cuda.synchronize()
+    return outs, moved, plans[0]["nsteps"]
+
+
+def run_loopback(runs, D, B, lib, so):
+    G = len(runs)
+    ds, dd, dn, dt = D
+    idbuf = (C.c_ubyte * 128)()
+    assert lib.tpnet_rccl_unique_id(so, idbuf) == 0
+    comms = []
+    for r in range(G):
+        h = C.c_void_p()
+        assert lib.tpnet_rccl_comm_create(so, idbuf, G, r, C.byref(h)) == 0
+        comms.append(h)
+    dev = ds.device
+    streams = [torch.cuda.Stream(dev) for _ in range(G)]
+    torch.cuda.synchronize()
+    res, failed = [None] * G, []
+
+    def rank_thread(r):
+        try:
+            with torch.cuda.stream(streams[r]):
+                res[r] = runs[r].run_stream_windowed(ds, dd, dn, dt, B, merge_outputs=False, comm=comms[r])
+        except Exception as ex:            # noqa: BLE001
+            failed.append((r, repr(ex)))
+    ths = [threading.Thread(target=rank_thread, args=(r,)) for r in range(G)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=180)
+    assert not failed and not any(th.is_alive() for th in ths), failed
+    torch.cuda.synchronize()
+    for r in range(G):
+        assert res[r] is not None, "the windowed shard declined"
+        assert lib.tpnet_rccl_comm_destroy(comms[r]) == 0
+    return res
+
+
+def main():
+    cfgs = [(2, 211, 128, 3, 2000, 100, 2e-6), (3, 150, 64, 2, 1333, 50, 1e-6), (2, 3000, 128, 3, 1500, 60, 2e-6),
+            (4, 400, 256, 3, 1700, 100, 1e-6), (2, 9228, 128, 3, 20 * 2000, 2000, 1e-6)]
+    if os.environ.get("TPNET_WSHARD_ONE"):
+        cfgs = cfgs[:1]
+    lib = _lib.load()
+    so = os.path.join(HERE, "librccl_loopback.so").encode()
+    dev = torch.device("cuda:0")
+    Dv = lambda x: torch.from_numpy(x).to(dev)
+    summary = []
+    for ci, (G, N, d, L, E, B, lam) in enumerate(cfgs):
+        src, dst, neg, t = stream_of(11 + ci, N, E)
+        P0 = torch.from_numpy((np.random.RandomState(77).randn(N, d) / np.sqrt(d)).astype(np.float32))
+        D = tuple(Dv(x) for x in (src, dst, neg, t))
+        halo = N                                               # (every remote node of the chunk gets a halo row)
+        # ---- the single-GPU run on the windowed schedule
+        ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L, time_decay_weight=lam,
+                                               device="cuda:0", use_matrix=False, beginning_time=np.float64(t[0]),
+                                               not_scale=False, enforce_dim=d)
+        ref.random_projections[0].data = P0.clone()
+        ref = ref.to(dev)
+        rfp, rfn = ref.run_stream(*D, B, schedule="windowed")
+        rl = torch.stack([ref.random_projections[i].detach() for i in range(0, L + 1)])
+        # ---- (A) plain copies
+        runs = make_shards(G, N, d, L, E, B, lam, t[0], P0, dev, halo)
+        outs, moved, nsteps = run_copy(runs, D, B, lib)
+        fpA = sum(o[0] for o in outs)
+        fnA = sum(o[1] for o in outs)
+        layA = full_layers(runs, N, L, d)
+        for r in range(G):
+            runs[r].rp.check_device_errors()
+        bad_f = int((fpA != rfp).sum()) + int((fnA != rfn).sum())
+        bad_s = int((layA != rl).sum())
+        assert bad_f == 0 and bad_s == 0, (f"config {ci}: {bad_f} feature values and {bad_s} table values differ from the single-GPU run "
+                                           f"(max {float((fpA - rfp).abs().max()):.3e} / {float((layA - rl).abs().max()):.3e})")
+        # ---- (B) the RCCL stand-in, one thread per shard, tpnet_wshard_run
+        runs_b = make_shards(G, N, d, L, E, B, lam, t[0], P0, dev, halo)
+        res = run_loopback(runs_b, D, B, lib, so)
+        fpB = sum(o[0] for o in res)
+        fnB = sum(o[1] for o in res)
+        layB = full_layers(runs_b, N, L, d)
+        assert torch.equal(fpB, rfp) and torch.equal(fnB, rfn) and torch.equal(layB, rl), f"config {ci}: the loopback transport differs"
+        assert float(runs_b[0].rp.now_time.item()) == float(t[-1])
+        summary.append((G, N, d, L, (E + B - 1) // B, nsteps, moved))
+    print("WSHARD OK " + "; ".join(f"G={g} N={n} d={d} L={l} batches={nb}: {ns} launches per shard, {mv} rows moved"
+                                   for g, n, d, l, nb, ns, mv in summary))
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,17 @@ SIGNATURES = {
     "tpnet_xplan_large_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "tpnet_xplan_targeted_large": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_size_t,
                                              _P, _P, _P, _P, _P, _P, _P]),
+    "tpnet_wshard_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tpnet_wshard_plan": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                    C.c_double, C.c_uint32, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.POINTER(_P)]),
+    "tpnet_wshard_info": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                    C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.POINTER(C.c_int64))]),
+    "tpnet_wshard_set_buffers": (C.c_int, [_P, _P, _P, _P, _P]),
+    "tpnet_wshard_begin": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "tpnet_wshard_step": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, _P, _P, _P]),
+    "tpnet_wshard_finish": (C.c_int, [_P, C.c_uint32, _P]),
+    "tpnet_wshard_run": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P]),
+    "tpnet_wshard_destroy": (None, [_P]),
     "tpnet_host_encoder_features": (C.c_int, [_SP, _P, _P, C.c_int64, C.c_int64, _P, _P, _P, C.c_int64, C.c_int32, C.c_double,
                                               C.c_double, C.c_uint32, C.POINTER(Mlp), _P, C.c_size_t, _P, _P, _P]),
 }

@@ -986,8 +986,17 @@ size_t wplan_log_bytes(int64_t max_edges, int d, int L) {
 
 // `shared_log` (may be null): the version log lives there instead of inside [ws, ws + ws_bytes) -- the plans of the chunks of a
 // multi-chunk stream each keep a region of their own (so that every one of them can be replayed, api.hip) and share ONE log
-int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out, float* shared_log) {
-    if (K < 1 || K > WIN_MAX_BATCHES || K > wplan_window_batches(batch, d, L)) return TPNET_ERR_BAD_ARG;
+// (the plan of a row shard's chunk, wshard.hip: global batches beyond 4096 edges, of which a rank computes its share -- the window
+// length is chosen there)
+size_t wplan_bytes_shard(int64_t max_edges, int64_t batch, int64_t N, int d, int L) {
+    if (max_edges < 1) max_edges = 1;
+    if (batch < 1) batch = 1;
+    return plan_bytes(max_edges, batch) + wplan_extra_bytes(max_edges, batch, N, d, L, 2);
+}
+
+int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out, float* shared_log,
+                bool shard) {
+    if (K < 1 || K > WIN_MAX_BATCHES || (!shard && K > wplan_window_batches(batch, d, L))) return TPNET_ERR_BAD_ARG;
     if (Ec > wplan_max_chunk_edges(batch, d, L)) return TPNET_ERR_BAD_ARG;
     int rc = plan_carve(ws, ws_bytes, Ec, batch, &out->base);
     if (rc) return rc;

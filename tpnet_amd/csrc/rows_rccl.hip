@@ -55,6 +55,22 @@ static int rccl_load(const char* lib_path) {
     return TPNET_OK;
 }
 
+// wshard.hip calls the exchange through the same entry points (false until a communicator has been created here)
+struct WsRccl {
+    int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+};
+bool rows_rccl_api(WsRccl* out) {
+    if (!g_rccl.handle || !out) return false;
+    out->send = g_rccl.send;
+    out->recv = g_rccl.recv;
+    out->group_start = g_rccl.group_start;
+    out->group_end = g_rccl.group_end;
+    return true;
+}
+
 }  // namespace tpnet
 
 using namespace tpnet;

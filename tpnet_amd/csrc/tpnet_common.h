@@ -304,7 +304,8 @@ size_t wplan_bytes(int64_t max_edges, int64_t batch, int64_t N, int d, int L);
 int wplan_window_batches(int64_t batch, int d, int L);                 // 0 = the windowed path does not apply
 int64_t wplan_max_chunk_edges(int64_t batch, int d, int L);            // edges one plan (and its log) may cover
 int wplan_carve(void* ws, size_t ws_bytes, int64_t Ec, int64_t batch, int64_t N, int d, int L, int K, WPlan* out,
-                float* shared_log = nullptr);   // K <= wplan_window_batches; shared_log: the version log lives outside the region
+                float* shared_log = nullptr, bool shard = false);   // K <= wplan_window_batches (shard: chosen by the caller); shared_log: the version log lives outside the region
+size_t wplan_bytes_shard(int64_t max_edges, int64_t batch, int64_t N, int d, int L);   // workspace of a row shard's chunk (wshard.hip)
 size_t wplan_log_bytes(int64_t max_edges, int d, int L);       // the version log's share of wplan_bytes
 int wplan_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                 const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
@@ -323,10 +324,16 @@ int wplan3_build(const tpnet_state& st, const WPlan& p, const int64_t* src, cons
 bool wplan_dense_eligible(int64_t N, int d, int L, int64_t batch);
 size_t wplan_dense_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int L);          // 0: not eligible
 bool wplan_dense_applies(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, int K);
+// own (row shard, wshard.hip; -1: everything): the stream holds LOCAL ids, rows < own are this rank's, the rows behind them halo
+// rows of other ranks' nodes -- only contributions to owned targets are planned (a halo node's run is ONE log slot, filled by the
+// exchange), only owned nodes are written back; status (shard): [0] += batches whose owned contributions exceeded the sort
 int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                       const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
-                      bool want_readout, bool replay, hipStream_t s);
-bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s);
+                      bool want_readout, bool replay, hipStream_t s, int64_t own = -1, uint32_t* status = nullptr);
+bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s,
+                           int64_t own = -1);
+bool wplan_dense_applies_shard(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, int K);
+
 uint32_t wplan_heavy_threshold(int K, int64_t batch, int d);
 bool wplan_medium_chains(int d);          // rows that are exactly one chunk of their geometry: chain_medium serves (wstep.hip)
 // pipeline step j of a chunk of nw windows: layer i of window j-i+1 (i = 1..L) and the readout of window j-L, whichever

@@ -20,36 +20,14 @@
 // acquire of the XCD's L2 cost 4-5 us against ~1.7 us for a kernel boundary, and every phase ran on the sort's few workgroups.)
 // Same WPlan contents as the sorted planner up to the order of the chains inside a length class; the arithmetic of every run is
 // identical, so all three planners give bit-identical results (tests/test_gpu_parity.py::test_three_launch_planner_equals_chunk_planner).
-#include "wplan_common.hpp"
+#include "wplan_dense.hpp"
 
 namespace tpnet {
 
-static constexpr int DCH = 256;                     // nodes per chunk = threads per workgroup of every kernel but the sort
-static constexpr int DENSE_MAX_WINDOWS = 256;       // (window, class) counters live in LDS: 8 KB
-static constexpr int DENSE_TL = 512;
-static constexpr int DENSE_MAX_CHUNKS = 2048;       // chunks of 256 nodes (a thread per node in phase B): N <= 524 288
-
-struct DView {                 // the dense planner's arrays (WPlan::dense, carved by wplan_carve)
-    uint16_t* len;             // [nb][Ns]
-    uint2* m;                  // [nb][Ns] {pre, len | prevb << 16}; prevb = 0xFFFF: no run before batch b
-    uint32_t* crank;           // [nw][Ns] B1: rank of the chain (n, w) among the chains of its (chunk of nodes, window, class)
-    uint2* wsl;                // [nw][Ns] B1a: {contributions of n in window w, batch of its last run there (0xFFFF: none)}
-    uint32_t* tot;             // [Ns] contributions of node n in the chunk
-    uint32_t* lastb;           // [Ns] batch of its last run (0xFFFF: none)
-    uint32_t* base;            // [Ns] B1: exclusive prefix of tot inside the node's chunk of BS nodes
-    uint32_t* basef;           // [Ns] C: first position of node n (base + the chunk's base): what the write-back and a replay read
-    uint32_t* ctot;            // [nchunks] B1: contributions per chunk of nodes
-    uint32_t* ccnt;            // [nchunks][nw * 8] B1: chains per (chunk, window, class)
-    uint32_t* cpre;            // [nchunks][nw * 8] B2: the same, summed over the earlier chunks
-    uint32_t* ptot;            // [nw * 8] B2: chains per (window, class)
-    int64_t Ns;                // row stride (N rounded up to 64)
-};
-
-static inline int64_t dense_ns(int64_t N) { return (N + 63) / 64 * 64; }
-
+static constexpr int64_t DENSE_SHARD_MAX_BATCH = 8192;     // a row shard's global batch (wshard.hip): 16 contributions per thread of its sort
 bool wplan_dense_eligible(int64_t N, int d, int L, int64_t batch) {
     static const int off = TPNET_DEV_INT(NO_PLAN_DENSE, 0);
-    if (off || batch < 1 || batch > PLAN_ONE_MAX || N > (int64_t)DENSE_MAX_CHUNKS * 256) return false;
+    if (off || batch < 1 || batch > DENSE_SHARD_MAX_BATCH || N > (int64_t)DENSE_MAX_CHUNKS * 256) return false;
     return (int64_t)N * 12 <= batch * (int64_t)L * d * 4;     // half the version-log bytes of one batch
 }
 
@@ -65,73 +43,6 @@ size_t wplan_dense_bytes(int64_t Ec, int64_t batch, int64_t N, int d, int L) {
            2 * al(nchunks * nw * 8 * 4) + al(nw * 8 * 4) + 256;
 }
 
-static DView dview_of(const WPlan& p, int64_t Ec, int64_t batch, int64_t N) {
-    DView v;
-    const size_t nb = (size_t)((Ec + batch - 1) / batch);
-    const size_t Ns = (size_t)dense_ns(N);
-    size_t nw = (nb + 1) / 2 + 1;
-    if (nw > (size_t)DENSE_MAX_WINDOWS) nw = DENSE_MAX_WINDOWS;
-    const size_t nchunks = (Ns + 255) / 256;
-    char* c = reinterpret_cast<char*>(p.dense);
-    auto take = [&](size_t bytes) { void* r = c; c += (bytes + 255) / 256 * 256; return r; };
-    v.len = (uint16_t*)take(nb * Ns * 2);
-    v.m = (uint2*)take(nb * Ns * 8);
-    v.crank = (uint32_t*)take(nw * Ns * 4);
-    v.wsl = (uint2*)take(nw * Ns * 8);
-    v.tot = (uint32_t*)take(Ns * 4);
-    v.lastb = (uint32_t*)take(Ns * 4);
-    v.base = (uint32_t*)take(Ns * 4);
-    v.basef = (uint32_t*)take(Ns * 4);
-    v.ctot = (uint32_t*)take(nchunks * 4);
-    v.ccnt = (uint32_t*)take(nchunks * nw * 8 * 4);
-    v.cpre = (uint32_t*)take(nchunks * nw * 8 * 4);
-    v.ptot = (uint32_t*)take(nw * 8 * 4);
-    v.Ns = (int64_t)Ns;
-    return v;
-}
-
-// exclusive scan of one value per thread over the workgroup (wave shuffles + one LDS word per wave); total = the sum
-template <int BS>
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* [BS / 64] */, uint32_t& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)inc, o, 64);
-        if (lane >= o) inc += u;
-    }
-    __syncthreads();                                        // (wsum may still be read from an earlier scan)
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < BS / 64; ++i) {
-        const uint32_t s = wsum[i];
-        if (i < wave) base += s;
-        tot += s;
-    }
-    total = tot;
-    return base + inc - v;
-}
-
-struct DVRef { uint32_t ref; double t_src; };
-
-// the version of node v before batch b, given m[b][v] (and, speculatively loaded, base[v] and the node's meta record)
-// (tl: the batches' closing clocks staged in LDS by the caller's workgroup, or nullptr -> read from the descriptors)
-__device__ __forceinline__ DVRef dense_version(const BatchDesc* __restrict__ desc, const double* tl, uint2 m, uint32_t basev,
-                                               uint4 m0, uint4 m1) {
-    DVRef r;
-    if (m.x > 0u) {
-        r.ref = basev + m.x - 1u;                           // the tail of its previous run
-        r.t_src = tl ? tl[m.y >> 16] : desc[m.y >> 16].t_last;
-    } else {
-        const uint32_t c = m0.x & 1u;
-        r.ref = WREF_TABLE | c;
-        r.t_src = c ? __hiloint2double((int)m1.y, (int)m1.x) : __hiloint2double((int)m0.w, (int)m0.z);
-    }
-    return r;
-}
-
 struct DArgs {
     const int64_t* src;
     const int64_t* dst;
@@ -143,6 +54,8 @@ struct DArgs {
     int64_t Ec, Bfull, N, nb, nw;
     double now_time, lambda;
     int32_t node_bits, L, nwhich /* 0: no readout, 2: src / dst, 3: + neg */, nchunks;
+    int64_t own;               // row shard: local ids < own are this rank's rows (= N: everything)
+    uint32_t* status;          // row shard: [0] batches whose owned contributions exceeded the sort's capacity
 };
 
 // phase C, contributions: batch-sorted position x
@@ -226,18 +139,21 @@ __device__ __forceinline__ void dense_neg(const WPlan& p, const DView& D, const 
 }
 
 // the same inside phase C: the node's first position = its chunk's base (LDS) + its place in the chunk
+// (which = 2: the negative of edge e; which = 1, row shards only: its dst when another rank owns it -- no contribution of this rank
+// has that node as its target, so dense_place left the reference of the (src, dst) readout unwritten)
 __device__ __forceinline__ void dense_neg_c(const WPlan& p, const DView& D, const DArgs& a, const uint32_t* __restrict__ cbase,
-                                            const double* tl, int64_t e) {
+                                            const double* tl, int64_t e, int which = 2) {
     const BatchDesc* __restrict__ desc = p.base.desc;
-    int64_t node = a.neg[e];
+    int64_t node = which == 2 ? a.neg[e] : a.dst[e];
     if ((uint64_t)node >= (uint64_t)a.N) node = 0;
+    if (which == 1 && node < a.own) return;
     const int64_t b = e / a.Bfull;
     const uint2 m = D.m[b * D.Ns + node];
     const uint32_t bs = D.base[node] + cbase[(uint32_t)node / (uint32_t)DCH];
     const uint4 m0 = reinterpret_cast<const uint4*>(a.meta + node)[0], m1 = reinterpret_cast<const uint4*>(a.meta + node)[1];
     const DVRef r = dense_version(desc, tl, m, bs, m0, m1);
-    p.e_ref[2 * a.Ec + e] = r.ref;
-    p.e_g[2 * a.Ec + e] = decay3_f32(a.lambda, desc[b].now - r.t_src);
+    p.e_ref[(int64_t)which * a.Ec + e] = r.ref;
+    p.e_g[(int64_t)which * a.Ec + e] = decay3_f32(a.lambda, desc[b].now - r.t_src);
 }
 
 // ---- A: a workgroup per batch (wplan_common.hpp: wsort_batch): the batch's contributions sorted by target, its row of len
@@ -249,6 +165,155 @@ __global__ __launch_bounds__(BS) void k_dense_sort(WPlan p, WTmp q, DView D, DAr
                                a.t_prev, a.lambda, a.L, a.err, p.K, bb, D.len + bb * D.Ns);
 }
 
+
+// ---- A (row shard): the batch holds the edges of ALL ranks (local ids: rows < own are this rank's, the rows behind them halo rows
+// of other ranks' nodes); only the contributions to OWNED targets are sorted -- ~2 B / G of the batch's 2 B, so a global batch of up
+// to 8 192 edges fits the one-workgroup sort -- and a halo node that is a target in this batch gets len = 1: its run is ONE slot of
+// the version log, which the owner's result is received into (wshard.hip).  Order: thread t takes contributions [t C, (t + 1) C) of
+// the batch (src side first, then dst side, edge by edge: models/TPNet.py:93-96), the kept ones are compacted in that order (one
+// block scan) and the stable sort keeps it inside a target's run.  desc[b].n_light = kept contributions (k_dense_place skips the rest).
+template <int BS, int IPT>
+__global__ __launch_bounds__(BS) void k_dense_sort_shard(WPlan p, WTmp q, DView D, DArgs a) {
+    using Sort = rocprim::block_radix_sort<uint32_t, BS, IPT, uint32_t>;
+    constexpr int NC = BS * IPT;
+    constexpr int CMAX = 16;                               // contributions per thread before the compaction: 2 B <= 16 BS
+    __shared__ union U {
+        typename Sort::storage_type sort;
+        struct { uint32_t key[NC]; uint32_t ustart[NC]; } s;
+        struct { uint32_t ckey[NC]; uint32_t cval[NC]; } c;
+    } u;
+    __shared__ uint32_t wsum[BS / 64];
+    static_assert(sizeof(U) <= 60 * 1024, "k_dense_sort_shard: LDS budget");
+    const int64_t bb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t e0 = bb * a.Bfull;
+    const int32_t B = (int32_t)((a.Ec - e0 < a.Bfull) ? (a.Ec - e0) : a.Bfull);
+    const int64_t* __restrict__ src = a.src + e0;
+    const int64_t* __restrict__ dst = a.dst + e0;
+    const double* __restrict__ t = a.t + e0;
+    const int64_t g0 = 2 * e0;
+    uint16_t* __restrict__ lenrow = D.len + bb * D.Ns;
+    for (int64_t n = tid; n < a.N; n += BS) lenrow[n] = 0;
+    __syncthreads();
+    const double t_last = t[B - 1];
+    const int nall = 2 * B;
+    const int C = (nall + BS - 1) / BS;
+    uint32_t rk[CMAX];
+    uint32_t kept = 0;
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) {
+        rk[k] = 0xFFFFFFFFu;
+        const int j = tid * C + k;
+        if (k < C && j < nall) {
+            const bool side = j >= B;
+            const int e = side ? j - B : j;
+            const int64_t sv = src[e], dv = dst[e];
+            const bool ok = (uint64_t)sv < (uint64_t)a.N && (uint64_t)dv < (uint64_t)a.N;
+            if (!ok) {
+                if (!side) atomicAdd(a.err, 1u);             // once per bad edge (the shard's relabelling has rejected such ids already)
+            } else {
+                const int64_t tg = side ? dv : sv;
+                if (tg < a.own) { rk[k] = (uint32_t)tg; ++kept; }
+                else lenrow[tg] = 1;                         // a halo node is a target here: one slot (many writers, one value)
+            }
+        }
+    }
+    uint32_t total;
+    uint32_t off = block_excl_scan<BS>(kept, wsum, total);
+    if (total > (uint32_t)NC) {                              // (uniform) more owned contributions than the sort holds: the caller falls back
+        if (tid == 0 && a.status) atomicAdd(a.status, 1u);
+        total = NC;
+    }
+#pragma unroll
+    for (int k = 0; k < CMAX; ++k) {
+        if (rk[k] != 0xFFFFFFFFu) {
+            if (off < (uint32_t)NC) { u.c.ckey[off] = rk[k]; u.c.cval[off] = (uint32_t)(tid * C + k); }
+            ++off;
+        }
+    }
+    __syncthreads();
+    const int nc = (int)total;
+    uint32_t keys[IPT], vals[IPT];
+    const uint32_t pad_key = 1u << a.node_bits;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid * IPT + k;
+        keys[k] = j < nc ? u.c.ckey[j] : pad_key;
+        vals[k] = j < nc ? u.c.cval[j] : 0u;
+    }
+    __syncthreads();
+    Sort().sort(keys, vals, u.sort, 0u, (unsigned)(a.node_bits + 1));
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) u.s.key[tid * IPT + k] = keys[k];
+    __syncthreads();
+    uint32_t hcount = 0;
+    bool hd[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid * IPT + k;
+        hd[k] = j < nc && (j == 0 || u.s.key[j - 1] != keys[k]);
+        hcount += hd[k] ? 1u : 0u;
+        if (j < nc) {
+            const uint32_t val = vals[k];
+            const bool side = val >= (uint32_t)B;
+            const int e = side ? (int)val - B : (int)val;
+            const int64_t sv = src[e], dv = dst[e];
+            const float x = (float)t_last - (float)t[e];     // the reference's casts (models/TPNet.py:77-78), as wsort_batch
+            q.bkey[g0 + j] = keys[k];
+            q.bpart[g0 + j] = (int32_t)(side ? sv : dv);
+            q.bcoef[g0 + j] = expf((float)(-a.lambda) * x);
+            q.bval[g0 + j] = val;
+            q.binv[g0 + val] = (uint32_t)(g0 + j);
+        }
+    }
+    uint32_t htotal;
+    uint32_t rank = block_excl_scan<BS>(hcount, wsum, htotal);
+    uint32_t myrun[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        if (hd[k]) {
+            u.s.ustart[rank] = (uint32_t)(tid * IPT + k);
+            ++rank;
+        }
+        myrun[k] = rank - 1u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = tid * IPT + k;
+        if (j < nc) {
+            const uint32_t st = u.s.ustart[myrun[k]];
+            const uint32_t en = (myrun[k] + 1 < htotal) ? u.s.ustart[myrun[k] + 1] : (uint32_t)nc;
+            const uint32_t ri = (uint32_t)j - st;
+            const bool tail = (uint32_t)j + 1u == en;
+            uint32_t fl = 0;
+            if (ri == 0) fl |= WREF_RUN_HEAD;
+            if (tail) fl |= WREF_RUN_TAIL;
+            if (ri % WIN_BLOCK == 0) fl |= WREF_BLK_HEAD;
+            if (ri % WIN_BLOCK == WIN_BLOCK - 1 || tail) fl |= WREF_BLK_TAIL;
+            q.bri[g0 + j] = ri;
+            q.bflags[g0 + j] = fl;
+        }
+    }
+    for (uint32_t r = tid; r < htotal; r += BS) {
+        const uint32_t st = u.s.ustart[r];
+        const uint32_t en = (r + 1 < htotal) ? u.s.ustart[r + 1] : (uint32_t)nc;
+        lenrow[u.s.key[st]] = (uint16_t)(en - st);
+    }
+    if (tid == 0) {
+        BatchDesc Dd;
+        Dd.e0 = e0;
+        Dd.ne = B;
+        Dd.pad = 0;
+        Dd.t_last = t_last;
+        Dd.now = (bb == 0) ? (a.t_prev ? *a.t_prev : a.now_time) : a.t[e0 - 1];
+        Dd.n_light = (uint32_t)nc;
+        Dd.n_heavy = 0;
+        for (int i = 0; i < TPNET_MAX_LAYERS; ++i) Dd.decay[i] = 1.0f;
+        p.base.desc[bb] = Dd;
+    }
+}
 
 // ---- B1: a workgroup per (chunk of DCH nodes, window), a thread per node: the node's contributions in the window and the
 // batch of its last run there; its chain in the window (that many contributions) ranked among the chunk's chains of the same
@@ -283,7 +348,7 @@ __global__ __launch_bounds__(DCH) void k_dense_win(WPlan p, DView D, DArgs a) {
     }
     if (!live) sum = 0;
     if (live) D.wsl[w * D.Ns + n] = make_uint2(sum, last);
-    const int cl = sum ? wchain_class(sum, p.heavy_thr) : -1;
+    const int cl = (sum && n < a.own) ? wchain_class(sum, p.heavy_thr) : -1;     // (a halo node's runs are filled by the exchange: no chain)
     uint32_t myrank = 0;
 #pragma unroll
     for (int c8 = 0; c8 < 8; ++c8) {
@@ -425,10 +490,21 @@ __global__ __launch_bounds__(DCH) void k_dense_place(WPlan p, WTmp q, DView D, D
     const int64_t gid = (int64_t)blockIdx.x * DCH + tid, gsz = (int64_t)gridDim.x * DCH;
     for (int64_t n = gid; n < a.N; n += gsz) D.basef[n] = D.base[n] + cbase[n / DCH];   // (for the write-back and a replay)
     const int64_t nc = 2 * a.Ec;
-    const int64_t items = nc + (a.nwhich == 3 ? a.Ec : 0);
+    const bool shard = a.own < a.N;
+    const int64_t n_neg = a.nwhich == 3 ? a.Ec : 0;
+    const int64_t items = nc + n_neg + ((shard && a.nwhich >= 2) ? a.Ec : 0);
     for (int64_t x = gid; x < items; x += gsz) {
-        if (x < nc) dense_place(p, q, D, a, lstart, cbase, tl, x);
-        else dense_neg_c(p, D, a, cbase, tl, x - nc);
+        if (x < nc) {
+            if (shard) {                                  // (a shard sorted only the contributions to its own targets: the batch's first n_light positions)
+                const int64_t b = x / (2 * a.Bfull);
+                if (x - 2 * b * a.Bfull >= (int64_t)p.base.desc[b].n_light) continue;
+            }
+            dense_place(p, q, D, a, lstart, cbase, tl, x);
+        } else if (x < nc + n_neg) {
+            dense_neg_c(p, D, a, cbase, tl, x - nc);
+        } else {
+            dense_neg_c(p, D, a, cbase, tl, x - nc - n_neg, 1);
+        }
     }
 }
 
@@ -442,14 +518,14 @@ __global__ __launch_bounds__(256) void k_wplan_dense_negs(WPlan p, DView D, DArg
 // end of a chunk planned here: the last version of every touched node -> the other copy of its table bundle, meta published.
 // One lane group per node: {tot, base, lastb} -> the log row -> the table (three dependent round trips).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wwriteback_dense(tpnet_state S, WPlan p, DView D, uint32_t bid) {
+__global__ __launch_bounds__(256) void k_wwriteback_dense(tpnet_state S, WPlan p, DView D, uint32_t bid, int64_t own) {
     constexpr int LANES = 32;
     const int per = S.L * S.d;
     const int pv = per / 4;
     NodeMeta* meta = reinterpret_cast<NodeMeta*>(S.meta);
     const int gl = threadIdx.x % LANES, g = threadIdx.x / LANES;
     constexpr int GPB = 256 / LANES;
-    for (int64_t n = (int64_t)blockIdx.x * GPB + g; n < S.N; n += (int64_t)gridDim.x * GPB) {
+    for (int64_t n = (int64_t)blockIdx.x * GPB + g; n < own; n += (int64_t)gridDim.x * GPB) {
         const uint32_t tot = D.tot[n];
         const uint32_t bs = D.basef[n], lb = D.lastb[n];
         const uint32_t ver = meta[n].ver;
@@ -464,6 +540,9 @@ __global__ __launch_bounds__(256) void k_wwriteback_dense(tpnet_state S, WPlan p
 }
 
 bool wplan_dense_applies(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, int K) {
+    return batch <= PLAN_ONE_MAX && wplan_dense_applies_shard(st, p, Ec, batch, K);
+}
+bool wplan_dense_applies_shard(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, int K) {
     if (!p.dense || K < 1 || !wplan_dense_eligible(st.N, st.d, st.L, batch)) return false;
     const int64_t nb = (Ec + batch - 1) / batch;
     const int64_t nw = (nb + K - 1) / K;
@@ -474,8 +553,11 @@ bool wplan_dense_applies(const tpnet_state& st, const WPlan& p, int64_t Ec, int6
 
 int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src, const int64_t* dst, const int64_t* neg,
                       const double* t, int64_t Ec, int64_t batch, double now_time, const double* t_prev_dev, double lambda,
-                      bool want_readout, bool replay, hipStream_t s) {
-    if (!wplan_dense_applies(st, p, Ec, batch, p.K)) return TPNET_ERR_BAD_ARG;
+                      bool want_readout, bool replay, hipStream_t s, int64_t own, uint32_t* status) {
+    if (own < 0 || own > st.N) own = st.N;
+    const bool shard = own < st.N;
+    if (!(shard ? wplan_dense_applies_shard(st, p, Ec, batch, p.K) : wplan_dense_applies(st, p, Ec, batch, p.K))) return TPNET_ERR_BAD_ARG;
+    if (shard && replay) return TPNET_ERR_BAD_ARG;                      // (a shard's plan is kept by its runner, not replayed here)
     const int64_t nb = (Ec + batch - 1) / batch;
     const WTmp q = wtmp_of(p, (size_t)(2 * Ec));
     const DView D = dview_of(p, Ec, batch, st.N);
@@ -491,6 +573,8 @@ int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src,
     a.L = st.L;
     a.nwhich = want_readout ? (neg ? 3 : 2) : 0;
     a.nchunks = (int32_t)((st.N + DCH - 1) / DCH);
+    a.own = own;
+    a.status = status;
     if (replay) {
         if (a.nwhich == 3) {
             int g = (int)((Ec + 255) / 256);
@@ -502,7 +586,8 @@ int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src,
     }
 #define TPNET_WDENSE(BS_, IPT_) hipLaunchKernelGGL((k_dense_sort<BS_, IPT_>), dim3((unsigned)nb), dim3(BS_), 0, s, p, q, D, a)
     const int64_t n2 = 2 * batch;
-    if (n2 <= 512) TPNET_WDENSE(256, 2);
+    if (shard) hipLaunchKernelGGL((k_dense_sort_shard<1024, 4>), dim3((unsigned)nb), dim3(1024), 0, s, p, q, D, a);
+    else if (n2 <= 512) TPNET_WDENSE(256, 2);
     else if (n2 <= 1024) TPNET_WDENSE(512, 2);
     else if (n2 <= 2048) TPNET_WDENSE(1024, 2);
     else TPNET_WDENSE(1024, 4);
@@ -517,12 +602,15 @@ int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src,
     return TPNET_OK;
 }
 
-bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s) {
+bool wplan_dense_writeback(const tpnet_state& st, const WPlan& p, int64_t Ec, int64_t batch, uint32_t launch_id, hipStream_t s,
+                           int64_t own) {
     if ((st.L * st.d) % 4 != 0) return false;
+    if (own < 0 || own > st.N) own = st.N;
     const DView D = dview_of(p, Ec, batch, st.N);
-    int64_t grid = (st.N + 7) / 8;
+    int64_t grid = (own + 7) / 8;
     if (grid > 16384) grid = 16384;
-    hipLaunchKernelGGL(k_wwriteback_dense, dim3((unsigned)grid), dim3(256), 0, s, st, p, D, launch_id);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_wwriteback_dense, dim3((unsigned)grid), dim3(256), 0, s, st, p, D, launch_id, own);
     return hipGetLastError() == hipSuccess;
 }
 

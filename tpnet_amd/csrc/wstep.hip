@@ -813,12 +813,16 @@ __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpip
         const bool both = npos != 0 && nneg != 0;
         for (int64_t base = (int64_t)rb * RGPB; base < npairs; base += (int64_t)nblk * RGPB) {
             const int64_t pw = base + rg;
-            const bool valid = pw < npairs;
+            const bool valid_ = pw < npairs;
             // (src,dst) and (src,neg) of one edge sit in adjacent lane groups: the src rows are fetched by the same instructions
-            const int64_t idx = valid ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
-            const bool isneg = valid && (both ? (pw & 1) != 0 : (pw >= npos));      // (a lane group past the list reads dst[e0]: `neg` may be null)
+            const int64_t idx = valid_ ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
+            const bool isneg = valid_ && (both ? (pw & 1) != 0 : (pw >= npos));      // (a lane group past the list reads dst[e0]: `neg` may be null)
             const int64_t e = e0 + idx;
             int64_t ids[2] = {a.src[e], isneg ? a.neg[e] : a.dst[e]};
+            // row shard (own_mod = 0: local ids, rows < own_rem are this rank's): the pair belongs to the rank that owns its src node;
+            // a wave none of whose pairs is this rank's moves on
+            const bool valid = valid_ && (a.own_mod != 0 || ids[0] < (int64_t)a.own_rem);
+            if (a.own_mod == 0 && !__any(valid)) continue;
             const int which[2] = {0, isneg ? 2 : 1};
             float* out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
             const bool idok = valid && (uint64_t)ids[0] < (uint64_t)S.N && (uint64_t)ids[1] < (uint64_t)S.N;

@@ -733,6 +733,22 @@ class ShardedStreamRunner:
         all-gather of the send buffers from which every rank takes its parts.)  Same results as the all-gather variant; each
         rank receives only what it reads."""
         rp, G, me = self.rp, self.G, self.me
+        self.last_stream_windowed = False
+        nb_ = (int(src.numel()) + int(batch_size) - 1) // int(batch_size)
+        if self.windowed and G > 1 and timing is None and nb_ >= self.windowed_min_batches and src.is_cuda:
+            # every rank takes the same decision: tpnet_wshard_plan declines on shapes (all ranks alike) or on counts that all ranks
+            # derive from the same stream -- except a batch whose OWNED contributions overflow one rank's sort: agreed on below
+            self._check_pending_status()
+            W = self.plan_windowed(src, dst, neg, t, batch_size)
+            ok = W is not None
+            if not self.detached:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=rp._dev() if dist.get_backend(self.group) == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                ok = bool(int(flag.item()))
+            if ok:
+                return self.run_stream_windowed(src, dst, neg, t, batch_size, t_host_last, merge_outputs, out_pos, out_neg, plan=W)
+            if W is not None:
+                _lib.load().tpnet_wshard_destroy(W["handle"])
         ctx = self.prepare_targeted(src, dst, neg, t, batch_size, t_host_last, out_pos=out_pos, out_neg=out_neg,
                                     zero_outputs=merge_outputs and G > 1)
         if ctx["E"] == 0:
@@ -806,6 +822,175 @@ class ShardedStreamRunner:
                           step_ms=sum(e[1].elapsed_time(e[2]) for e in evs) / nb,
                           exchange_ms=sum(e[0].elapsed_time(e[1]) for e in evs) / nb)
         return self.finish_targeted(ctx, merge_outputs)
+
+    # ---- the shard on the windowed pipeline (csrc/wshard.hip) -------------------------------------------------------------------
+    windowed = True                 # G > 1: one launch + one exchange per WINDOW of batches where tpnet_wshard_plan serves the call
+    windowed_min_batches = 16       # (as the single-GPU schedule: below that the per-batch launches win)
+    last_stream_windowed = False
+
+    def _wshard_buffers(self, d, L, n_p0, n_send, n_recv, dev):
+        """The windowed shard's exchange buffers, kept across calls and only ever grown."""
+        b = self.__dict__.get("_wshard_bufs")
+        need = (max(n_p0, 1), max(n_send, 1), max(n_recv, 1))
+        if b is None or b["dev"] != dev or any(x < y for x, y in zip(b["n"], need)):
+            n = tuple(max(x, y) for x, y in zip(b["n"], need)) if (b is not None and b["dev"] == dev) else need
+            b = dict(dev=dev, n=n, send_p0=torch.empty((n[0], d), dtype=torch.float32, device=dev),
+                     send_q=torch.empty((n[0], L * d), dtype=torch.float32, device=dev),
+                     sendbuf=torch.empty((n[1], d), dtype=torch.float32, device=dev),
+                     recvbuf=torch.empty((n[2], d), dtype=torch.float32, device=dev))
+            self.__dict__["_wshard_bufs"] = b
+        return b
+
+    def plan_windowed(self, src, dst, neg, t, batch_size: int, want_pos: bool = True, want_neg: bool = True):
+        """tpnet_wshard_plan for one call (the whole call is one chunk of the pipeline): a dict with the plan's handle, its counts
+        and the exchange buffers -- or None where the windowed shard does not serve the call (the per-batch shard then does)."""
+        rp, G, me = self.rp, self.G, self.me
+        rp._ensure_engine()
+        lib = _lib.load()
+        dev = rp._dev()
+        E, B = int(src.numel()), int(batch_size)
+        L, d = rp.num_layer, rp.dim
+        if E == 0 or rp.exact or (E + B - 1) // B < 4:
+            return None
+        for x, dt in ((src, torch.int64), (dst, torch.int64), (t, torch.float64)) + (((neg, torch.int64),) if neg is not None else ()):
+            if x.device != dev or x.dtype != dt or not x.is_contiguous() or x.numel() != E:
+                return None
+        need = int(lib.tpnet_wshard_workspace_bytes(rp.node_num, d, L, E, B, G, self.n_cap))
+        if need == 0:
+            return None
+        eng = rp._engine()
+        if eng["ws"] is None or eng["ws"].numel() < need:
+            eng["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        rp._drop_plan()                                   # (the workspace is this call's now)
+        ws = eng["ws"]
+        h = C.c_void_p()
+        flags = _lib.FLAG_NOT_SCALE if rp.not_scale else 0
+        want_neg = want_neg and neg is not None
+        rc = lib.tpnet_wshard_plan(rp._st_ref(), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
+                                   E, B, self.N, G, me, self.n_cap, rp._now_host, float(rp.time_decay_weight), flags,
+                                   1 if want_pos else 0, 1 if want_neg else 0, ws.data_ptr(), ws.numel(), rp._stream(), C.byref(h))
+        if rc == 1:
+            return None
+        _lib.check(rc, "wshard_plan")
+        ns, halo, ms, mr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        pc, psc, prc = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
+        _lib.check(lib.tpnet_wshard_info(h, C.byref(ns), C.byref(halo), C.byref(ms), C.byref(mr), C.byref(pc), C.byref(psc), C.byref(prc)),
+                   "wshard_info")
+        nsteps = int(ns.value)
+        chunk_cnt = np.ctypeslib.as_array(pc, shape=(G,)).copy()
+        send_cnt = np.ctypeslib.as_array(psc, shape=(nsteps, G)).copy()
+        recv_cnt = np.ctypeslib.as_array(prc, shape=(nsteps, G)).copy()
+        bufs = self._wshard_buffers(d, L, int(chunk_cnt[me]), int(ms.value), int(mr.value), dev)
+        _lib.check(lib.tpnet_wshard_set_buffers(h, bufs["send_p0"].data_ptr(), bufs["send_q"].data_ptr(), bufs["sendbuf"].data_ptr(),
+                                                bufs["recvbuf"].data_ptr()), "wshard_set_buffers")
+        hstart = np.concatenate([[0], np.cumsum([0 if o == me else int(chunk_cnt[o]) for o in range(G)])]).astype(np.int64)
+        return dict(handle=h, nsteps=nsteps, halo=int(halo.value), chunk_cnt=chunk_cnt, send_cnt=send_cnt, recv_cnt=recv_cnt, bufs=bufs,
+                    hstart=hstart, E=E, B=B, ws=ws, want_pos=want_pos, want_neg=want_neg)
+
+    def run_stream_windowed(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True, out_pos=None,
+                            out_neg=None, comm="auto", plan=None):
+        """run_stream on the windowed pipeline (see the module's doc and csrc/wshard.hip): one launch + one exchange per window of
+        batches.  Returns (feat_pos, feat_neg), or None where tpnet_wshard_plan does not serve the call (nothing has run then)."""
+        rp, G, me = self.rp, self.G, self.me
+        W = plan if plan is not None else self.plan_windowed(src, dst, neg, t, batch_size)
+        if W is None:
+            return None
+        lib = _lib.load()
+        dev = rp._dev()
+        E, NG = W["E"], rp.pair_wise_feature_dim
+        h = W["handle"]
+        try:
+            zero = merge_outputs and G > 1
+            for name, o in (("out_pos", out_pos), ("out_neg", out_neg)):
+                if o is not None and (o.dtype != torch.float32 or o.device != dev or not o.is_contiguous() or tuple(o.shape) != (E, NG)):
+                    raise ValueError(f"{name} must be a contiguous float32 tensor of shape ({E}, {NG}) on {dev}")
+            if out_pos is None:
+                out_pos = torch.zeros((E, NG), dtype=torch.float32, device=dev)
+            elif zero:
+                out_pos.zero_()
+            if neg is None:
+                out_neg = None
+            elif out_neg is None:
+                out_neg = torch.zeros((E, NG), dtype=torch.float32, device=dev)
+            elif zero:
+                out_neg.zero_()
+            lid = rp._next_launch_ids(1)
+            stream = rp._stream()
+            op, on = out_pos.data_ptr(), (out_neg.data_ptr() if out_neg is not None else None)
+            if comm == "auto":
+                nccl = G > 1 and not self.detached and dist.get_backend(self.group) == "nccl"
+                comm = self._c_comm() if nccl else None
+            if comm is not None or G == 1:
+                _lib.check(lib.tpnet_wshard_run(h, comm, op, on, lid, stream), "wshard_run")
+            else:
+                self._wshard_run_gloo(W, op, on, lid, stream)
+            if t_host_last is not None:
+                t_end = float(np.asarray(t_host_last, dtype=np.float64)[-1])
+            else:
+                t_end = float(t[-1].item())
+            rp._now_host = t_end
+            rp._params_valid = False
+            rp._now_dirty = True
+            rp._table_written()
+        finally:
+            lib.tpnet_wshard_destroy(h)
+        self.last_stream_windowed = True
+        if G > 1 and merge_outputs and not self.detached:
+            dist.all_reduce(out_pos, group=self.group)
+            if out_neg is not None:
+                dist.all_reduce(out_neg, group=self.group)
+        return out_pos, out_neg
+
+    def _wshard_run_gloo(self, W, op, on, lid, stream):
+        """The windowed shard's loop with the rows moved by torch.distributed (gloo in the tests; a process group without the C-side
+        RCCL communicator): pack launches, an all-gather of the padded send buffers from which every rank takes its parts, unpack
+        launches -- the same pack / unpack kernels and the same buffers as the RCCL loop."""
+        lib = _lib.load()
+        rp, G, me = self.rp, self.G, self.me
+        dev = rp._dev()
+        L, d = rp.num_layer, rp.dim
+        h, bufs = W["handle"], W["bufs"]
+        all_plans = [None] * G
+        dist.all_gather_object(all_plans, (W["chunk_cnt"], W["send_cnt"], W["recv_cnt"]), group=self.group)
+        PH_LAUNCH, PH_PACK, PH_UNPACK = 1, 2, 8
+        # ---- the chunk's halo rows
+        _lib.check(lib.tpnet_wshard_begin(h, None, PH_PACK, stream), "wshard_begin")
+        cmax = max(int(max(p[0])) for p in all_plans) or 1
+        pad_p0 = torch.zeros((cmax, d), dtype=torch.float32, device=dev)
+        pad_q = torch.zeros((cmax, L * d), dtype=torch.float32, device=dev)
+        mine = int(W["chunk_cnt"][me])
+        pad_p0[:mine].copy_(bufs["send_p0"][:mine]); pad_q[:mine].copy_(bufs["send_q"][:mine])
+        g_p0 = [torch.empty_like(pad_p0) for _ in range(G)]
+        g_q = [torch.empty_like(pad_q) for _ in range(G)]
+        dist.all_gather(g_p0, pad_p0, group=self.group)
+        dist.all_gather(g_q, pad_q, group=self.group)
+        p0_t = rp._plist()[0].data
+        q_t = rp._eng["q"].view(2, rp.node_num, L * d)
+        for o in range(G):
+            c = int(W["chunk_cnt"][o])
+            if o != me and c:
+                a0 = self.n_cap + int(W["hstart"][o])
+                p0_t[a0:a0 + c].copy_(g_p0[o][:c])
+                q_t[0, a0:a0 + c].copy_(g_q[o][:c])
+        # ---- the pipeline
+        smax = max(int(p[1].sum(axis=1).max()) for p in all_plans) or 1
+        pad = torch.zeros((smax, d), dtype=torch.float32, device=dev)
+        gath = [torch.empty_like(pad) for _ in range(G)]
+        for j in range(W["nsteps"]):
+            _lib.check(lib.tpnet_wshard_step(h, None, j, PH_LAUNCH | PH_PACK, op, on, stream), "wshard_step")
+            if any(int(p[1][j].sum()) for p in all_plans):
+                ns = int(W["send_cnt"][j].sum())
+                pad[:ns].copy_(bufs["sendbuf"][:ns])
+                dist.all_gather(gath, pad, group=self.group)
+                ro = 0
+                for o in range(G):                      # what owner o packed for me sits behind what it packed for the peers before me
+                    c = int(W["recv_cnt"][j][o])
+                    if c:
+                        a0 = int(all_plans[o][1][j][:me].sum())
+                        bufs["recvbuf"][ro:ro + c].copy_(gath[o][a0:a0 + c])
+                    ro += c
+                _lib.check(lib.tpnet_wshard_step(h, None, j, PH_UNPACK, op, on, stream), "wshard_step")
+        _lib.check(lib.tpnet_wshard_finish(h, lid, stream), "wshard_finish")
 
     def gather_full_layers(self):
         """All ranks' owned rows interleaved back into global order: [L+1, N, d] on every rank (tests / checkpoints of small
