@@ -303,6 +303,90 @@ def test_sharded_stream_equals_single_gpu(cfg, exchange):
         assert cmp[6] < 0.6 * cmp[7], cmp
 
 
+def _gpu_worker_windowed(rank, world, port, cfg, q):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        import tpnet_amd
+        from tpnet_amd.sharded import ShardedStreamRunner
+        N, d, L, E, B, lam = cfg
+        dev = torch.device("cuda:0")
+        src, dst, neg, t = _stream(5, N, E)
+        P0 = torch.from_numpy((np.random.RandomState(77).randn(N, d) / np.sqrt(d)).astype(np.float32))
+        runner = ShardedStreamRunner.create(node_num=N, edge_num=E, dim=d, num_layer=L, time_decay_weight=lam, device=dev,
+                                            beginning_time=np.float64(t[0]), halo_rows=max(3 * B, N), seed=rank)
+        runner.set_full_p0(P0)
+        runner.exchange = "targeted"
+        D = lambda x: torch.from_numpy(x).to(dev)
+        fp, fn = runner.run_stream(D(src), D(dst), D(neg), D(t), B)
+        took = runner.last_stream_windowed
+        layers = runner.gather_full_layers().cpu()
+        runner.check_device_errors()
+        # a second stream on the table the first one left (the chunk's halo rows now carry a pending decay)
+        src2, dst2, neg2, t2 = _stream(6, N, E)
+        t2 = t2 + (t[-1] - t2[0]) + 1.0
+        fp2, fn2 = runner.run_stream(D(src2), D(dst2), D(neg2), D(t2), B)
+        layers2 = runner.gather_full_layers().cpu()
+        if rank == 0:
+            ref = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L, time_decay_weight=lam,
+                                                   device="cuda:0", use_matrix=False, beginning_time=np.float64(t[0]),
+                                                   not_scale=False, enforce_dim=d)
+            ref.random_projections[0].data = P0.clone()
+            ref = ref.to(dev)
+            rfp, rfn = ref.run_stream(D(src), D(dst), D(neg), D(t), B, schedule="windowed")
+            rl = torch.stack([ref.random_projections[i].detach() for i in range(0, L + 1)]).cpu()
+            rfp2, rfn2 = ref.run_stream(D(src2), D(dst2), D(neg2), D(t2), B, schedule="windowed")
+            rl2 = torch.stack([ref.random_projections[i].detach() for i in range(0, L + 1)]).cpu()
+            scale = float(rl2[1:].abs().max())
+            q.put(("cmp", took, bool(torch.equal(fp, rfp)), bool(torch.equal(fn, rfn)), bool(torch.equal(layers, rl)),
+                   max(float((fp2 - rfp2).abs().max()), float((fn2 - rfn2).abs().max())),
+                   float((layers2[1:] - rl2[1:]).abs().max()) / scale, float(runner.rp.now_time.item()) == float(t2[-1])))
+        q.put(("done", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(211, 128, 3, 2000, 100, 2e-6), (600, 64, 2, 2990, 100, 1e-6)])
+def test_windowed_shard_two_gloo_ranks_equal_single_gpu(cfg):
+    """Two ranks (gloo) sharing cuda:0 through ShardedStreamRunner.run_stream: from 16 batches on the stream takes the WINDOWED
+    shard (csrc/wshard.hip: one launch + one exchange per window of batches).  On a table fresh from a reset the two shards equal
+    the single-GPU run on the windowed schedule BIT FOR BIT (features and every layer: a log slot travels as it is); a second
+    stream on the table the first one left equals it within the per-batch shard's tolerances (the chunk's halo rows carry one
+    extra f32 rounding of their pending decay)."""
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker_windowed, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    msgs = [q.get(timeout=300) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=120)
+    cmp = [m for m in msgs if m[0] == "cmp"][0]
+    assert cmp[1], "the stream did not take the windowed shard"
+    assert cmp[2] and cmp[3] and cmp[4], cmp
+    assert cmp[5] < 2e-4 and cmp[6] < 1e-5 and cmp[7], cmp
+
+
+@pytest.mark.gpu
+def test_windowed_shard_equals_single_gpu_bit_for_bit():
+    """Two, three and four row shards in ONE process on the windowed pipeline (tests/loopback/run_wshard.py): the phases of
+    tpnet_wshard_begin / tpnet_wshard_step with the rows moved by plain copies, and tpnet_wshard_run with every shard a host thread
+    on the in-process RCCL stand-in -- features and tables BIT FOR BIT equal to the single-GPU run on the windowed schedule (hubs
+    whose chains span windows, ragged tail, d = 64 / 128 / 256, L = 2 / 3, the C2 table with global batches of 2 000 edges)."""
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.fail("needs a GPU")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "loopback")
+    if not os.path.exists(os.path.join(here, "librccl_loopback.so")):
+        subprocess.run(["make", "-C", here], check=True)
+    res = subprocess.run([sys.executable, os.path.join(here, "run_wshard.py")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "WSHARD OK" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
+
+
 def _c_loop_worker(port, cfg, use_c, q):
     """One rank on RCCL with the collectives forced: the batch loop as ONE C call per batch with RCCL called from C
     (tpnet_rows_step), or through torch.distributed -- same results as the plain single-GPU stream."""
