@@ -716,8 +716,11 @@ def main():
         the elapsed seconds, the bytes of table a rank holds, and the kernel / exchange figures of THIS rank."""
         from tpnet_amd.sharded import ShardedStreamRunner
         a_src, a_dst, a_neg, a_t = arrs
+        # halo rows: 3 per edge of a batch are always enough for the per-batch shard; the windowed shard keeps ONE row per remote node a
+        # whole call touches -- on a table this small (C2: 9 228 rows) that is every remote node
+        halo_ = max(3 * Bg_, min(N_, 65536)) if N_ <= 65536 else 3 * Bg_
         runner = ShardedStreamRunner.create(node_num=N_, edge_num=E_cfg, dim=d_, num_layer=L, time_decay_weight=lam_,
-                                            device=dev, beginning_time=np.float64(0.0), halo_rows=3 * Bg_,
+                                            device=dev, beginning_time=np.float64(0.0), halo_rows=halo_,
                                             draw_on_device=draw_on_device)
         # targeted exchange (every row only to the ranks that read it, received in place, grouped ncclSend / ncclRecv from C);
         # TPNET_BENCH_EXCHANGE=allgather: one all-gather of every touched row per step
@@ -736,11 +739,15 @@ def main():
             ws_b = rp_._eng["ws"].numel()
             will_window = bool(lib_.tpnet_stream_schedule(rp_.node_num, d_, L, k_steps * Bg_, Bg_, 0, ws_b) == 1)
         else:
-            will_window = False
+            # (G > 1: from 16 batches the stream takes the windowed shard; the warm-up call takes it too, from 4 batches, so that its
+            # kernels and buffers exist before the clock starts)
+            will_window = bool(runner.G > 1 and runner.windowed and k_steps >= runner.windowed_min_batches)
+        min_b = runner.windowed_min_batches
 
         def run(a, b_, timing=None):
             sl_ = slice(a * Bg_, b_ * Bg_)
             n_ = (b_ - a) * Bg_
+            runner.windowed_min_batches = 4 if (will_window and b_ <= W) else min_b
             t_last = t_host[np.minimum(np.arange(a + 1, b_ + 1) * Bg_, len(t_host)) - 1]
             # (a warm-up call of >= 4 batches runs the schedule the timed call will run: its kernels are loaded before the clock starts)
             runner.schedule = "windowed" if (will_window and b_ <= W and b_ - a >= 4) else None
@@ -771,31 +778,63 @@ def main():
                                      cfg_name=None)
         else:
             tm = {}
+            rp_.reset_random_projections()
             run(W, W + k_steps, timing=tm)
-            per_launch_edges = Bg_ / world                      # this rank's share of a step: the pairs / targets it owns
-            ach = bpe_ * per_launch_edges / (tm["step_ms"] * 1e-3) / 1e9 if tm.get("step_ms") else 0.0
-            xc = runner.__dict__.get("_xplan_cache")
-            R_ = xc[1] if xc else None
-            rows_s = float(np.mean(R_["stot"])) if R_ is not None else 0.0
-            rows_r = float(np.mean(R_["rtot"])) if R_ is not None else 0.0
             row_b = (L + 1) * d_ * 4
-            info["roof"] = {"bound": "hbm", "kernel": "k_step (fused readout + update of one batch, restricted to the pairs / targets this rank "
-                            "owns; one launch per step behind the step's exchange)", "kernel_short": "k_step", "windowed": False,
-                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                            "traffic_source": {"stale": True, "reason": "no PMC pass of the sharded step exists (one-GPU builder pool)"},
-                            "algorithmic_bytes_per_launch": bpe_ * per_launch_edges, "edges_per_launch": per_launch_edges,
-                            "launches": tm.get("batches"), "steps": tm.get("batches"),
-                            "avg_launch_period_us": tm.get("step_ms", 0.0) * 1e3, "stream_ms_events": tm.get("total_ms"),
-                            "rank": rank,
-                            "duration_note": "HIP events on the launch stream around every step launch of rank 0 (tpnet_time_rows_stream_targeted), "
-                                             "an extra pass over the timed batches; achieved = section-8(d) bytes per edge x this rank's "
-                                             "share of the global batch (1 / N of it) / the average step duration",
-                            "exchange": {"what": "per step: one pack launch + ONE grouped ncclSend / ncclRecv (rows received in place in the halo)",
-                                         "avg_us_per_step": tm.get("exchange_ms", 0.0) * 1e3,
-                                         "rows_sent_per_step": rows_s, "rows_received_per_step": rows_r,
-                                         "bytes_sent_per_step": rows_s * row_b, "bytes_received_per_step": rows_r * row_b,
-                                         "bytes_per_step_per_peer": (rows_s * row_b / (world - 1)) if world > 1 else 0.0,
-                                         "row_bytes": row_b, "transport": ("rccl (C loop)" if (R_ is not None and backend == "nccl") else backend)}}
+            transport = "rccl (C loop)" if backend == "nccl" else backend
+            if tm.get("windowed"):
+                # the shard ran on the windowed pipeline (csrc/wshard.hip): one k_wpipe launch + one exchange per window of batches
+                nl = max(1, int(tm.get("launches") or 1))
+                per_launch_edges = k_steps * Bg_ / world / nl   # this rank's share: the pairs / targets it owns
+                ach = bpe_ * per_launch_edges / (tm["step_ms"] * 1e-3) / 1e9 if tm.get("step_ms") else 0.0
+                info["roof"] = {"bound": "hbm", "kernel": "k_wpipe (windowed schedule on a row shard: one launch per pipeline step = layer i of "
+                                "window j-i+1 + the readouts of window j-L, restricted to the chains / pairs this rank owns; one exchange "
+                                "behind every launch)", "kernel_short": "k_wpipe", "windowed": True,
+                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                "traffic_source": {"stale": True, "reason": "no PMC pass of the sharded pipeline exists (one-GPU builder pool)"},
+                                "algorithmic_bytes_per_launch": bpe_ * per_launch_edges, "edges_per_launch": per_launch_edges,
+                                "launches": nl, "steps": k_steps, "avg_launch_period_us": tm.get("step_ms", 0.0) * 1e3,
+                                "stream_ms_events": tm.get("total_ms"), "rank": rank,
+                                "duration_note": "HIP events on the launch stream around every k_wpipe launch of rank 0 (tpnet_time_wshard_run), an "
+                                                 "extra pass over the timed batches; achieved = section-8(d) bytes per edge x this rank's share "
+                                                 "(1 / N) of the edges a launch covers / the average launch duration",
+                                "exchange": {"what": "per launch: pack + ONE grouped ncclSend / ncclRecv + unpack of the launch's results that "
+                                                     "other ranks read (log slots, layer by layer); once per call: the touched rows of every "
+                                                     "rank to every other (the chunk's halo rows)",
+                                             "avg_us_per_launch": tm.get("exchange_ms", 0.0) * 1e3,
+                                             "rows_sent_per_launch": tm.get("rows_sent_per_launch"),
+                                             "rows_received_per_launch": tm.get("rows_received_per_launch"),
+                                             "bytes_sent_per_launch": (tm.get("rows_sent_per_launch") or 0.0) * d_ * 4,
+                                             "bytes_received_per_launch": (tm.get("rows_received_per_launch") or 0.0) * d_ * 4,
+                                             "bytes_per_launch_per_peer": ((tm.get("rows_sent_per_launch") or 0.0) * d_ * 4 / (world - 1)) if world > 1 else 0.0,
+                                             "chunk_rows_sent": tm.get("chunk_rows_sent"), "chunk_rows_received": tm.get("chunk_rows_received"),
+                                             "chunk_bytes_received": (tm.get("chunk_rows_received") or 0) * row_b,
+                                             "row_bytes": d_ * 4, "transport": transport}}
+            else:
+                per_launch_edges = Bg_ / world                      # this rank's share of a step: the pairs / targets it owns
+                ach = bpe_ * per_launch_edges / (tm["step_ms"] * 1e-3) / 1e9 if tm.get("step_ms") else 0.0
+                xc = runner.__dict__.get("_xplan_cache")
+                R_ = xc[1] if xc else None
+                rows_s = float(np.mean(R_["stot"])) if R_ is not None else 0.0
+                rows_r = float(np.mean(R_["rtot"])) if R_ is not None else 0.0
+                info["roof"] = {"bound": "hbm", "kernel": "k_step (fused readout + update of one batch, restricted to the pairs / targets this rank "
+                                "owns; one launch per step behind the step's exchange)", "kernel_short": "k_step", "windowed": False,
+                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                "traffic_source": {"stale": True, "reason": "no PMC pass of the sharded step exists (one-GPU builder pool)"},
+                                "algorithmic_bytes_per_launch": bpe_ * per_launch_edges, "edges_per_launch": per_launch_edges,
+                                "launches": tm.get("batches"), "steps": tm.get("batches"),
+                                "avg_launch_period_us": tm.get("step_ms", 0.0) * 1e3, "stream_ms_events": tm.get("total_ms"),
+                                "rank": rank,
+                                "duration_note": "HIP events on the launch stream around every step launch of rank 0 (tpnet_time_rows_stream_targeted), "
+                                                 "an extra pass over the timed batches; achieved = section-8(d) bytes per edge x this rank's "
+                                                 "share of the global batch (1 / N of it) / the average step duration",
+                                "exchange": {"what": "per step: one pack launch + ONE grouped ncclSend / ncclRecv (rows received in place in the halo)",
+                                             "avg_us_per_step": tm.get("exchange_ms", 0.0) * 1e3,
+                                             "rows_sent_per_step": rows_s, "rows_received_per_step": rows_r,
+                                             "bytes_sent_per_step": rows_s * row_b, "bytes_received_per_step": rows_r * row_b,
+                                             "bytes_per_step_per_peer": (rows_s * row_b / (world - 1)) if world > 1 else 0.0,
+                                             "row_bytes": row_b, "transport": transport}}
+            info["schedule"] = "windowed" if tm.get("windowed") else "batch"
         info["regions"] = {"n": len(regs), "value_is": "median", "wall_us": [x * 1e6 for x in regs]}
         runner.close()
         del o_pos, o_neg
@@ -803,6 +842,7 @@ def main():
 
     def rows_leg(k_steps):
         return sharded_rows(N, d, cfg["lam"], cfg["E"], Bg, (d_src, d_dst, d_neg, d_t), t, k_steps)
+    halo_rows_main = max(3 * Bg, min(N, 65536)) if N <= 65536 else 3 * Bg
 
     def cols_leg(k_steps):
         from tpnet_amd.sharded import ColumnShardedRunner
@@ -874,7 +914,8 @@ def main():
                    f"per-step collective; the 36 distinct raw Gram entries per pair are reduce-scattered (RCCL) per "
                    f"chunk of ~2M edges behind the next chunk's kernels",
            "rows": f"rows sharded over {world} GPUs (owner = id % {world}; every GPU holds only its {(N + world - 1) // world} "
-                   f"rows of all {L + 1} layers + {3 * Bg} halo rows), global batch {Bg} = {B} per GPU, per step one grouped RCCL "
+                   f"rows of all {L + 1} layers + {halo_rows_main} halo rows), global batch {Bg} = {B} per GPU; from 16 batches on the windowed "
+                   f"pipeline (one k_wpipe launch + one grouped RCCL send / recv per window of batches), else per step one grouped RCCL "
                    f"send / recv of the rows each peer reads, received in place ({os.environ.get('TPNET_BENCH_EXCHANGE', 'targeted')} exchange)"}[shard]
 
     def emit(row_info=None, roof=None, cpu=None, dropin=None, extra=None):
@@ -893,6 +934,7 @@ def main():
         if shard == "rows":
             line["config"]["table_bytes_per_gpu"] = row_bytes
             line["timed_regions"] = rows_info.get("regions")
+            line["config"]["schedule"] = rows_info.get("schedule")
         if dropin is not None:
             line["dropin"] = dropin
         if shard == "single" and len(regions) > 1:

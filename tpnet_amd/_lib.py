@@ -161,6 +161,7 @@ DEV_SIGNATURES = {
     "tpnet_time_stream": (C.c_int, [_SP, _P, _P, _P, _P, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
                                     C.c_uint32, _P, _P, _P, C.c_size_t, C.c_int, C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
+    "tpnet_time_wshard_run": (C.c_int, [_P, _P, _P, _P, C.c_uint32, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tpnet_time_rows_stream_targeted": (C.c_int, [_SP, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P, _P, _P,
                                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_uint32, C.c_uint32,
                                                   C.c_int32, _P, _P, _P, C.c_size_t, _P, C.POINTER(C.c_float), C.POINTER(C.c_float),

@@ -32,6 +32,12 @@ int tpnet_time_rows_stream_targeted(const tpnet_state* st, void* comm, const int
                                     float* out_neg, void* workspace, size_t ws_bytes, void* stream, float* total_ms_out,
                                     float* step_ms_out, float* exchange_ms_out);
 
+/* tpnet_wshard_run with HIP events on `stream` around every pipeline step's launch and around its pack + exchange + unpack; one
+ * synchronise at the end.  total_ms_out = the whole call (the chunk's halo exchange included); launch_ms_out / exchange_ms_out =
+ * averages per step. */
+int tpnet_time_wshard_run(tpnet_wshard* w, void* comm, float* out_pos, float* out_neg, uint32_t launch_id, void* stream,
+                          float* total_ms_out, float* launch_ms_out, float* exchange_ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -645,4 +645,43 @@ int tpnet_wshard_run(tpnet_wshard* w, void* comm, float* out_pos, float* out_neg
     return tpnet_wshard_finish(w, launch_id, stream);
 }
 
+/* measurement aid (tpnet_dev.h): tpnet_wshard_run with HIP events on `stream` around every step's launch and around its pack +
+ * exchange + unpack; one synchronise at the end.  launch_ms_out / exchange_ms_out: averages per step. */
+int tpnet_time_wshard_run(tpnet_wshard* w, void* comm, float* out_pos, float* out_neg, uint32_t launch_id, void* stream,
+                          float* total_ms_out, float* launch_ms_out, float* exchange_ms_out) {
+    if (!w) return TPNET_ERR_BAD_ARG;
+    if (w->G > 1 && !comm) return TPNET_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)w->nsteps;
+    std::vector<hipEvent_t> ev(3 * n + 1);
+    for (auto& e : ev) TPNET_HIP_TRY(hipEventCreate(&e));
+    (void)hipEventRecord(ev[3 * n], s);
+    int rc = tpnet_wshard_begin(w, comm, WS_PH_PACK | WS_PH_EXCHANGE, stream);
+    for (size_t j = 0; j < n && rc == TPNET_OK; ++j) {
+        (void)hipEventRecord(ev[3 * j], s);
+        rc = tpnet_wshard_step(w, comm, (int64_t)j, WS_PH_LAUNCH, out_pos, out_neg, stream);
+        (void)hipEventRecord(ev[3 * j + 1], s);
+        if (rc == TPNET_OK) rc = tpnet_wshard_step(w, comm, (int64_t)j, WS_PH_PACK | WS_PH_EXCHANGE | WS_PH_UNPACK, out_pos, out_neg, stream);
+        (void)hipEventRecord(ev[3 * j + 2], s);
+    }
+    if (rc == TPNET_OK) rc = tpnet_wshard_finish(w, launch_id, stream);
+    if (rc == TPNET_OK) {
+        TPNET_HIP_TRY(hipStreamSynchronize(s));
+        double la = 0.0, xc = 0.0;
+        float ms = 0.f;
+        for (size_t j = 0; j < n; ++j) {
+            TPNET_HIP_TRY(hipEventElapsedTime(&ms, ev[3 * j], ev[3 * j + 1]));
+            la += ms;
+            TPNET_HIP_TRY(hipEventElapsedTime(&ms, ev[3 * j + 1], ev[3 * j + 2]));
+            xc += ms;
+        }
+        TPNET_HIP_TRY(hipEventElapsedTime(&ms, ev[3 * n], ev[3 * n - 1]));
+        if (total_ms_out) *total_ms_out = ms;
+        if (launch_ms_out) *launch_ms_out = (float)(la / (double)n);
+        if (exchange_ms_out) *exchange_ms_out = (float)(xc / (double)n);
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
 }  // extern "C"

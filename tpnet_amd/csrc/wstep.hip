@@ -730,7 +730,10 @@ __device__ __forceinline__ uint32_t hub_chains(const WStep& st, const WinDesc& w
 // ---------------------------------------------------------------------------------------------------------------
 // RS: the readout takes the 16-lane x 2-vector geometry while the chains keep 32 lanes x 1 vector (rows of 17..32 vectors:
 // a long list of independent pairs wants four pairs per wave, a chain wants a contribution per lane and round)
-template <int LPP, int VPL, int L, bool FULL, bool RS>
+// SHARD: the launch of a row shard (wshard.hip): StreamArgs::own_mod = 0, local ids, only the pairs whose src node is this rank's
+// (ids < own_rem) are read out -- a variant of its own: the C2 kernel sits exactly at the 128 registers four waves per SIMD allow, and
+// the test cost it 28-44 bytes of scratch per lane (4 % per launch)
+template <int LPP, int VPL, int L, bool FULL, bool RS, bool SHARD = false>
 __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpipe(tpnet_state S, WPlan P, StreamArgs a, WStep st, int64_t Ec, int64_t B,
                                               double lambda, uint32_t flags) {
     constexpr int W = 4;
@@ -811,6 +814,8 @@ __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpip
         const int64_t nneg = a.out_neg ? ne : 0;
         const int64_t npairs = npos + nneg;
         const bool both = npos != 0 && nneg != 0;
+        const uint64_t own_lim = SHARD ? (uint64_t)(uint32_t)a.own_rem : ~0ull;     // (scalar: ids below it are this rank's)
+        (void)own_lim;
         for (int64_t base = (int64_t)rb * RGPB; base < npairs; base += (int64_t)nblk * RGPB) {
             const int64_t pw = base + rg;
             const bool valid_ = pw < npairs;
@@ -821,8 +826,11 @@ __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpip
             int64_t ids[2] = {a.src[e], isneg ? a.neg[e] : a.dst[e]};
             // row shard (own_mod = 0: local ids, rows < own_rem are this rank's): the pair belongs to the rank that owns its src node;
             // a wave none of whose pairs is this rank's moves on
-            const bool valid = valid_ && (a.own_mod != 0 || ids[0] < (int64_t)a.own_rem);
-            if (a.own_mod == 0 && !__any(valid)) continue;
+            bool valid = valid_;
+            if constexpr (SHARD) {
+                valid = valid_ && (uint64_t)ids[0] < own_lim;
+                if (!__any(valid)) continue;
+            }
             const int which[2] = {0, isneg ? 2 : 1};
             float* out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
             const bool idok = valid && (uint64_t)ids[0] < (uint64_t)S.N && (uint64_t)ids[1] < (uint64_t)S.N;
@@ -1055,15 +1063,23 @@ int launch_wstep(const tpnet_state& st, const StreamArgs& a, const WPlan& p, int
     }
     ws.seg[2 * L + 2] = nb;
     if (nb == 0) return TPNET_OK;
+    const bool shard = a.own_mod == 0;
     TPNET_DISPATCH_G(geo, ({
         if constexpr (W == 4) {
             if constexpr (LPP == 32 && VPL == 1) {
-                if (rsplit)
+                if (rsplit && shard)
+                    hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, true, true>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+                else if (rsplit)
                     hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, true>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+                else if (shard)
+                    hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false, true>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
                 else
                     hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
             } else {
-                hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+                if (shard)
+                    hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false, true>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
+                else
+                    hipLaunchKernelGGL((k_wpipe<LPP, VPL, L, FULL, false>), dim3(nb), dim3(WB), 0, s, st, p, a, ws, Ec, batch, lambda, flags);
             }
         } else {
             return TPNET_ERR_BAD_ARG;

@@ -468,6 +468,12 @@ class ShardedStreamRunner:
             rp.reserve_stream(E, B)
         else:
             rp._workspace(E, B, keep_plan=True)
+            if self.windowed and self.G > 1:
+                need = int(lib.tpnet_wshard_workspace_bytes(rp.node_num, rp.dim, rp.num_layer, E, B, self.G, self.n_cap))
+                eng = rp._engine()
+                if need and (eng["ws"] is None or eng["ws"].numel() < need):
+                    eng["ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+                    rp._drop_plan()
 
     def _check_pending_status(self):
         """The status words of a one-rank exchange plan whose read-back was left in flight (relabel_targeted_device, G = 1)."""
@@ -603,6 +609,21 @@ class ShardedStreamRunner:
             z = torch.zeros((0, NG), dtype=torch.float32, device=dev)
             return dict(E=0, B=B, nb=0, out_pos=z, out_neg=z.clone() if neg is not None else None, now=rp._now_host)
         self._check_pending_status()
+        if G == 1 and self.single_rank_pipeline and not rp.exact and src.is_cuda:
+            # ONE rank: every id is its own local row and nothing travels -- no exchange plan; the stream runs on the module's own
+            # schedules (the windowed pipeline from 16 batches on), which count ids out of range themselves (check_device_errors)
+            for name, o in (("out_pos", out_pos), ("out_neg", out_neg)):
+                if o is not None and (o.dtype != torch.float32 or o.device != dev or not o.is_contiguous() or tuple(o.shape) != (E, NG)):
+                    raise ValueError(f"{name} must be a contiguous float32 tensor of shape ({E}, {NG}) on {dev}")
+            if out_pos is None:
+                out_pos = torch.empty((E, NG), dtype=torch.float32, device=dev)
+            if neg is None:
+                out_neg = None
+            elif out_neg is None:
+                out_neg = torch.empty((E, NG), dtype=torch.float32, device=dev)
+            t_end = float(np.asarray(t_host_last, dtype=np.float64)[-1]) if t_host_last is not None else float(t[-1].item())
+            return dict(E=E, B=B, nb=nb, out_pos=out_pos, out_neg=out_neg, now=rp._now_host, ls=src, ld=dst, ln=neg, t=t,
+                        t_last=np.array([t_end], dtype=np.float64), windowed=True, comm=None, nccl=False)
         sig = self._stream_sig(src, dst, neg, t, E, B) if self.reuse_plans else None
         xc = self.__dict__.get("_xplan_cache")
         R = xc[1] if (sig is not None and xc is not None and xc[0] == sig) else None
@@ -735,7 +756,7 @@ class ShardedStreamRunner:
         rp, G, me = self.rp, self.G, self.me
         self.last_stream_windowed = False
         nb_ = (int(src.numel()) + int(batch_size) - 1) // int(batch_size)
-        if self.windowed and G > 1 and timing is None and nb_ >= self.windowed_min_batches and src.is_cuda:
+        if self.windowed and G > 1 and nb_ >= self.windowed_min_batches and src.is_cuda:
             # every rank takes the same decision: tpnet_wshard_plan declines on shapes (all ranks alike) or on counts that all ranks
             # derive from the same stream -- except a batch whose OWNED contributions overflow one rank's sort: agreed on below
             self._check_pending_status()
@@ -746,7 +767,8 @@ class ShardedStreamRunner:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
                 ok = bool(int(flag.item()))
             if ok:
-                return self.run_stream_windowed(src, dst, neg, t, batch_size, t_host_last, merge_outputs, out_pos, out_neg, plan=W)
+                return self.run_stream_windowed(src, dst, neg, t, batch_size, t_host_last, merge_outputs, out_pos, out_neg, plan=W,
+                                                timing=timing)
             if W is not None:
                 _lib.load().tpnet_wshard_destroy(W["handle"])
         ctx = self.prepare_targeted(src, dst, neg, t, batch_size, t_host_last, out_pos=out_pos, out_neg=out_neg,
@@ -888,7 +910,7 @@ class ShardedStreamRunner:
                     hstart=hstart, E=E, B=B, ws=ws, want_pos=want_pos, want_neg=want_neg)
 
     def run_stream_windowed(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True, out_pos=None,
-                            out_neg=None, comm="auto", plan=None):
+                            out_neg=None, comm="auto", plan=None, timing=None):
         """run_stream on the windowed pipeline (see the module's doc and csrc/wshard.hip): one launch + one exchange per window of
         batches.  Returns (feat_pos, feat_neg), or None where tpnet_wshard_plan does not serve the call (nothing has run then)."""
         rp, G, me = self.rp, self.G, self.me
@@ -921,9 +943,19 @@ class ShardedStreamRunner:
                 nccl = G > 1 and not self.detached and dist.get_backend(self.group) == "nccl"
                 comm = self._c_comm() if nccl else None
             if comm is not None or G == 1:
-                _lib.check(lib.tpnet_wshard_run(h, comm, op, on, lid, stream), "wshard_run")
+                if timing is not None:
+                    tot, la, xc = C.c_float(0), C.c_float(0), C.c_float(0)
+                    _lib.check(lib.tpnet_time_wshard_run(h, comm, op, on, lid, stream, C.byref(tot), C.byref(la), C.byref(xc)),
+                               "time_wshard_run")
+                    timing.update(total_ms=tot.value, step_ms=la.value, exchange_ms=xc.value, batches=W["nsteps"], windowed=True)
+                else:
+                    _lib.check(lib.tpnet_wshard_run(h, comm, op, on, lid, stream), "wshard_run")
             else:
-                self._wshard_run_gloo(W, op, on, lid, stream)
+                self._wshard_run_gloo(W, op, on, lid, stream, timing)
+            if timing is not None:
+                timing.update(windowed=True, launches=W["nsteps"], rows_sent_per_launch=float(W["send_cnt"].sum()) / W["nsteps"],
+                              rows_received_per_launch=float(W["recv_cnt"].sum()) / W["nsteps"],
+                              chunk_rows_sent=int(W["chunk_cnt"][me]) * (G - 1), chunk_rows_received=int(W["halo"]))
             if t_host_last is not None:
                 t_end = float(np.asarray(t_host_last, dtype=np.float64)[-1])
             else:
@@ -941,7 +973,7 @@ class ShardedStreamRunner:
                 dist.all_reduce(out_neg, group=self.group)
         return out_pos, out_neg
 
-    def _wshard_run_gloo(self, W, op, on, lid, stream):
+    def _wshard_run_gloo(self, W, op, on, lid, stream, timing=None):
         """The windowed shard's loop with the rows moved by torch.distributed (gloo in the tests; a process group without the C-side
         RCCL communicator): pack launches, an all-gather of the padded send buffers from which every rank takes its parts, unpack
         launches -- the same pack / unpack kernels and the same buffers as the RCCL loop."""
@@ -976,8 +1008,15 @@ class ShardedStreamRunner:
         smax = max(int(p[1].sum(axis=1).max()) for p in all_plans) or 1
         pad = torch.zeros((smax, d), dtype=torch.float32, device=dev)
         gath = [torch.empty_like(pad) for _ in range(G)]
+        cur = torch.cuda.current_stream(dev)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(W["nsteps"])] if timing is not None else None
         for j in range(W["nsteps"]):
-            _lib.check(lib.tpnet_wshard_step(h, None, j, PH_LAUNCH | PH_PACK, op, on, stream), "wshard_step")
+            if evs:
+                evs[j][0].record(cur)
+            _lib.check(lib.tpnet_wshard_step(h, None, j, PH_LAUNCH, op, on, stream), "wshard_step")
+            if evs:
+                evs[j][1].record(cur)
+            _lib.check(lib.tpnet_wshard_step(h, None, j, PH_PACK, op, on, stream), "wshard_step")
             if any(int(p[1][j].sum()) for p in all_plans):
                 ns = int(W["send_cnt"][j].sum())
                 pad[:ns].copy_(bufs["sendbuf"][:ns])
@@ -990,7 +1029,14 @@ class ShardedStreamRunner:
                         bufs["recvbuf"][ro:ro + c].copy_(gath[o][a0:a0 + c])
                     ro += c
                 _lib.check(lib.tpnet_wshard_step(h, None, j, PH_UNPACK, op, on, stream), "wshard_step")
+            if evs:
+                evs[j][2].record(cur)
         _lib.check(lib.tpnet_wshard_finish(h, lid, stream), "wshard_finish")
+        if evs:
+            evs[-1][2].synchronize()
+            n = len(evs)
+            timing.update(total_ms=evs[0][0].elapsed_time(evs[-1][2]), step_ms=sum(e[0].elapsed_time(e[1]) for e in evs) / n,
+                          exchange_ms=sum(e[1].elapsed_time(e[2]) for e in evs) / n, batches=n)
 
     def gather_full_layers(self):
         """All ranks' owned rows interleaved back into global order: [L+1, N, d] on every rank (tests / checkpoints of small
