@@ -53,7 +53,10 @@ typedef enum tpnet_status {
     TPNET_ERR_HIP = -3,         /* a HIP runtime call failed; tpnet_last_hip_error() has the hipError_t */
     TPNET_ERR_INDEX = -4,       /* a node id outside [0, N) was found (checked on device; such ids are skipped,
                                    never dereferenced) -- reported by tpnet_check_errors() */
-    TPNET_ERR_NO_DEVICE = -5
+    TPNET_ERR_NO_DEVICE = -5,
+    TPNET_ERR_NEED_GRAM = -6    /* tpnet_anchored_features / tpnet_encoder_features / tpnet_host_*: called with gram == NULL (allowed
+                                   where tpnet_encoder_fused_supported), but the one-launch kernel could not be launched on this
+                                   runtime: call again with a gram buffer (readout and dense layers then run as two launches) */
 } tpnet_status;
 
 /* 32-byte per-node record.  tref is kept per copy so that a launch rewriting a node never disturbs what a

@@ -1155,6 +1155,68 @@ def test_stream_with_no_negatives_at_all(d, L, N, B, nb, schedule):
     b.check_device_errors()
 
 
+@pytest.mark.parametrize("schedule", ["windowed", "batch"])
+@pytest.mark.parametrize("d,L,N,B,nb", [(128, 3, 500, 37, 40), (64, 2, 300, 50, 25), (256, 3, 2000, 1100, 6)])
+def test_every_optional_pointer_null_on_both_schedules(d, L, N, B, nb, schedule):
+    """tpnet_run_stream / tpnet_run_stream_tagged through the raw C ABI with each optional pointer NULL in turn, on BOTH schedules
+    (round 4's fault lived where only one schedule had been tried: `neg == NULL` on the pipeline): out_pos alone, out_neg alone,
+    neither (the update alone), neg + out_neg NULL, t_end_out NULL / given, tag NULL / given.  Every output that exists equals the
+    full run's bit for bit (batches > 1 024 edges on the per-batch schedule: 2e-5, the edge-fused update sums in another order when
+    the (src, dst) readout is missing), and so does the state; out_neg without neg is TPNET_ERR_BAD_ARG."""
+    import ctypes as C
+    from tpnet_amd import _lib
+    _need_gpu()
+    lib = _lib.load()
+    rng = np.random.RandomState(7 * d + B)
+    E = nb * B - B // 3
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    flag = {"windowed": _lib.FLAG_SCHED_WINDOWED, "batch": _lib.FLAG_SCHED_BATCH}[schedule]
+    NG = (2 * L + 2) ** 2
+
+    def run(pos, negs, with_neg_ids, t_out, tagged):
+        rp = _module(N, d, L, 2e-6, t[0], P0=P0)
+        rp._ensure_engine()
+        ws = rp._workspace(E, B, stream=True)
+        st = rp._state()
+        op = torch.full((E, NG), -7.0, device=DEV) if pos else None
+        on = torch.full((E, NG), -7.0, device=DEV) if negs else None
+        tv = C.c_double(-1.0)
+        tag = _lib.PlanTag() if tagged else None
+        args = [C.byref(st), ds.data_ptr(), dd.data_ptr(), dn.data_ptr() if with_neg_ids else None, dt.data_ptr(), E, B, float(t[0]),
+                2e-6, rp._next_launch_ids((E + B - 1) // B), flag, op.data_ptr() if pos else None, on.data_ptr() if negs else None,
+                ws.data_ptr(), ws.numel(), C.byref(tv) if t_out else None, rp._stream()]
+        rc = lib.tpnet_run_stream_tagged(*args, C.byref(tag) if tagged else None) if tagged is not None else lib.tpnet_run_stream(*args)
+        if rc == 0:
+            torch.cuda.synchronize()
+            rp._now_host = float(t[-1]); rp._params_valid = False; rp._now_dirty = True; rp._table_written()
+            if t_out:
+                assert tv.value == float(t[-1])
+            rp.check_device_errors()
+        return rc, op, on, (_layers(rp) if rc == 0 else None)
+
+    rc, fp, fn, lay = run(True, True, True, True, None)
+    assert rc == 0 and float(fp.min()) > -7.0 and float(fn.min()) > -7.0
+    fused = schedule == "batch" and B > 1024            # (the edge-fused update needs the (src, dst) readout in the same launch)
+    for pos, negs, ids, t_out, tagged in [(True, False, True, False, None), (False, True, True, True, None), (False, False, True, False, None),
+                                          (True, False, False, True, None), (False, False, False, False, None),
+                                          (True, True, True, False, True), (True, False, False, False, True), (False, False, True, True, True)]:
+        rc, op, on, lay2 = run(pos, negs, ids, t_out, tagged)
+        assert rc == 0, (pos, negs, ids, t_out, tagged, rc)
+        if pos:
+            assert torch.equal(op, fp), (pos, negs, ids)
+        if negs:
+            assert torch.equal(on, fn), (pos, negs, ids)
+        if fused and not pos:
+            np.testing.assert_allclose(lay2, lay, rtol=2e-5, atol=2e-5 * float(np.abs(lay).max()))
+        else:
+            np.testing.assert_array_equal(lay2, lay)
+    rc, _, _, _ = run(False, True, False, False, None)             # out_neg without neg
+    assert rc == -1
+
+
 @pytest.mark.parametrize("nb,d,N,B", [(15, 64, 500, 100), (16, 64, 500, 100), (60, 64, 500, 100),
                                       (20, 128, 9228, 1000)])     # (the driver's timed shape: C2, 20 batches)
 def test_auto_schedule_on_both_sides_of_its_threshold(nb, d, N, B):

@@ -21,6 +21,7 @@ FLAG_PLAN_HASHED = 128
 FLAG_NO_MFMA_READOUT = 256
 
 ERR_INDEX = -4
+ERR_NEED_GRAM = -6
 
 
 class NodeMeta(C.Structure):
@@ -175,6 +176,11 @@ class TPNetHipError(RuntimeError):
     pass
 
 
+class NeedGramBuffer(TPNetHipError):
+    """TPNET_ERR_NEED_GRAM: an encoder call without a feature buffer met a runtime that refuses the one-launch kernel -- the caller
+    retries once with a scratch buffer (readout and dense layers as two launches)."""
+
+
 def load():
     """Load libtpnet_hip.so (built by __graft_entry__.build() / tpnet_amd/csrc/Makefile).  Raises if absent."""
     global _lib
@@ -223,5 +229,7 @@ def check(rc: int, what: str = ""):
     msg = lib.tpnet_strerror(rc).decode()
     if rc == ERR_INDEX:
         raise IndexError(f"tpnet_hip {what}: {msg}")
+    if rc == ERR_NEED_GRAM:
+        raise NeedGramBuffer(f"tpnet_hip {what}: {msg}")
     extra = f" (hipError_t {lib.tpnet_last_hip_error()})" if rc == -3 else ""
     raise TPNetHipError(f"tpnet_hip {what}: {msg}{extra}")

@@ -359,6 +359,7 @@ const char* tpnet_strerror(int status) {
         case TPNET_ERR_HIP: return "HIP runtime error";
         case TPNET_ERR_INDEX: return "node id out of range";
         case TPNET_ERR_NO_DEVICE: return "no HIP device";
+        case TPNET_ERR_NEED_GRAM: return "the one-launch encoder kernel is not available: call again with a gram buffer";
         default: return "unknown status";
     }
 }

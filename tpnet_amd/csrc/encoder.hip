@@ -45,7 +45,7 @@ int tpnet_anchored_features(const tpnet_state* st, const int64_t* neigh, const i
     if (!(flags & TPNET_FLAG_NO_MFMA_READOUT) && encoder_fused_supported(*st, n_rows, K, mlp) &&
         launch_encoder_fused(*st, neigh, a1, a2, n_rows, K, now_time, lambda, flags, mlp, gram, out, (hipStream_t)stream) == TPNET_OK)
         return TPNET_OK;
-    if (!gram) return TPNET_ERR_BAD_ARG;
+    if (!gram) return TPNET_ERR_NEED_GRAM;             // (the fused launch was refused after the caller had been told it may pass NULL)
     if (!pair_gram_anchored_supported(*st)) return TPNET_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t F = 64;

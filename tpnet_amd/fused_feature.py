@@ -55,17 +55,25 @@ def _w2f_cols(dev):
 # rows from which the matrix-core backward serves a call: one launch + a sum of partials against ten small torch launches -- at the
 # decoder's 1 000 rows per call a training step went 704 -> 520-570 us (bench.py, dropin.train); below, the torch expressions
 MFMA_BWD_FROM = 512
+# "mfma" (default): weight gradients of self.mlp on the matrix cores from MFMA_BWD_FROM rows on -- two-piece bf16 operands, three
+# products per term, fp32 accumulation: ~2^-16 per PRODUCT (3-5e-6 of the terms' magnitude observed, 4e-5 allowed by the tests)
+# where the reference's fp32 GEMMs carry 2^-24; "torch": always the fp32 torch expressions (five GEMMs + three elementwise passes).
+# A module overrides the process-wide value with an attribute of the same name on its self.mlp (rp.mlp.mlp_backward = "torch").
+mlp_backward = "mfma"
+_declined_once = set()
 
 
-def weight_grads_f32(x, gy, w1, b1, w2, prep):
+def weight_grads_f32(x, gy, w1, b1, w2, prep, mode=None):
     """Gradients of (mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias) given the pre-mlp features x [n, 64] and the gradient
     gy [n, 64] of self.mlp's output, fp32 class.  Long lists (the encoder's calls: 80 000 rows each at C2) take ONE launch on the
     matrix cores (tpnet_mlp64_bwd_f32: hidden layer recomputed, both weight-gradient products contracted over the rows with
     two-piece bf16 operands and fp32 accumulation, one partial result per workgroup, summed in a fixed order) instead of five
     fp32 GEMMs and three elementwise passes over n x 256 floats; `prep` = the prepared() entry the forward used -- if a Parameter
-    changed since (never in a normal training step), or for short lists and CPU tensors, the torch expressions serve."""
+    changed since (never in a normal training step), or for short lists and CPU tensors, the torch expressions serve.
+    mode: "mfma" | "torch" (None: the module-level `mlp_backward`)."""
+    mode = mode or mlp_backward
     n = int(x.shape[0])
-    if (prep is not None and x.is_cuda and n >= MFMA_BWD_FROM and x.dtype == torch.float32 and prep[1].w1 and prep[1].w2t
+    if (mode == "mfma" and prep is not None and x.is_cuda and n >= MFMA_BWD_FROM and x.dtype == torch.float32 and prep[1].w1 and prep[1].w2t
             and prep[0][:6] == (w1.data_ptr(), w1._version, b1.data_ptr(), b1._version, w2.data_ptr(), w2._version)):
         lib = _lib.load()
         x = x.contiguous()
@@ -79,6 +87,10 @@ def weight_grads_f32(x, gy, w1, b1, w2, prep):
             tot = part[:rc].sum(0)
             H, F = w1.shape
             return tot[:H * F].view(H, F), tot[2 * H * F:2 * H * F + H], tot[H * F:2 * H * F].view(F, H), gy.sum(0)
+        if rc not in _declined_once:                    # (said once per code: the torch expressions below serve the call)
+            _declined_once.add(rc)
+            import warnings
+            warnings.warn(f"tpnet_mlp64_bwd_f32 declined a call of {n} rows (rc {rc}): weight gradients by the fp32 torch expressions")
     pre = torch.addmm(b1, x, w1.t())                 # fp32 recompute of the hidden layer
     hid = torch.relu(pre)
     gh = (gy @ w2) * (pre > 0)
@@ -89,7 +101,7 @@ class _MlpF32(torch.autograd.Function):
     """self.mlp alone on the fp32 matrix cores (tpnet_mlp64_f32); backward = weight_grads_f32."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, mlp_ref, prep=None):
+    def forward(ctx, x, w1, b1, w2, b2, mlp_ref, prep=None, mode=None):
         x = x.contiguous()
         y = torch.empty_like(x)
         if x.shape[0]:
@@ -99,6 +111,7 @@ class _MlpF32(torch.autograd.Function):
                 _lib.check(rc, "mlp64_f32")
         ctx.save_for_backward(x, w1, b1, w2)
         ctx.prep = prep
+        ctx.mode = mode
         return y
 
     @staticmethod
@@ -108,9 +121,9 @@ class _MlpF32(torch.autograd.Function):
             pre = torch.addmm(b1, x, w1.t())
             hid = torch.relu(pre)
             gh = (gy @ w2) * (pre > 0)
-            return gh @ w1, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None, None
-        gw1, gb1, gw2, gb2 = weight_grads_f32(x, gy, w1, b1, w2, ctx.prep)
-        return None, gw1, gb1, gw2, gb2, None, None
+            return gh @ w1, gh.t() @ x, gh.sum(0), gy.t() @ hid, gy.sum(0), None, None, None
+        gw1, gb1, gw2, gb2 = weight_grads_f32(x, gy, w1, b1, w2, ctx.prep, ctx.mode)
+        return None, gw1, gb1, gw2, gb2, None, None, None
 
 
 def mlp_f32(mlp, x):
@@ -121,7 +134,7 @@ def mlp_f32(mlp, x):
     if prep is None or not prep[1].w1:
         return None
     if needs_grad(prep[4]):
-        return _MlpF32.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, prep[2], prep)
+        return _MlpF32.apply(x, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, prep[2], prep, getattr(mlp, "mlp_backward", None))
     return _MlpF32.forward(_NoCtx(), x, None, None, None, None, prep[2])
 
 
@@ -144,7 +157,12 @@ def invalidate(mlp=None):
 def prepared(mlp, F):
     """(key, tpnet_mlp struct, its byref, keep-alive tensors) or None if `mlp` is not the reference's Linear-ReLU-Linear on
     a GPU: transposed f32 copies of the weights, rebuilt only when a parameter changed (optimizer step, load_state_dict,
-    .to()): keyed on (data_ptr, _version) of the four tensors."""
+    .to()): keyed on (data_ptr, _version) of the four tensors.
+    CONTRACT: the Parameters are updated through versioned ops (optimizer steps, copy_(), load_state_dict, .to()).  b1, b2 and
+    tpnet_mlp::w1 are the Parameters' OWN storage while w1t / w2t / w2f / wimg are derived copies, so a write that bumps no version
+    counter (p.data.clamp_(), a raw pointer) leaves a MIX of live and stale values until invalidate(mlp) is called; and the derived
+    buffers are rewritten in place on the CURRENT stream -- update the Parameters on the stream that runs the module's kernels (the
+    reference's loop has one stream)."""
     try:
         l1, l2 = mlp._modules["0"], mlp._modules["2"]
         p1, p2 = l1._parameters, l2._parameters      # (the dicts behind l1.weight ...: nn.Module.__getattr__ is ~0.4 us per read,
@@ -190,18 +208,19 @@ class _FusedFeature(torch.autograd.Function):
     """forward(w1, b1, w2, b2, launch): `launch(out_gram)` enqueues the fused kernel and returns the features."""
 
     @staticmethod
-    def forward(ctx, w1, b1, w2, b2, launch, n, F, prep=None):
+    def forward(ctx, w1, b1, w2, b2, launch, n, F, prep=None, mode=None):
         gram = torch.empty((n, F), dtype=torch.float32, device=w1.device)
         out = launch(gram)
         ctx.save_for_backward(gram, w1, b1, w2)
         ctx.prep = prep
+        ctx.mode = mode
         return out
 
     @staticmethod
     def backward(ctx, gy):
         x, w1, b1, w2 = ctx.saved_tensors
-        gw1, gb1, gw2, gb2 = weight_grads_f32(x, gy, w1, b1, w2, ctx.prep)
-        return gw1, gb1, gw2, gb2, None, None, None, None
+        gw1, gb1, gw2, gb2 = weight_grads_f32(x, gy, w1, b1, w2, ctx.prep, ctx.mode)
+        return gw1, gb1, gw2, gb2, None, None, None, None, None
 
 
 def needs_grad(keep_params) -> bool:
@@ -209,4 +228,5 @@ def needs_grad(keep_params) -> bool:
 
 
 def apply_with_grad(mlp, launch, n, F):
-    return _FusedFeature.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n, F, _PREPARED.get(mlp))
+    return _FusedFeature.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, launch, n, F, _PREPARED.get(mlp),
+                               getattr(mlp, "mlp_backward", None))

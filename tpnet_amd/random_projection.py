@@ -746,6 +746,11 @@ class RandomProjectionModule(nn.Module):
             return None
         NG = self.pair_wise_feature_dim
         flags = _lib.FLAG_NOT_SCALE if self.not_scale else 0
+        grad = _ff.needs_grad(prep[4])
+        if grad and int(lib.tpnet_host_encoder_pattern(src.ctypes.data, dst.ctypes.data, n, self.node_num)) < 4:
+            # (training: the cheap host check FIRST -- a declined call would already have allocated an n x 64 feature buffer and an
+            # autograd node over it, for the general path to do the same work again)
+            return None
         # ONE crossing (tpnet_host_anchored_features): pattern and range check, the neighbours + anchors staged through a pinned
         # ring of its own (4 slots of 1 MB, created at the first call of this kind; the kernel reads the slot, no copy is enqueued)
         # and the launch -- 82 us of host time per 80 000-pair call before (C check, two numpy reductions, a pinned copy and an
@@ -765,7 +770,10 @@ class RandomProjectionModule(nn.Module):
                 return out
             # (no backward pass: no feature buffer; the call declines -- served stays 0 -- where readout and dense layers are two
             # launches, and where the arrays are not the pattern or hold an id out of range: the path below then answers)
-            res = _ff.apply_with_grad(self.mlp, launch_host, n, NG) if _ff.needs_grad(prep[4]) else launch_host(None)
+            try:
+                res = _ff.apply_with_grad(self.mlp, launch_host, n, NG) if grad else launch_host(None)
+            except _lib.NeedGramBuffer:
+                res = launch_host(torch.empty((n, NG), dtype=torch.float32, device=eng["dev"]))
             if served.value >= 4:
                 return res
         K = int(lib.tpnet_host_encoder_pattern(src.ctypes.data, dst.ctypes.data, n, self.node_num))
@@ -781,9 +789,9 @@ class RandomProjectionModule(nn.Module):
                                                    float(self.time_decay_weight), flags, prep[2], _ptr_or_null(gram), out.data_ptr(),
                                                    _raw_stream(self._eng["dev_index"])), "anchored_features")
             return out
-        if _ff.needs_grad(prep[4]):
+        if grad:
             return _ff.apply_with_grad(self.mlp, launch, n, NG)
-        return launch(self._gram_buffer(m, K, prep, n, NG))
+        return self._launch_no_grad(launch, m, K, prep, n, NG)
 
     def pair_gram_anchored(self, neighbor_ids, first_anchor_ids, second_anchor_ids, matrix_cores=True):
         """The encoder's readout before self.mlp (models/TPNet.py:311-324): neighbor_ids [n, K] (the sampled neighbours of n
@@ -818,6 +826,14 @@ class RandomProjectionModule(nn.Module):
                                                 self._now_host, float(self.time_decay_weight), flags, out[0].data_ptr(),
                                                 out[1].data_ptr(), self._stream()), "pair_gram_anchored")
         return out
+
+    def _launch_no_grad(self, launch, n_rows, K, prep, n, NG):
+        """An encoder call without a backward pass: no feature buffer where readout and dense layers are one launch; if the runtime
+        refuses that launch after all (TPNET_ERR_NEED_GRAM), once more with a scratch buffer."""
+        try:
+            return launch(self._gram_buffer(n_rows, K, prep, n, NG))
+        except _lib.NeedGramBuffer:
+            return launch(torch.empty((n, NG), dtype=torch.float32, device=self._eng["dev"]))
 
     def _gram_buffer(self, n_rows, K, prep, n, NG):
         """Where the pre-mlp features of an encoder call go when no backward pass needs them: nowhere (None) if readout and dense
@@ -858,7 +874,7 @@ class RandomProjectionModule(nn.Module):
                     return out
                 if _ff.needs_grad(prep[4]):
                     return _ff.apply_with_grad(self.mlp, launch, 2 * n * K, NG)
-                return launch(self._gram_buffer(n, K, prep, 2 * n * K, NG))
+                return self._launch_no_grad(launch, n, K, prep, 2 * n * K, NG)
         g = self.pair_gram_anchored(neighbor_ids, first_anchor_ids, second_anchor_ids)
         return self._apply_mlp(g.view(-1, self.pair_wise_feature_dim))
 
@@ -915,7 +931,7 @@ class RandomProjectionModule(nn.Module):
                 return out
             if _ff.needs_grad(prep[4]):
                 return _ff.apply_with_grad(self.mlp, launch, 4 * B * K, NG), neigh
-            return launch(self._gram_buffer(2 * B, K, prep, 4 * B * K, NG)), neigh
+            return self._launch_no_grad(launch, 2 * B, K, prep, 4 * B * K, NG), neigh
         if host:
             s_d, o_d, t_d = self._to_device(self._check_ids(src_ids, "src_ids"), self._check_ids(other_ids, "other_ids"), times)
             return self.encoder_pair_features(sampler, s_d, o_d, t_d, num_neighbors)
