@@ -92,6 +92,10 @@ struct StreamArgs {
     float* out_neg;
     int32_t own_mod;   // row sharding: this rank computes targets / pairs (by their src node) with id % own_mod == own_rem
     int32_t own_rem;   // (own_mod = 1: everything; own_mod = 0: compact local table, the rank owns ids < own_rem)
+    // the windowed pipeline of a row shard (wshard.hip): the edges whose src node this rank owns, window by window (ascending): the
+    // readout role of window w walks own_list[own_start[w] .. own_start[w + 1]) instead of every edge of the window
+    const uint32_t* own_list = nullptr;
+    const uint32_t* own_start = nullptr;
 };
 
 // Launch geometry of the fast paths: LPP lanes cooperate on one row (one pair / one target), each lane owning VPL

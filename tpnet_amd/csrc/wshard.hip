@@ -22,6 +22,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include <dlfcn.h>
@@ -109,6 +110,21 @@ __global__ __launch_bounds__(256) void k_ws_relabel(const int64_t* __restrict__ 
     }
 }
 
+// ---- the edges whose src node this rank owns, in order (the readout role of a window walks its slice) ----------------------------
+struct WsOwnFlag {
+    const int64_t* lsrc;
+    int64_t n_owned;
+    __device__ uint32_t operator()(int64_t e) const { return lsrc[e] < n_owned ? 1u : 0u; }
+};
+__global__ __launch_bounds__(256) void k_ws_ownlist(const int64_t* __restrict__ lsrc, int64_t n_owned, int64_t E, int64_t Ew, int64_t nw,
+                                                    const uint32_t* __restrict__ rank /* [E + 1] exclusive scan of the flags */,
+                                                    uint32_t* __restrict__ own_list, uint32_t* __restrict__ own_start) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = gid; e < E; e += gsz)
+        if (lsrc[e] < n_owned) own_list[rank[e]] = (uint32_t)e;
+    for (int64_t w = gid; w <= nw; w += gsz) own_start[w] = rank[(w * Ew < E) ? w * Ew : E];
+}
+
 // ---- what travels ----------------------------------------------------------------------------------------------------------
 // item key: list (0 = this rank receives, 1 = it sends) | kind (0 = A: read as a partner row or by a readout, layers 1..L-1 travel;
 // 1 = B: read by a readout, layer L travels too) | window | peer | log slot
@@ -120,78 +136,119 @@ __device__ __host__ __forceinline__ unsigned long long ws_key(int list, int kind
 }
 
 struct WsNeed {
+    const int64_t* gsrc;                  // the call's GLOBAL ids: owner(n) = n % G (a lookup of the owner of a halo row through the
+    const int64_t* gdst;                  // by-value table of halo ranges was an indexed load from a stack copy per probe)
+    const int64_t* gneg;
     const int64_t* lsrc;
     const int64_t* ldst;
     const int64_t* lneg;
-    const NodeMeta* meta;
     int64_t E, B;
-    int32_t K, have_pos, have_neg;
-    uint32_t* want;                       // [2 E] per slot: bit 0 = item A emitted, bit 1 = item B emitted (this rank reads it)
-    unsigned long long* sa;               // [2 E] per slot: readers an A item was emitted for
-    unsigned long long* sb;               // [2 E] per slot: readers a B item was emitted for
-    unsigned long long* keys;             // [6 E] appended items (the rest stays ~0: sorted to the end)
+    int32_t K, have_pos, have_neg, G;
+    // marks, plain idempotent stores (no atomics: a hub's version is read by thousands of edges of a batch -- per-slot atomic masks
+    // were ~48 000 same-address returning atomics per plan on the hub's owner at G = 8, 145 us of the plan):
+    uint8_t* fa;                          // [2 E][G] slot x reader: another rank reads this rank's run (kind A)
+    uint8_t* fb;                          // [2 E][G] ... by one of its readouts (kind B)
+    uint8_t* wa;                          // [2 E] slot: this rank reads another rank's run: its owner + 1 (kind A)
+    uint8_t* wb;                          // [2 E] ... by one of its readouts (kind B)
+    uint16_t* ww;                         // [2 E] slot: the window of the run
+    unsigned long long* keys;             // [6 E] the items (k_ws_items)
     uint32_t* counter;
 };
 
-__device__ __forceinline__ void ws_emit(const WsNeed& a, bool pred, unsigned long long key) {
-    const unsigned long long m = __ballot(pred);
-    if (!m) return;
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(a.counter, (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1, 64);
-    if (pred) a.keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+// reader `r` reads node x (owner o) in its version before batch b (level 1: as a partner row of one of its targets; level 2: by one
+// of its readouts)
+__device__ __forceinline__ void ws_need(const WsNeed& a, const WsOwners& ow, const DView& D, bool live, int r, int o, int64_t x,
+                                        int64_t b, int level) {
+    if (!live || o == r || !(o == ow.me || r == ow.me)) return;
+    const uint2 m = D.m[b * D.Ns + x];
+    if (m.x == 0u) return;                                   // (the table's pre-chunk row: it came with the chunk's halo rows)
+    const uint32_t slot = D.basef[x] + m.x - 1u;
+    a.ww[slot] = (uint16_t)((m.y >> 16) / (uint32_t)a.K);
+    if (r == ow.me) {                                        // this rank reads another rank's run
+        a.wa[slot] = (uint8_t)(o + 1);
+        if (level == 2) a.wb[slot] = (uint8_t)(o + 1);
+    } else {                                                 // another rank reads this rank's run
+        a.fa[(size_t)slot * a.G + r] = 1;
+        if (level == 2) a.fb[(size_t)slot * a.G + r] = 1;
+    }
 }
 
-// reader `r` reads node x's version before batch b (level 1: as a partner row of one of its targets; level 2: by one of its readouts)
-__device__ __forceinline__ void ws_need(const WsNeed& a, const WsOwners& ow, const DView& D, const BatchDesc* __restrict__ desc,
-                                        bool live, int r, int64_t x, int64_t b, int level) {
-    bool eA = false, eB = false;
-    int list = 0;
-    uint32_t slot = 0, w = 0, peer = 0;
-    if (live) {
-        const int o = ws_owner(ow, x);
-        if (o != r && (o == ow.me || r == ow.me)) {
-            const uint2 m = D.m[b * D.Ns + x];
-            if (m.x > 0u) {                                  // (else: the table's pre-chunk row -- it came with the chunk's halo rows)
-                slot = D.basef[x] + m.x - 1u;
-                w = (m.y >> 16) / (uint32_t)a.K;
-                if (r == ow.me) {                            // this rank reads another rank's run
-                    list = 0;
-                    peer = (uint32_t)o;
-                    const uint32_t bits = level == 2 ? 3u : 1u;
-                    const uint32_t old = atomicOr(&a.want[slot], bits);
-                    eA = !(old & 1u);
-                    eB = level == 2 && !(old & 2u);
-                } else {                                     // another rank reads this rank's run
-                    list = 1;
-                    peer = (uint32_t)r;
-                    const unsigned long long bit = 1ull << r;
-                    eA = !(atomicOr(&a.sa[slot], bit) & bit);
-                    if (level == 2) eB = !(atomicOr(&a.sb[slot], bit) & bit);
-                }
+__global__ __launch_bounds__(256) void k_ws_needs(WsNeed a, WsOwners ow, DView D) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = a.lsrc[e], d = a.ldst[e];
+        const int64_t g = a.lneg ? a.lneg[e] : 0;
+        const int64_t b = e / a.B;
+        const int os = (int)((uint64_t)a.gsrc[e] % (uint32_t)ow.G), od = (int)((uint64_t)a.gdst[e] % (uint32_t)ow.G);
+        const int og = a.gneg ? (int)((uint64_t)a.gneg[e] % (uint32_t)ow.G) : 0;
+        ws_need(a, ow, D, true, os, od, d, b, 1);                          // target s, partner d   (models/TPNet.py:90-93)
+        ws_need(a, ow, D, true, od, os, s, b, 1);                          // target d, partner s   (models/TPNet.py:94-96)
+        ws_need(a, ow, D, a.have_pos != 0, os, od, d, b, 2);               // readout (s, d): the owner of s computes it
+        ws_need(a, ow, D, a.have_neg && a.lneg, os, og, g, b, 2);          // readout (s, neg)
+    }
+}
+
+// the marks -> items.  A thread takes 16 consecutive marks of both kinds (two 16-byte loads), a wave appends its items with ONE atomic
+// on the counter (a thread per mark was one atomic per 64 marks: ~45 000 same-address atomics per plan at G = 8, 66 us)
+__device__ __forceinline__ int ws_nonzero_bytes(uint4 v) {
+    int n = 0;
+    const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t x = q[k];
+        x |= x >> 4; x |= x >> 2; x |= x >> 1;               // bit 0 of every byte = the byte is non-zero
+        n += __popc(x & 0x01010101u);
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void k_ws_items(WsNeed a) {
+    const int64_t nslot = 2 * a.E;
+    const int64_t n_send = nslot * a.G;                      // marks of the send lists; behind them the nslot marks of the receive lists
+    const int64_t chunks_s = (n_send + 15) / 16, chunks_r = (nslot + 15) / 16;
+    const int64_t nchunk = chunks_s + chunks_r;
+    const int64_t per = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (nchunk + per - 1) / per;
+    const int lane = threadIdx.x & 63;
+    for (int64_t it = 0; it < rounds; ++it) {                // (every lane of a wave runs every round: the wave scans together)
+        const int64_t c = it * per + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
+        const bool send = c < chunks_s;
+        const int64_t i0 = send ? c * 16 : (c - chunks_s) * 16;
+        if (c < nchunk) {                                     // (the arrays are 256-byte aligned and padded: whole 16-byte loads)
+            va = *reinterpret_cast<const uint4*>((send ? a.fa : a.wa) + i0);
+            vb = *reinterpret_cast<const uint4*>((send ? a.fb : a.wb) + i0);
+        }
+        const int lim = (int)((send ? n_send : nslot) - i0 < 16 ? (send ? n_send : nslot) - i0 : 16);
+        const uint8_t* ba = reinterpret_cast<const uint8_t*>(&va);
+        const uint8_t* bb = reinterpret_cast<const uint8_t*>(&vb);
+        int cnt = 0;
+        if (c < nchunk) {
+            if (lim == 16) cnt = ws_nonzero_bytes(va) + ws_nonzero_bytes(vb);
+            else
+                for (int k = 0; k < lim; ++k) cnt += (ba[k] ? 1 : 0) + (bb[k] ? 1 : 0);
+        }
+        int inc = cnt;
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) {
+            const int v = __shfl_up(inc, o2, 64);
+            if (lane >= o2) inc += v;
+        }
+        const int total = __shfl(inc, 63, 64);
+        if (total == 0) continue;
+        uint32_t base = 0;
+        if (lane == 63) base = atomicAdd(a.counter, (uint32_t)total);
+        uint32_t at = (uint32_t)__shfl((int)base, 63, 64) + (uint32_t)(inc - cnt);
+        if (cnt > 0) {
+            for (int k = 0; k < lim; ++k) {
+                const uint32_t fa = ba[k], fb = bb[k];
+                if (!(fa | fb)) continue;
+                const int64_t i = i0 + k;
+                const uint32_t slot = send ? (uint32_t)(i / a.G) : (uint32_t)i;
+                const uint32_t w = a.ww[slot];
+                const int list = send ? 1 : 0;
+                if (fa) a.keys[at++] = ws_key(list, 0, w, send ? (uint32_t)(i % a.G) : fa - 1u, slot);
+                if (fb) a.keys[at++] = ws_key(list, 1, w, send ? (uint32_t)(i % a.G) : fb - 1u, slot);
             }
         }
-    }
-    ws_emit(a, eA, ws_key(list, 0, w, peer, slot));
-    ws_emit(a, eB, ws_key(list, 1, w, peer, slot));
-}
-
-__global__ __launch_bounds__(256) void k_ws_needs(WsNeed a, WsOwners ow, DView D, const BatchDesc* __restrict__ desc) {
-    const int64_t per = (int64_t)gridDim.x * blockDim.x;
-    const int64_t rounds = (a.E + per - 1) / per;
-    for (int64_t it = 0; it < rounds; ++it) {                // (every lane of a wave runs every round: ws_emit ballots)
-        const int64_t e = it * per + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool live = e < a.E;
-        const int64_t ec = live ? e : 0;
-        const int64_t s = a.lsrc[ec], d = a.ldst[ec];
-        const int64_t g = a.lneg ? a.lneg[ec] : 0;
-        const int64_t b = ec / a.B;
-        const int os = ws_owner(ow, s), od = ws_owner(ow, d);
-        ws_need(a, ow, D, desc, live, os, d, b, 1);                              // target s, partner d   (models/TPNet.py:90-93)
-        ws_need(a, ow, D, desc, live, od, s, b, 1);                              // target d, partner s   (models/TPNet.py:94-96)
-        ws_need(a, ow, D, desc, live && a.have_pos, os, d, b, 2);                // readout (s, d): the owner of s computes it
-        ws_need(a, ow, D, desc, live && a.have_neg && a.lneg, os, g, b, 2);      // readout (s, neg)
     }
 }
 
@@ -315,9 +372,10 @@ static size_t ws_scratch_bytes(int64_t n_cap, int32_t G, int64_t E, int64_t nb, 
     const size_t nq = (size_t)G * (size_t)n_cap + 1;
     const size_t cap = 6 * (size_t)E;
     const size_t nsteps = (size_t)nb + (size_t)L + 1;
-    return ws_al(nq) + ws_al(nq * 4) + 3 * ws_al((size_t)E * 8) + ws_al((size_t)n_cap * 8) + ws_al(2 * (size_t)E * 4) +
-           2 * ws_al(2 * (size_t)E * 8) + 2 * ws_al(cap * 8) + ws_al((4 * (size_t)nb * G + 1) * 4) + ws_al(2 * nsteps * G * 4) +
-           2 * ws_al(cap * 3 * 4) + ws_al((size_t)(G + 2) * 8) + ws_al(16) + ws_sort_tmp(cap, nq) + 1024;
+    return ws_al(nq) + ws_al(nq * 4) + 3 * ws_al((size_t)E * 8) + ws_al((size_t)n_cap * 8) + 2 * ws_al(2 * (size_t)E * G) +
+           2 * ws_al(2 * (size_t)E) + ws_al(4 * (size_t)E) + 2 * ws_al(cap * 8) + ws_al((4 * (size_t)nb * G + 1) * 4) + ws_al(2 * nsteps * G * 4) +
+           2 * ws_al(cap * 3 * 4) + ws_al((size_t)(G + 2) * 8) + ws_al(16) + ws_sort_tmp(cap, nq > (size_t)E + 1 ? nq : (size_t)E + 1) +
+           2 * ws_al(((size_t)E + 1) * 4) + ws_al(((size_t)nb + 2) * 4) + 1024;
 }
 
 extern "C" {
@@ -331,7 +389,7 @@ size_t tpnet_wshard_workspace_bytes(int64_t n_local, int32_t d, int32_t L, int64
 void tpnet_wshard_destroy(tpnet_wshard* w) { delete w; }
 
 // returns TPNET_OK and *out = the plan; or 1 = the windowed shard does not serve this call (the caller takes the per-batch shard);
-// or a negative tpnet_status.  Synchronises `stream` twice (the chunk's halo counts; the exchange lists' counts).
+// or a negative tpnet_status.  Synchronises `stream` three times (the chunk's halo counts; the number of items; the exchange lists' counts).
 int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* dst, const int64_t* neg, const double* t, int64_t E,
                       int64_t batch, int64_t N_global, int32_t G, int32_t me, int32_t n_owned, double now_time, double lambda,
                       uint32_t flags, int32_t want_pos, int32_t want_neg, void* workspace, size_t ws_bytes, void* stream,
@@ -379,9 +437,11 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
     int64_t* ldst = (int64_t*)take((size_t)E * 8);
     int64_t* lneg = (int64_t*)take((size_t)E * 8);
     w->pack_ids = (int64_t*)take((size_t)n_cap * 8);
-    uint32_t* want = (uint32_t*)take(2 * (size_t)E * 4);
-    unsigned long long* sa = (unsigned long long*)take(2 * (size_t)E * 8);
-    unsigned long long* sb = (unsigned long long*)take(2 * (size_t)E * 8);
+    uint8_t* fa = (uint8_t*)take(2 * (size_t)E * G);
+    uint8_t* fb = (uint8_t*)take(2 * (size_t)E * G);
+    uint8_t* wa = (uint8_t*)take(2 * (size_t)E);
+    uint8_t* wb = (uint8_t*)take(2 * (size_t)E);
+    uint16_t* ww = (uint16_t*)take(4 * (size_t)E);
     unsigned long long* keys = (unsigned long long*)take(cap * 8);
     unsigned long long* sorted = (unsigned long long*)take(cap * 8);
     uint32_t* off = (uint32_t*)take((4 * (size_t)nw * G + 1) * 4);
@@ -390,8 +450,11 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
     w->ent[1] = (uint32_t*)take(cap * 3 * 4);
     int64_t* cnt_dev = (int64_t*)take((size_t)(G + 2) * 8);
     uint32_t* status = (uint32_t*)take(16);
+    uint32_t* own_list = (uint32_t*)take(((size_t)E + 1) * 4);
+    uint32_t* erank = (uint32_t*)take(((size_t)E + 1) * 4);
+    uint32_t* own_start = (uint32_t*)take(((size_t)nw + 2) * 4);
     void* tmp = c;
-    size_t tmp_bytes = ws_sort_tmp(cap, nq);
+    size_t tmp_bytes = ws_sort_tmp(cap, nq > (size_t)E + 1 ? nq : (size_t)E + 1);
     if ((size_t)(c + tmp_bytes - reinterpret_cast<char*>(workspace)) > ws_bytes) return fail(TPNET_ERR_WORKSPACE);
 
     // ---- relabel: the chunk's touched nodes, one local id each
@@ -433,12 +496,22 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
     a.src = lsrc; a.dst = ldst; a.neg = neg ? lneg : nullptr; a.t = t;
     a.out_pos = nullptr; a.out_neg = nullptr;
     a.own_mod = 0; a.own_rem = n_owned;
+    {
+        // the rank's own edges (src node owned), in order, and every window's slice of them
+        size_t tb = tmp_bytes;
+        auto flags_it = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), WsOwnFlag{lsrc, (int64_t)n_owned});
+        if (rocprim::exclusive_scan(tmp, tb, flags_it, erank, 0u, (size_t)E + 1, rocprim::plus<uint32_t>(), s, false) != hipSuccess)
+            return fail(TPNET_ERR_HIP);
+        int g1 = (int)((E + 255) / 256);
+        if (g1 > 4096) g1 = 4096;
+        hipLaunchKernelGGL(k_ws_ownlist, dim3(g1), dim3(256), 0, s, lsrc, (int64_t)n_owned, E, w->p.Ew, nw, erank, own_list, own_start);
+        a.own_list = own_list;
+        a.own_start = own_start;
+    }
 
     // ---- what travels after every step: items, sorted; counts per (list, kind, window, peer)
-    TPNET_HIP_TRY(hipMemsetAsync(want, 0, 2 * (size_t)E * 4, s));
-    TPNET_HIP_TRY(hipMemsetAsync(sa, 0, 2 * (size_t)E * 8, s));
-    TPNET_HIP_TRY(hipMemsetAsync(sb, 0, 2 * (size_t)E * 8, s));
-    TPNET_HIP_TRY(hipMemsetAsync(keys, 0xFF, cap * 8, s));
+    // (fa .. wb are contiguous in the workspace: one fill)
+    TPNET_HIP_TRY(hipMemsetAsync(fa, 0, (size_t)(reinterpret_cast<char*>(ww) - reinterpret_cast<char*>(fa)), s));
     TPNET_HIP_TRY(hipMemsetAsync(status + 2, 0, 4, s));
     WsOwners ow{};
     ow.G = G; ow.me = me; ow.n_owned = n_owned;
@@ -446,18 +519,29 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
     const DView D = dview_of(w->p, E, batch, st->N);
     if (G > 1) {
         WsNeed nd{};
+        nd.gsrc = src; nd.gdst = dst; nd.gneg = neg;
         nd.lsrc = lsrc; nd.ldst = ldst; nd.lneg = neg ? lneg : nullptr;
-        nd.meta = reinterpret_cast<const NodeMeta*>(st->meta);
-        nd.E = E; nd.B = batch; nd.K = K; nd.have_pos = want_pos ? 1 : 0; nd.have_neg = want_neg ? 1 : 0;
-        nd.want = want; nd.sa = sa; nd.sb = sb; nd.keys = keys; nd.counter = status + 2;
+            nd.E = E; nd.B = batch; nd.K = K; nd.have_pos = want_pos ? 1 : 0; nd.have_neg = want_neg ? 1 : 0; nd.G = G;
+        nd.fa = fa; nd.fb = fb; nd.wa = wa; nd.wb = wb; nd.ww = ww; nd.keys = keys; nd.counter = status + 2;
         int g2 = (int)((E + 255) / 256);
-        if (g2 > 2048) g2 = 2048;
-        hipLaunchKernelGGL(k_ws_needs, dim3(g2), dim3(256), 0, s, nd, ow, D, (const BatchDesc*)w->p.base.desc);
-        size_t tb = tmp_bytes;
-        if (rocprim::radix_sort_keys(tmp, tb, keys, sorted, cap, 0u, (unsigned)(2 + WS_WIN_BITS + WS_PEER_BITS + WS_SLOT_BITS + 1), s, false) !=
-            hipSuccess)
+        if (g2 > 4096) g2 = 4096;
+        hipLaunchKernelGGL(k_ws_needs, dim3(g2), dim3(256), 0, s, nd, ow, D);
+        int64_t gi = ((2 * E * (G + 1) + 31) / 16 + 255) / 256;
+        if (gi > 8192) gi = 8192;
+        hipLaunchKernelGGL(k_ws_items, dim3((unsigned)gi), dim3(256), 0, s, nd);
+        // how many items there are sizes the sort (a sort of the 6 E slots the array has room for was 8 x the work at G = 8)
+        if (hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
             return fail(TPNET_ERR_HIP);
-        hipLaunchKernelGGL(k_ws_offsets, dim3((unsigned)((4 * nw * G + 256) / 256)), dim3(256), 0, s, sorted, (uint32_t)cap, nw, G, off);
+        if (hstat[1]) return fail(1);                                // a batch's owned contributions exceeded the sort: per batch
+        const uint32_t n_items = hstat[2];
+        if (n_items > cap) return fail(TPNET_ERR_WORKSPACE);
+        if (n_items > 0) {
+            size_t tb = tmp_bytes;
+            if (rocprim::radix_sort_keys(tmp, tb, keys, sorted, (size_t)n_items, 0u, (unsigned)(2 + WS_WIN_BITS + WS_PEER_BITS + WS_SLOT_BITS), s,
+                                         false) != hipSuccess)
+                return fail(TPNET_ERR_HIP);
+        }
+        hipLaunchKernelGGL(k_ws_offsets, dim3((unsigned)((4 * nw * G + 256) / 256)), dim3(256), 0, s, sorted, n_items, nw, G, off);
     } else {
         TPNET_HIP_TRY(hipMemsetAsync(off, 0, (4 * (size_t)nw * G + 1) * 4, s));
     }
@@ -466,7 +550,6 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
         hipMemcpyAsync(hstat, status, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return fail(TPNET_ERR_HIP);
     if (hstat[1]) return fail(1);                                    // a batch's owned contributions exceeded the sort: per batch
-    if (hstat[2] > cap) return fail(TPNET_ERR_WORKSPACE);
     auto cnt_of = [&](int list, int kind, int64_t ww, int peer) -> int64_t {
         if (ww < 0 || ww >= nw) return 0;
         const size_t q = ((size_t)(list * 2 + kind) * (size_t)nw + (size_t)ww) * (size_t)G + (size_t)peer;

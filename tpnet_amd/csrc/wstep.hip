@@ -809,28 +809,22 @@ __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpip
         const bool do_scale = !(flags & TPNET_FLAG_NOT_SCALE) && !packed;
         const int ostride = packed ? C::NT : C::NG;
         const int64_t e0 = w * P.Ew;
-        const int64_t ne = (Ec - e0 < P.Ew) ? Ec - e0 : P.Ew;
+        // (a row shard walks the list of the window's edges whose src node is its own: a rank of G would otherwise walk G times its share)
+        const int64_t l0 = SHARD ? (int64_t)a.own_start[w] : 0;
+        const int64_t ne = SHARD ? (int64_t)a.own_start[w + 1] - l0 : ((Ec - e0 < P.Ew) ? Ec - e0 : P.Ew);
         const int64_t npos = a.out_pos ? ne : 0;
         const int64_t nneg = a.out_neg ? ne : 0;
         const int64_t npairs = npos + nneg;
         const bool both = npos != 0 && nneg != 0;
-        const uint64_t own_lim = SHARD ? (uint64_t)(uint32_t)a.own_rem : ~0ull;     // (scalar: ids below it are this rank's)
-        (void)own_lim;
         for (int64_t base = (int64_t)rb * RGPB; base < npairs; base += (int64_t)nblk * RGPB) {
             const int64_t pw = base + rg;
-            const bool valid_ = pw < npairs;
+            const bool valid = pw < npairs;
             // (src,dst) and (src,neg) of one edge sit in adjacent lane groups: the src rows are fetched by the same instructions
-            const int64_t idx = valid_ ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
-            const bool isneg = valid_ && (both ? (pw & 1) != 0 : (pw >= npos));      // (a lane group past the list reads dst[e0]: `neg` may be null)
-            const int64_t e = e0 + idx;
+            const int64_t idx = valid ? (both ? (pw >> 1) : (pw < npos ? pw : pw - npos)) : 0;
+            const bool isneg = valid && (both ? (pw & 1) != 0 : (pw >= npos));      // (a lane group past the list reads dst[e0]: `neg` may be null)
+            int64_t e = e0 + idx;
+            if constexpr (SHARD) e = valid ? (int64_t)a.own_list[l0 + idx] : e0;
             int64_t ids[2] = {a.src[e], isneg ? a.neg[e] : a.dst[e]};
-            // row shard (own_mod = 0: local ids, rows < own_rem are this rank's): the pair belongs to the rank that owns its src node;
-            // a wave none of whose pairs is this rank's moves on
-            bool valid = valid_;
-            if constexpr (SHARD) {
-                valid = valid_ && (uint64_t)ids[0] < own_lim;
-                if (!__any(valid)) continue;
-            }
             const int which[2] = {0, isneg ? 2 : 1};
             float* out = (isneg ? a.out_neg : a.out_pos) + e * ostride;
             const bool idok = valid && (uint64_t)ids[0] < (uint64_t)S.N && (uint64_t)ids[1] < (uint64_t)S.N;
