@@ -183,7 +183,12 @@ __global__ __launch_bounds__(BS) void k_dense_sort_shard(WPlan p, WTmp q, DView 
         struct { uint32_t ckey[NC]; uint32_t cval[NC]; } c;
     } u;
     __shared__ uint32_t wsum[BS / 64];
-    static_assert(sizeof(U) <= 60 * 1024, "k_dense_sort_shard: LDS budget");
+    // halo nodes that are targets in this batch: a bitmap in LDS, written out as whole rows of the length matrix afterwards (14 000
+    // scattered 2-byte stores per batch otherwise); halo rows beyond HBITS * 32 (tables the dense planner does not reach anyway)
+    // fall back to the direct store
+    constexpr int HBITS = 2048;                            // 65 536 halo rows
+    __shared__ uint32_t hbits[HBITS];
+    static_assert(sizeof(U) + sizeof(uint32_t) * HBITS <= 62 * 1024, "k_dense_sort_shard: LDS budget");
     const int64_t bb = blockIdx.x;
     const int tid = threadIdx.x;
     const int64_t e0 = bb * a.Bfull;
@@ -193,7 +198,9 @@ __global__ __launch_bounds__(BS) void k_dense_sort_shard(WPlan p, WTmp q, DView 
     const double* __restrict__ t = a.t + e0;
     const int64_t g0 = 2 * e0;
     uint16_t* __restrict__ lenrow = D.len + bb * D.Ns;
-    for (int64_t n = tid; n < a.N; n += BS) lenrow[n] = 0;
+    for (int i = tid; i < HBITS; i += BS) hbits[i] = 0u;
+    const bool hfit = a.N - a.own <= (int64_t)HBITS * 32;
+    for (int64_t n = tid; n < (hfit ? a.own : a.N); n += BS) lenrow[n] = 0;
     __syncthreads();
     const double t_last = t[B - 1];
     const int nall = 2 * B;
@@ -214,12 +221,15 @@ __global__ __launch_bounds__(BS) void k_dense_sort_shard(WPlan p, WTmp q, DView 
             } else {
                 const int64_t tg = side ? dv : sv;
                 if (tg < a.own) { rk[k] = (uint32_t)tg; ++kept; }
-                else lenrow[tg] = 1;                         // a halo node is a target here: one slot (many writers, one value)
+                else if (hfit) atomicOr(&hbits[(tg - a.own) >> 5], 1u << ((tg - a.own) & 31));   // a halo node is a target here (LDS bitmap)
+                else lenrow[tg] = 1;
             }
         }
     }
     uint32_t total;
-    uint32_t off = block_excl_scan<BS>(kept, wsum, total);
+    uint32_t off = block_excl_scan<BS>(kept, wsum, total);   // (its barriers also publish the bitmap)
+    if (hfit)
+        for (int64_t n = a.own + tid; n < a.N; n += BS) lenrow[n] = (uint16_t)((hbits[(n - a.own) >> 5] >> ((n - a.own) & 31)) & 1u);
     if (total > (uint32_t)NC) {                              // (uniform) more owned contributions than the sort holds: the caller falls back
         if (tid == 0 && a.status) atomicAdd(a.status, 1u);
         total = NC;
