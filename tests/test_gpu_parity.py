@@ -1205,14 +1205,18 @@ def test_every_optional_pointer_null_on_both_schedules(d, L, N, B, nb, schedule)
                                           (True, True, True, False, True), (True, False, False, False, True), (False, False, True, True, True)]:
         rc, op, on, lay2 = run(pos, negs, ids, t_out, tagged)
         assert rc == 0, (pos, negs, ids, t_out, tagged, rc)
+        if fused and not pos:
+            # (without the (src, dst) readout the per-batch kernel's edge-fused update is off: the same sums in another order, so the
+            # state -- and every later batch's features -- agree to rounding, not to the bit)
+            if negs:
+                np.testing.assert_allclose(on.cpu().numpy(), fn.cpu().numpy(), rtol=1e-4, atol=2e-5)
+            np.testing.assert_allclose(lay2, lay, rtol=2e-5, atol=2e-5 * float(np.abs(lay).max()))
+            continue
         if pos:
             assert torch.equal(op, fp), (pos, negs, ids)
         if negs:
             assert torch.equal(on, fn), (pos, negs, ids)
-        if fused and not pos:
-            np.testing.assert_allclose(lay2, lay, rtol=2e-5, atol=2e-5 * float(np.abs(lay).max()))
-        else:
-            np.testing.assert_array_equal(lay2, lay)
+        np.testing.assert_array_equal(lay2, lay)
     rc, _, _, _ = run(False, True, False, False, None)             # out_neg without neg
     assert rc == -1
 

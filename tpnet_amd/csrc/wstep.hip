@@ -206,22 +206,41 @@ __device__ __forceinline__ void chain_light(const tpnet_state& S, const WPlan& P
 //   5. one group walks the completed runs in order: row = row * decay + run sum, stores every run's result.
 // Same association as chain_light.  Every loop bound is uniform over the workgroup (barriers inside).
 // ---------------------------------------------------------------------------------------------------------------
-struct HRec {             // a resolved contribution (16 bytes, LDS)
-    const float* row;     // partner's row of layer (layer-1), this unit's column part NOT yet applied
-    float w, gp;          // time weight, pending decay g^(layer-1)
+struct HRec {             // a resolved contribution (12 bytes, LDS; 16 until round 5: the pointer)
+    uint32_t row;         // partner's row of layer (layer-1), in rows of d floats of its array (0xFFFFFFFF: no contribution):
+                          // layer 1 -> p0; else the sign bit of w selects the version log (set) or the table's q array (clear)
+    float w, gp;          // time weight (>= 0: its sign bit is free), pending decay g^(layer-1)
 };
+static_assert(sizeof(HRec) == 12, "HRec must be 12 bytes");
+
+// partner_row as (row index, array): what chain_heavy parks in LDS -- 12 bytes per contribution instead of 16 let a segment hold 152
+// blocks of 8 in the LDS that held 128 (a C2 hub of ~1 050 contributions per 10-batch window is 135-140 blocks: ONE pass, not two)
+__device__ __forceinline__ uint32_t partner_row_index(const tpnet_state& S, int layer, int32_t pv, uint32_t ref, float g, float& gp,
+                                                      bool& in_log) {
+    const int L = S.L;
+    in_log = false;
+    if (layer == 1) {
+        gp = 1.0f;
+        return (uint32_t)pv;
+    }
+    gp = pow_rep(g, layer - 1);
+    if (ref & WREF_TABLE) return (uint32_t)((((int64_t)(ref & 1u) * S.N + pv) * L) + (layer - 2));
+    in_log = true;
+    return (uint32_t)((int64_t)(ref & WREF_SLOT_MASK) * L + (layer - 2));
+}
 
 template <int LPH>
 struct HeavyCfg {
     static constexpr int G = WB / LPH;                       // groups per workgroup
     static constexpr int PW = LPH * 4;                       // floats of a row one part covers
-    static constexpr int TSEG = 128;                         // tasks per segment (<= 1024 contributions)
+    // tasks per segment: what fits the LDS that 128 tasks of 16-byte records took (per task: 8 records + PW partial sums + 2 words)
+    static constexpr int TSEG = 128 * (8 * 4 + PW + 2) / (8 * 3 + PW + 2);
     static constexpr int HT = (TSEG + G - 1) / G < 4 ? (TSEG + G - 1) / G : 4;   // tasks a group has in flight
     // lds_u layout (32-bit words)
     static constexpr int O_START = 0, O_END = 64, O_DECP = 128 /* rank-indexed decay^layer */, O_TOFF = 192 /* [65] by bw */,
                          O_RLIST = 260 /* [64] */, O_NRUN = 324, O_RTOFF = 328 /* [65] by rank */, O_RSLOT = 396 /* [64] by rank */,
                          O_RSUM = 460 /* [64][PW] floats by rank */, O_REC = O_RSUM + 64 * PW /* HRec[TSEG*8] */,
-                         O_PART = O_REC + TSEG * WIN_BLOCK * 4 /* [TSEG][PW] floats */, O_TPOS = O_PART + TSEG * PW /* [TSEG] */,
+                         O_PART = O_REC + TSEG * WIN_BLOCK * 3 /* [TSEG][PW] floats */, O_TPOS = O_PART + TSEG * PW /* [TSEG] */,
                          O_TN = O_TPOS + TSEG /* [TSEG] */, WORDS = O_TN + TSEG;
 };
 
@@ -351,9 +370,10 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
             for (int q = 0; q < 4; ++q) {
                 const uint32_t x = x0 + (uint32_t)(q * WB + tid);
                 HRec r;
-                r.row = partner_row(S, P, layer, pv[q], ref[q], glog[q], r.gp);
-                r.w = w[q];
-                if (!in[q]) { r.row = nullptr; r.w = 0.0f; r.gp = 0.0f; }
+                bool in_log;
+                r.row = partner_row_index(S, layer, pv[q], ref[q], glog[q], r.gp, in_log);
+                r.w = in_log ? __uint_as_float(__float_as_uint(w[q]) | 0x80000000u) : w[q];
+                if (!in[q]) { r.row = 0xFFFFFFFFu; r.w = 0.0f; r.gp = 0.0f; }
                 if (x < (Tend - T0) * WIN_BLOCK) rec[x] = r;
             }
         }
@@ -372,10 +392,11 @@ __device__ __forceinline__ void chain_heavy(const tpnet_state& S, const WPlan& P
 #pragma unroll
                 for (int k = 0; k < WIN_BLOCK; ++k) {
                     const HRec q = rr[k];
-                    ok[k] = act[h] && q.row != nullptr;
-                    w[k] = q.w;
+                    ok[k] = act[h] && q.row != 0xFFFFFFFFu;
+                    w[k] = __uint_as_float(__float_as_uint(q.w) & 0x7FFFFFFFu);
                     gp[k] = q.gp;
-                    ldv_pred<4>(ok[k] ? q.row : S.p0, vi, ok[k] && vok, r[k]);
+                    const float* rbase = layer == 1 ? S.p0 : ((__float_as_uint(q.w) & 0x80000000u) ? P.log : S.q);
+                    ldv_pred<4>(ok[k] ? rbase + (int64_t)q.row * d : S.p0, vi, ok[k] && vok, r[k]);
                 }
 #pragma unroll
                 for (int x = 0; x < 4; ++x) sb[h][x] = 0.0f;
