@@ -214,6 +214,13 @@ int tpnet_mlp_prepare_image(const float* w1, const float* b1, const float* w2, c
  * A stage serves ONE calling thread and one device (the reference's loop is single-threaded under the GIL). */
 typedef struct tpnet_stage tpnet_stage;
 int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out);
+/* (ABI 7) where the ring lives: mode 0 = pinned, device-mapped HOST memory (tpnet_stage_create: the kernels read the ids over PCIe,
+ * one more ~2-us round trip at the head of every kernel's chain of dependent loads); 1 = DEVICE memory that the host writes through
+ * the large BAR (fine-grained; +~1.6 us of host stores per 16 KB call, a local read at the head of the kernels; TPNET_ERR_NO_DEVICE
+ * without a large BAR); -1 = 1 where the device has a large BAR, else 0.  Meant for the small per-batch ring: host stores through
+ * the BAR run at ~7 GB/s. */
+int tpnet_stage_create_ex(int32_t slots, size_t slot_bytes, int32_t mode, tpnet_stage** out);
+int tpnet_stage_in_device_memory(const tpnet_stage* stage);
 int tpnet_stage_destroy(tpnet_stage* stage);
 /* largest n / B the host entry points accept for a stage (slot_bytes / 16, slot_bytes / 24 capped at 2048) */
 int64_t tpnet_stage_max_pairs(const tpnet_stage* stage);

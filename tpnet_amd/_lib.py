@@ -126,6 +126,8 @@ SIGNATURES = {
     "tpnet_mlp_prepare_image": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "tpnet_mlp_prepare": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "tpnet_stage_create": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(_P)]),
+    "tpnet_stage_create_ex": (C.c_int, [C.c_int32, C.c_size_t, C.c_int32, C.POINTER(_P)]),
+    "tpnet_stage_in_device_memory": (C.c_int, [_P]),
     "tpnet_stage_destroy": (C.c_int, [_P]),
     "tpnet_stage_max_pairs": (C.c_int64, [_P]),
     "tpnet_stage_max_batch": (C.c_int64, [_P]),

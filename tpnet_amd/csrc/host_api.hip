@@ -13,8 +13,9 @@
 #include <new>
 
 struct tpnet_stage {
-    char* base = nullptr;        // hipHostMalloc'ed (mapped, portable)
+    char* base = nullptr;        // hipHostMalloc'ed (mapped, portable) -- or, device_memory: DEVICE memory the host writes through the BAR
     char* dev_base = nullptr;    // its device address
+    bool device_memory = false;
     size_t slot_bytes = 0;
     int32_t n_slots = 0;
     int32_t pos = 0;             // the slot being filled
@@ -52,6 +53,12 @@ static int stage_acquire(tpnet_stage* sg, size_t bytes, hipStream_t s, char** ho
     return TPNET_OK;
 }
 
+// the host has written a call's arrays: a ring in device memory was written through write-combining stores, which must have left the
+// core before the launch's doorbell is rung
+static inline void stage_written(const tpnet_stage* sg) {
+    if (sg->device_memory) __builtin_ia32_sfence();
+}
+
 // the launches that read `bytes` from the acquired address are enqueued on s
 static int stage_release(tpnet_stage* sg, size_t bytes, hipStream_t s) {
     sg->off += (bytes + 255) / 256 * 256;
@@ -78,30 +85,49 @@ using namespace tpnet;
 
 extern "C" {
 
-int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out) {
-    if (!out || slots < 2 || slots > 1024 || slot_bytes < 64) return TPNET_ERR_BAD_ARG;
+// mode: 0 = pinned, device-mapped host memory (the kernels read the ids over PCIe: one more ~2-us round trip at the head of every
+// kernel's dependent chain); 1 = device memory that the host writes through the large BAR (fine-grained: the kernels read what the
+// host wrote, not a stale cache line; +~1.6 us of host time per 16 KB call, -~1.5 us at the head of every kernel that reads a slot);
+// -1 = 1 where the device has a large BAR, else 0
+int tpnet_stage_create_ex(int32_t slots, size_t slot_bytes, int32_t mode, tpnet_stage** out) {
+    if (!out || slots < 2 || slots > 1024 || slot_bytes < 64 || mode < -1 || mode > 1) return TPNET_ERR_BAD_ARG;
     *out = nullptr;
     tpnet_stage* sg = new (std::nothrow) tpnet_stage();
     if (!sg) return TPNET_ERR_BAD_ARG;
     sg->slot_bytes = (slot_bytes + 255) / 256 * 256;
     sg->n_slots = slots;
     void* mem = nullptr;
-    if (hipHostMalloc(&mem, sg->slot_bytes * (size_t)slots, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
-        delete sg;
-        return TPNET_ERR_HIP;
+    bool bar = false;
+    if (mode != 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.isLargeBar) bar = true;
+        if (mode == 1 && !bar) { delete sg; return TPNET_ERR_NO_DEVICE; }
     }
-    sg->base = reinterpret_cast<char*>(mem);
-    void* dptr = nullptr;
-    if (hipHostGetDevicePointer(&dptr, mem, 0) != hipSuccess) { (void)hipHostFree(mem); delete sg; return TPNET_ERR_HIP; }
-    sg->dev_base = reinterpret_cast<char*>(dptr);
+    if (bar && hipExtMallocWithFlags(&mem, sg->slot_bytes * (size_t)slots, hipDeviceMallocFinegrained) == hipSuccess) {
+        sg->device_memory = true;
+        sg->base = reinterpret_cast<char*>(mem);
+        sg->dev_base = sg->base;
+    } else {
+        if (mode == 1) { delete sg; return TPNET_ERR_HIP; }
+        if (hipHostMalloc(&mem, sg->slot_bytes * (size_t)slots, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            delete sg;
+            return TPNET_ERR_HIP;
+        }
+        sg->base = reinterpret_cast<char*>(mem);
+        void* dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, mem, 0) != hipSuccess) { (void)hipHostFree(mem); delete sg; return TPNET_ERR_HIP; }
+        sg->dev_base = reinterpret_cast<char*>(dptr);
+    }
+    auto free_mem = [&]() { if (sg->device_memory) (void)hipFree(mem); else (void)hipHostFree(mem); };
     sg->ev = new (std::nothrow) hipEvent_t[slots];
     sg->used = new (std::nothrow) bool[slots];
-    if (!sg->ev || !sg->used) { (void)hipHostFree(mem); delete[] sg->ev; delete[] sg->used; delete sg; return TPNET_ERR_BAD_ARG; }
+    if (!sg->ev || !sg->used) { free_mem(); delete[] sg->ev; delete[] sg->used; delete sg; return TPNET_ERR_BAD_ARG; }
     for (int i = 0; i < slots; ++i) {
         sg->used[i] = false;
         if (hipEventCreateWithFlags(&sg->ev[i], hipEventDisableTiming) != hipSuccess) {
             for (int j = 0; j < i; ++j) (void)hipEventDestroy(sg->ev[j]);
-            (void)hipHostFree(mem);
+            free_mem();
             delete[] sg->ev; delete[] sg->used; delete sg;
             return TPNET_ERR_HIP;
         }
@@ -110,6 +136,10 @@ int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out) {
     return TPNET_OK;
 }
 
+int tpnet_stage_create(int32_t slots, size_t slot_bytes, tpnet_stage** out) { return tpnet_stage_create_ex(slots, slot_bytes, 0, out); }
+
+int tpnet_stage_in_device_memory(const tpnet_stage* sg) { return (sg && sg->device_memory) ? 1 : 0; }
+
 int tpnet_stage_destroy(tpnet_stage* sg) {
     if (!sg) return TPNET_OK;
     if (sg->open) (void)hipDeviceSynchronize();          // launches of the slot being filled: no event covers them yet
@@ -117,7 +147,8 @@ int tpnet_stage_destroy(tpnet_stage* sg) {
         if (sg->used[i]) (void)hipEventSynchronize(sg->ev[i]);
         (void)hipEventDestroy(sg->ev[i]);
     }
-    (void)hipHostFree(sg->base);
+    if (sg->device_memory) (void)hipFree(sg->base);
+    else (void)hipHostFree(sg->base);
     delete[] sg->ev;
     delete[] sg->used;
     delete sg;
@@ -153,6 +184,7 @@ int tpnet_host_pair_feature(const tpnet_state* st, tpnet_stage* stage, const int
     if (rc) return rc;
     int64_t* hu = reinterpret_cast<int64_t*>(host);
     if (!copy_ids(hu, h_u, n, st->N) || !copy_ids(hu + n, h_v, n, st->N)) return TPNET_ERR_INDEX;   // nothing consumed
+    stage_written(stage);
     const int64_t* du = reinterpret_cast<const int64_t*>(dev);
     if (mlp)
         rc = launch_pair_feature(*st, du, du + n, n, now_time, lambda, flags, *mlp, out_gram, out, s);
@@ -183,6 +215,7 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
         int64_t* hs = reinterpret_cast<int64_t*>(host);
         if (!copy_ids(hs, h_src, B, st->N) || !copy_ids(hs + B, h_dst, B, st->N)) return TPNET_ERR_INDEX;
         memcpy(hs + 2 * B, h_t, (size_t)B * 8);
+        stage_written(stage);
         int64_t* d = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(workspace) + pb);
         TPNET_HIP_TRY(hipMemcpyAsync(d, host, (size_t)B * 24, hipMemcpyHostToDevice, s));
         rc = stage_release(stage, (size_t)B * 24, s);
@@ -200,6 +233,7 @@ int tpnet_host_update(const tpnet_state* st, tpnet_stage* stage, const int64_t* 
     int64_t* hs = reinterpret_cast<int64_t*>(host);
     if (!copy_ids(hs, h_src, B, st->N) || !copy_ids(hs + B, h_dst, B, st->N)) return TPNET_ERR_INDEX;
     memcpy(hs + 2 * B, h_t, (size_t)B * 8);
+    stage_written(stage);
     const int64_t* ds = reinterpret_cast<const int64_t*>(dev);
     rc = plan_one(*st, p, ds, ds + B, reinterpret_cast<const double*>(ds + 2 * B), B, now_time, lambda, flags, s);
     if (rc) return rc;
@@ -231,6 +265,7 @@ int tpnet_host_encoder_features(const tpnet_state* st, tpnet_stage* stage, const
         hs[B + i] = h_other[i];
     }
     memcpy(hs + 2 * B, h_t, (size_t)B * 8);
+    stage_written(stage);
     const int64_t* ds = reinterpret_cast<const int64_t*>(dev);
     rc = tpnet_encoder_features(st, sampler, E, num_nodes, ds, ds + B, reinterpret_cast<const double*>(ds + 2 * B), B, K, now_time,
                                 lambda, flags, mlp, scratch, scratch_bytes, gram, out, stream);
@@ -344,6 +379,7 @@ int tpnet_host_anchored_features(const tpnet_state* st, tpnet_stage* stage, cons
     if (rc) return rc;
     int64_t* hn = reinterpret_cast<int64_t*>(host);
     if (pattern_and_stage(h_src, h_dst, n, st->N, hn, K, hn + h, hn + h + m) == 0) return TPNET_OK;   // an id out of range: general path
+    stage_written(stage);
     const int64_t* dn = reinterpret_cast<const int64_t*>(dev);
     rc = tpnet_anchored_features(st, dn, dn + h, dn + h + m, m, (int32_t)K, now_time, lambda, flags, mlp, gram, out, stream);
     if (rc) return rc;

@@ -30,6 +30,10 @@ _MAX_LAUNCH_ID = 0x7FFFFFFF - (1 << 24)
 
 # the current stream's raw handle without building a torch.cuda.Stream object (the hot methods need it every call)
 _BIG_SLOT_BYTES = 1 << 20      # one encoder call from host arrays: up to 100 000 neighbour ids + their anchors
+# where the per-batch staging ring of the host-array calls lives (tpnet_stage_create_ex): -1 = device memory written through the
+# large BAR where the device has one (the kernels' first loads are local: ~1.5 us less at the head of each of a batch's three
+# kernels, ~1.6 us more host time per call -- the per-batch loop is GPU-bound), 0 = pinned host memory, 1 = device memory or fail
+STAGE_MODE = -1
 
 
 def _ptr_or_null(t):
@@ -73,11 +77,11 @@ class _Stage:
     """The pinned, device-mapped staging ring of the host-array entry points (tpnet_stage_*): 8 slots of 256 KB, i.e. up to
     16 384 pairs or one batch of up to 2 048 edges per call.  The only thing the C library allocates; freed with the engine."""
 
-    def __init__(self, lib, dev, slots: int = 8, slot_bytes: int = 256 * 1024):
+    def __init__(self, lib, dev, slots: int = 8, slot_bytes: int = 256 * 1024, mode: int = 0):
         self._lib = lib
         h = C.c_void_p()
         with torch.cuda.device(dev):
-            _lib.check(lib.tpnet_stage_create(slots, slot_bytes, C.byref(h)), "stage_create")
+            _lib.check(lib.tpnet_stage_create_ex(slots, slot_bytes, int(mode), C.byref(h)), "stage_create")
         self.handle = h
         self.max_pairs = int(lib.tpnet_stage_max_pairs(h))
         self.max_batch = int(lib.tpnet_stage_max_batch(h))      # batches planned by one workgroup, read straight from the slot
@@ -241,8 +245,9 @@ class RandomProjectionModule(nn.Module):
                 q = torch.empty(lib.tpnet_q_bytes(N, d, L) // 4, dtype=torch.float32, device=dev)
                 meta = torch.empty(lib.tpnet_meta_bytes(N), dtype=torch.uint8, device=dev)
                 err = torch.zeros(4, dtype=torch.int32, device=dev)
+            # (the per-batch ring in device memory behind the large BAR where there is one: STAGE_MODE, tpnet_stage_create_ex)
             self._eng = dict(dev=dev, dev_index=dev.index if dev.index is not None else torch.cuda.current_device(), q=q,
-                             meta=meta, err=err, ws=None, stage=_Stage(lib, dev))
+                             meta=meta, err=err, ws=None, stage=_Stage(lib, dev, mode=STAGE_MODE))
             if dev not in _WARMED:
                 # once per process and device: the HIP runtime's first-use costs are paid here, not inside the first long
                 # call -- a burst of launches behind a busy kernel, then ONE synchronise (tools/first_call.py, first 20-batch
