@@ -116,6 +116,79 @@ def run(G, reps=4):
     return row
 
 
+def run_batch(G, reps=4):
+    """The same stream on the PER-BATCH shard (tpnet_pack_split + tpnet_step_batch per batch, rows moved by plain copies): the plan
+    of a call (exchange plan + per-batch plan of the kernels, wall clock) and the launches, per rank."""
+    Bg = B1 * G
+    E = nbt * Bg
+    src, dst, t, N = synthetic_stream(cfg["U"], cfg["I"], E, cfg["span"] * E / cfg["E"], seed=0)
+    neg = synthetic_negatives(cfg["U"], N, E, Bg, seed=1)
+    D = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, t)]
+    runs = [ShardedStreamRunner.create(node_num=N, edge_num=cfg["E"], dim=d, num_layer=L, time_decay_weight=cfg["lam"], device=dev,
+                                       beginning_time=np.float64(0.0), halo_rows=3 * Bg, seed=r, world=G, rank=r) for r in range(G)]
+    for r_ in runs:
+        r_.reuse_plans = False
+    res = []
+    nb = nbt
+    for rep in range(reps):
+        for r in range(G):
+            runs[r].rp.reset_random_projections()
+        torch.cuda.synchronize()
+        plan_us, cb = [], []
+        for r in range(G):
+            t0 = time.perf_counter()
+            c = runs[r].prepare_targeted(*D, Bg, comm=None)
+            torch.cuda.synchronize()
+            plan_us.append((time.perf_counter() - t0) * 1e6)
+            cb.append(c)
+        k_us = np.zeros(G); x_us = np.zeros(G)
+        for b in range(nb):
+            now = cb[0]["now"] if b == 0 else float(cb[0]["t_last"][b - 1])
+            for r in range(G):
+                c = cb[r]
+                e0, e1 = ev(), ev()
+                e0.record()
+                _lib.check(lib.tpnet_pack_split(C.byref(c["st"]), c["R"]["pack_ids"].data_ptr() + 8 * int(c["sstart"][b]), int(c["stot"][b]), now,
+                                                c["lam"], c["send_p0"].data_ptr(), c["send_q"].data_ptr(), runs[r].n_cap, int(c["rtot"][b]),
+                                                c["stream"]), "pack_split")
+                e1.record()
+                torch.cuda.synchronize()
+                x_us[r] += e0.elapsed_time(e1) * 1e3
+            for r in range(G):
+                c = cb[r]
+                rp = runs[r].rp
+                n_cap = runs[r].n_cap
+                ro = 0
+                for o in range(G):
+                    n = int(c["rcnt"][b][o])
+                    if n:
+                        a0 = int(cb[o]["scnt"][b][:r].sum())
+                        rp._plist()[0].data[n_cap + ro:n_cap + ro + n].copy_(cb[o]["send_p0"][a0:a0 + n])
+                        rp._eng["q"].view(2, rp.node_num, L * d)[0, n_cap + ro:n_cap + ro + n].copy_(cb[o]["send_q"][a0:a0 + n])
+                    ro += n
+            for r in range(G):
+                c = cb[r]
+                e0, e1 = ev(), ev()
+                e0.record()
+                _lib.check(lib.tpnet_step_batch(C.byref(c["st"]), c["ls"].data_ptr(), c["ld"].data_ptr(), c["ln"].data_ptr(), c["t"].data_ptr(),
+                                                E, Bg, b, c["lam"], c["lid0"] + b, c["flags"], 0, runs[r].n_cap, c["out_pos"].data_ptr(),
+                                                c["out_neg"].data_ptr(), c["ws"].data_ptr(), c["ws"].numel(), c["stream"]), "step_batch")
+                e1.record()
+                torch.cuda.synchronize()
+                k_us[r] += e0.elapsed_time(e1) * 1e3
+        for r in range(G):
+            runs[r].finish_targeted(cb[r], merge_outputs=False)
+        sent = max(float(c["stot"].sum()) for c in cb)
+        if rep >= 1:
+            res.append((max(plan_us), k_us.max(), x_us.max(), sent))
+    med = lambda i: float(np.median([x[i] for x in res]))
+    gpu = med(1) + med(2)
+    bytes_call = med(3) * (L + 1) * d * 4
+    links = max(1, min(G - 1, 7))
+    return dict(G=G, Bg=Bg, plan_us=med(0), step_us=med(1), pack_us=med(2), rows_sent=med(3), kern=nbt * Bg / (gpu * 1e-6),
+                comp=nbt * Bg / ((gpu + med(0)) * 1e-6), wire=bytes_call / (links * 153e9) * 1e6)
+
+
 print(f"# {nbt} batches of {B1} edges per GPU, {cfg['desc']}; every figure the slowest of the G ranks, median of 3 runs")
 print("| G | global batch | launches | plan (wall, us) | k_wpipe launches (us) | pack + unpack (us) | rows sent per rank | halo rows | per launch (us) | edges/s, kernels only | edges/s incl. plan | wire time at 153 GB/s per link (us) |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|")
@@ -129,3 +202,14 @@ for G in (1, 2, 4, 8):
     r = run(G)
     print(f"| {r['G']} | {r['Bg']} | {r['launches']} | {r['plan_us']:.0f} | {r['pipeline_us']:.0f} | {r['pack_unpack_us']:.0f} | {r['rows_sent']:.0f} | "
           f"{r['halo_rows']:.0f} | {r['per_launch']} | {r['edges_per_s_kernels'] / 1e6:.1f} M | {r['edges_per_s_compute'] / 1e6:.1f} M | {r['wire_us_at_xgmi']:.0f} |", flush=True)
+
+print()
+print(f"# the same stream on the PER-BATCH shard (pack + k_step per batch; {nbt} exchanges per call instead of the pipeline's launches)")
+print("| G | global batch | plan (wall, us) | k_step launches (us) | pack launches (us) | rows sent per rank (whole bundles) | edges/s, kernels only | edges/s incl. plan | wire time at 153 GB/s per link (us) |")
+print("|---|---|---|---|---|---|---|---|---|")
+for G in (2, 4, 8):
+    if ONLY and int(ONLY) != G:
+        continue
+    r = run_batch(G)
+    print(f"| {r['G']} | {r['Bg']} | {r['plan_us']:.0f} | {r['step_us']:.0f} | {r['pack_us']:.0f} | {r['rows_sent']:.0f} | {r['kern'] / 1e6:.1f} M | "
+          f"{r['comp'] / 1e6:.1f} M | {r['wire']:.0f} |", flush=True)
