@@ -149,6 +149,21 @@ def main():
             (4, 400, 256, 3, 1700, 100, 1e-6), (2, 9228, 128, 3, 20 * 2000, 2000, 1e-6)]
     if os.environ.get("TPNET_WSHARD_ONE"):
         cfgs = cfgs[:1]
+    if os.environ.get("TPNET_WSHARD_RANDOM"):              # "cases,seed": random shapes instead (a development soak, not the test)
+        ncase, seed = (int(x) for x in os.environ["TPNET_WSHARD_RANDOM"].split(","))
+        rg = np.random.RandomState(seed)
+        cfgs = []
+        while len(cfgs) < ncase:
+            G = int(rg.choice([2, 2, 3, 4, 5, 8]))
+            B = int(rg.choice([8, 37, 100, 257, 1000]))
+            nbr = int(rg.randint(4, 40))
+            N = int(rg.choice([60, 211, 1000, 5000]))
+            d = int(rg.choice([32, 64, 128, 256, 120]))
+            L = int(rg.choice([1, 2, 3, 3, 4]))
+            if (N // G + N) * 12 > B * L * d * 4:          # (the dense planner must reach the shard's table: else the call is declined)
+                continue
+            cfgs.append((G, N, d, L, max(4 * B, nbr * B - int(rg.randint(0, B))), B, float(rg.choice([1e-6, 2e-6, 1e-7]))))
+        print("random shapes:", cfgs, flush=True)
     lib = _lib.load()
     so = os.path.join(HERE, "librccl_loopback.so").encode()
     dev = torch.device("cuda:0")
