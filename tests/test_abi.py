@@ -62,6 +62,25 @@ def test_stream_workspace_sizes_for_one_and_for_several_chunks(hip_lib):
     assert many == one
 
 
+def test_multi_gpu_planners_size_their_scratch_without_a_gpu(hip_lib):
+    """ABI 7: the row shard on the windowed pipeline and the large exchange plan are sized by host arithmetic (no GPU call), and
+    refuse nonsense."""
+    import ctypes
+    ws = hip_lib.tpnet_wshard_workspace_bytes(4614 + 9228, 128, 3, 20 * 2000, 2000, 2, 4614)
+    assert ws > 20 * 2000 * 2 * 3 * 128 * 4                      # at least the version log of the call
+    assert hip_lib.tpnet_wshard_workspace_bytes(0, 128, 3, 1000, 100, 2, 10) == 0
+    assert hip_lib.tpnet_wshard_workspace_bytes(100, 128, 9, 1000, 100, 2, 10) == 0      # L > 4
+    assert hip_lib.tpnet_wshard_workspace_bytes(100, 128, 3, 1000, 100, 65, 10) == 0     # more than 64 ranks
+    big = hip_lib.tpnet_xplan_large_bytes(3 * 80000, 80000, 8)
+    assert big > 6 * 3 * 80000 * 8 * 2 and hip_lib.tpnet_xplan_large_bytes(0, 100, 2) == 0
+    h = ctypes.c_void_p()
+    assert hip_lib.tpnet_stage_create_ex(8, 1 << 16, 7, ctypes.byref(h)) == -1          # no such mode
+    assert hip_lib.tpnet_stage_in_device_memory(None) == 0
+    assert hip_lib.tpnet_wshard_plan(None, None, None, None, None, 10, 5, 10, 2, 0, 5, 0.0, 0.0, 0, 1, 1, None, 0, None, ctypes.byref(h)) == -1
+    assert hip_lib.tpnet_wshard_step(None, None, 0, 1, None, None, None) == -1 and hip_lib.tpnet_wshard_run(None, None, None, None, 1, None) == -1
+    assert hip_lib.tpnet_strerror(-6).startswith(b"the one-launch encoder kernel")
+
+
 def test_bad_arguments_are_rejected_without_a_gpu(hip_lib):
     from tpnet_amd import _lib
     st = _lib.State(p0=None, q=None, meta=None, N=10, d=16, L=3, err=None)

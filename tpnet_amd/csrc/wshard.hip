@@ -27,6 +27,7 @@
 
 #include <dlfcn.h>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace tpnet {
@@ -415,12 +416,13 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
     const int64_t nw = (nb + K - 1) / K;
     if (nw >= (1 << WS_WIN_BITS) || nw > 256) return 1;
     hipStream_t s = (hipStream_t)stream;
-    tpnet_wshard* w = new tpnet_wshard();
+    std::unique_ptr<tpnet_wshard> holder(new tpnet_wshard());       // (every early return below frees it)
+    tpnet_wshard* w = holder.get();
     w->st = *st; w->E = E; w->batch = batch; w->N_global = N_global; w->G = G; w->me = me; w->n_owned = n_owned; w->K = K;
     w->nw = nw; w->lambda = lambda; w->flags = flags; w->now_time = now_time;
     w->have_readout = want_pos || want_neg;
     w->nsteps = nw + (w->have_readout ? L : L - 1);
-    auto fail = [&](int rc) { delete w; return rc; };
+    auto fail = [&](int rc) { return rc; };
     const size_t plan_b = ws_al(wplan_bytes_shard(E, batch, st->N, d, L));
     char* base = reinterpret_cast<char*>((reinterpret_cast<size_t>(workspace) + 255) / 256 * 256);
     int rc = wplan_carve(base, plan_b, E, batch, st->N, d, L, K, &w->p, nullptr, true);
@@ -591,7 +593,7 @@ int tpnet_wshard_plan(const tpnet_state* st, const int64_t* src, const int64_t* 
         TPNET_HIP_TRY(hipStreamSynchronize(s));                      // (hpb leaves scope)
     }
     TPNET_HIP_TRY(hipGetLastError());
-    *out = w;
+    *out = holder.release();
     return TPNET_OK;
 }
 

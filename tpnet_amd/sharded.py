@@ -894,6 +894,17 @@ class ShardedStreamRunner:
         if rc == 1:
             return None
         _lib.check(rc, "wshard_plan")
+        try:
+            return self._plan_windowed_info(h, E, B, ws, want_pos, want_neg)
+        except Exception:
+            lib.tpnet_wshard_destroy(h)
+            raise
+
+    def _plan_windowed_info(self, h, E, B, ws, want_pos, want_neg):
+        rp, G, me = self.rp, self.G, self.me
+        lib = _lib.load()
+        dev = rp._dev()
+        L, d = rp.num_layer, rp.dim
         ns, halo, ms, mr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         pc, psc, prc = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)()
         _lib.check(lib.tpnet_wshard_info(h, C.byref(ns), C.byref(halo), C.byref(ms), C.byref(mr), C.byref(pc), C.byref(psc), C.byref(prc)),
