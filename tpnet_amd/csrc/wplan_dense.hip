@@ -166,6 +166,227 @@ __global__ __launch_bounds__(BS) void k_dense_sort(WPlan p, WTmp q, DView D, DAr
 }
 
 
+// ---- A without a sort (batches of up to 1 024 edges over tables of up to DENSE_GROUP_MAX_N nodes: every Wikipedia-shaped config).
+// The sort only serves to put every target's contributions side by side in the reference's order (ascending contribution number
+// j); with one LDS word per NODE that is a counting pass: tab[n] = contributions to n (LDS atomics, any order) -> an exclusive
+// scan in node order = the groups' spans (and the batch's whole row of the run-length matrix, written as it is scanned: nothing
+// to zero, nothing to scatter) -> members listed by arrival -> a member's rank = the members of its group with a smaller j (groups
+// of up to 16: counted; a hub: one wave, a bitmap over j, prefix pop-counts: plan.hip, k_plan_one_h) -> the arrays written span by
+// span.  The spans are in node order and the ranks in j order: the arrays are the stable sort's, entry for entry.
+static constexpr int DENSE_GROUP_MAX_N = 12288;
+template <int BS, int IPT, int NT>
+__global__ __launch_bounds__(BS) void k_dense_group(WPlan p, WTmp q, DView D, DArgs a) {
+    constexpr int NC = BS * IPT;
+    constexpr int SPT = NT / BS;                         // table entries per thread in the scan
+    static_assert(SPT * BS == NT && SPT % 4 == 0, "k_dense_group: table size");
+    constexpr int NW = BS / 64;
+    constexpr int BMW = NC / 32;
+    constexpr uint32_t SMALL = 16;
+    static_assert(NC <= 2048 && BMW <= 64, "k_dense_group: j fits 11 bits, a hub's bitmap one word per lane");
+    const int64_t bb = blockIdx.x;
+    const int64_t e0 = bb * a.Bfull;
+    const int32_t B = (int32_t)((a.Ec - e0 < a.Bfull) ? (a.Ec - e0) : a.Bfull);
+    const int64_t* __restrict__ src = a.src + e0;
+    const int64_t* __restrict__ dst = a.dst + e0;
+    const double* __restrict__ t = a.t + e0;
+    const int64_t g0 = 2 * e0;
+    uint16_t* __restrict__ lenrow = D.len + bb * D.Ns;
+    __shared__ __attribute__((aligned(16))) uint32_t tab[NT];   // contributions of node n; after the scan: span base << 16 | count
+    __shared__ uint16_t mem[NC];                         // members of the groups, span by span, in arrival order
+    __shared__ uint32_t sorted[NC];                      // position -> j | rank << 11 | (count - 1) << 22
+    __shared__ uint32_t bm[NW][BMW];                     // a wave's bitmap over j for the hub it ranks
+    __shared__ uint32_t e_src[NC / 2], e_dst[NC / 2];    // endpoint (0 if out of range) | bit 31: the EDGE has a bad endpoint
+    __shared__ float e_w[NC / 2];
+    __shared__ uint32_t n_big, wsum[NW];
+    __shared__ uint32_t big[NC / SMALL];                 // the nodes of the groups larger than SMALL
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = 2 * B;
+    constexpr int EPT = IPT / 2;
+    int64_t rs[EPT], rd[EPT];
+    double rt[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {                      // (the loads are in flight while the table is cleared)
+        const int e = k * BS + tid;
+        const int ec = e < B ? e : B - 1;
+        rs[k] = src[ec];
+        rd[k] = dst[ec];
+        rt[k] = t[ec];
+    }
+    const double t_last = t[B - 1];                      // next_time = node_interact_times[-1]   (TPNet.py:76)
+    // clock left by the previous batch (TPNet.py:99)
+    const double t_now = (bb == 0) ? (a.t_prev ? *a.t_prev : a.now_time) : a.t[e0 - 1];
+    if (tid == 0) n_big = 0;
+#pragma unroll
+    for (int k = 0; k < SPT / 4; ++k) reinterpret_cast<uint4*>(tab)[k * BS + tid] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = k * BS + tid;
+        if (e < B) {
+            const int64_t s = rs[k], dd = rd[k];
+            const bool oks = (uint64_t)s < (uint64_t)a.N, okd = (uint64_t)dd < (uint64_t)a.N;
+            const uint32_t bad = (oks && okd) ? 0u : 0x80000000u;
+            if (bad) atomicAdd(a.err, 1u);               // once per bad edge
+            e_src[e] = (oks ? (uint32_t)s : 0u) | bad;
+            e_dst[e] = (okd ? (uint32_t)dd : 0u) | bad;
+            const float x = (float)t_last - (float)rt[k];   // the reference's casts (models/TPNet.py:77-78), as wsort_batch
+            e_w[e] = bad ? 0.0f : expf((float)(-a.lambda) * x);
+        }
+    }
+    __syncthreads();
+    auto target_of = [&](int j) -> uint32_t {            // first the src-side scatter-adds, then the dst-side ones (TPNet.py:93-96)
+        return ((j >= B) ? e_dst[j - B] : e_src[j]) & 0x7FFFFFFFu;
+    };
+    uint32_t key[IPT], arr[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = k * BS + tid;
+        key[k] = 0;
+        arr[k] = 0;
+        if (j < nc) {
+            key[k] = target_of(j);
+            arr[k] = atomicAdd(&tab[key[k]], 1u);
+        }
+    }
+    __syncthreads();
+    // spans: exclusive scan of the nodes' counts (thread `tid` holds nodes [tid * SPT, tid * SPT + SPT)); the row of run lengths
+    uint32_t c[SPT], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SPT / 4; ++k) {
+        const uint4 v = reinterpret_cast<const uint4*>(tab)[tid * (SPT / 4) + k];
+        c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+        tsum += v.x + v.y + v.z + v.w;
+    }
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+#pragma unroll
+    for (int k = 0; k < SPT; ++k) {
+        const int64_t n = (int64_t)tid * SPT + k;
+        if (n < a.N) lenrow[n] = (uint16_t)c[k];
+    }
+    __syncthreads();
+    uint32_t base = inc - tsum;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        if (i < wave) base += wsum[i];
+    if (tsum) {
+#pragma unroll
+        for (int k = 0; k < SPT; ++k) {
+            tab[tid * SPT + k] = (base << 16) | c[k];
+            if (c[k] > SMALL) big[atomicAdd(&n_big, 1u)] = (uint32_t)(tid * SPT + k);
+            base += c[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = k * BS + tid;
+        if (j < nc) mem[(tab[key[k]] >> 16) + arr[k]] = (uint16_t)j;
+    }
+    __syncthreads();
+    auto emit = [&](uint32_t j, uint32_t gb, uint32_t rank, uint32_t cnt) {
+        sorted[gb + rank] = j | (rank << 11) | ((cnt - 1u) << 22);
+    };
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int j = k * BS + tid;
+        if (j < nc) {
+            const uint32_t cb = tab[key[k]];
+            const uint32_t gb = cb >> 16, cnt = cb & 0xFFFFu;
+            if (cnt <= SMALL) {
+                uint32_t rank = 0;
+                if (cnt > 1) {
+                    for (uint32_t m = 0; m < cnt; m += 4) {          // (four independent LDS reads per round; a read past the
+#pragma unroll                                                       //  span is masked)
+                        for (uint32_t i = 0; i < 4; ++i) {
+                            const uint32_t mm = m + i;
+                            const uint32_t o = mem[(gb + mm) < (uint32_t)NC ? gb + mm : 0u];
+                            rank += (mm < cnt && o < (uint32_t)j) ? 1u : 0u;
+                        }
+                    }
+                }
+                emit((uint32_t)j, gb, rank, cnt);
+            }
+        }
+    }
+    const uint32_t nbig = n_big;
+    for (uint32_t k = wave; k < nbig; k += NW) {         // a hub: one wave, a bitmap over j, prefix pop-counts
+        const uint32_t cb = tab[big[k]];
+        const uint32_t gb = cb >> 16, cnt = cb & 0xFFFFu;
+        if (lane < BMW) bm[wave][lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t m = lane; m < cnt; m += 64) {
+            const uint32_t j = mem[gb + m];
+            atomicOr(&bm[wave][j >> 5], 1u << (j & 31u));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t word = lane < BMW ? bm[wave][lane] : 0u;
+        uint32_t pre = (uint32_t)__popc(word);
+        const uint32_t own = pre;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)pre, o, 64);
+            if (lane >= o) pre += v;
+        }
+        pre -= own;
+        for (uint32_t m0 = 0; m0 < cnt; m0 += 64) {      // (uniform trip count: the shuffles are wave-wide)
+            const uint32_t m = m0 + lane;
+            const bool on = m < cnt;
+            const uint32_t j = on ? mem[gb + m] : 0u;
+            const uint32_t pw = (uint32_t)__shfl((int)pre, (int)(j >> 5), 64);
+            const uint32_t ww = (uint32_t)__shfl((int)word, (int)(j >> 5), 64);
+            const uint32_t rank = pw + (uint32_t)__popc(ww & ((1u << (j & 31u)) - 1u));
+            if (on) emit(j, gb, rank, cnt);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // the batch's arrays, span by span (coalesced)
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int pos = k * BS + tid;
+        if (pos < nc) {
+            const uint32_t v = sorted[pos];
+            const uint32_t j = v & 0x7FFu, ri = (v >> 11) & 0x7FFu, cnt = (v >> 22) + 1u;
+            const bool side = j >= (uint32_t)B;
+            const int e = side ? (int)j - B : (int)j;
+            const uint32_t es = e_src[e], ed = e_dst[e];
+            const bool ok = !(es & 0x80000000u);
+            const bool tail = ri + 1u == cnt;
+            uint32_t fl = 0;
+            if (ri == 0) fl |= WREF_RUN_HEAD;
+            if (tail) fl |= WREF_RUN_TAIL;
+            if (ri % WIN_BLOCK == 0) fl |= WREF_BLK_HEAD;
+            if (ri % WIN_BLOCK == WIN_BLOCK - 1 || tail) fl |= WREF_BLK_TAIL;
+            q.bkey[g0 + pos] = (side ? ed : es) & 0x7FFFFFFFu;
+            q.bpart[g0 + pos] = ok ? (int32_t)((side ? es : ed) & 0x7FFFFFFFu) : 0;
+            q.bcoef[g0 + pos] = ok ? e_w[e] : 0.0f;
+            q.bval[g0 + pos] = j;
+            q.binv[g0 + j] = (uint32_t)(g0 + pos);
+            q.bri[g0 + pos] = ri;
+            q.bflags[g0 + pos] = fl;
+        }
+    }
+    if (tid == 0) {
+        BatchDesc Dn;
+        Dn.e0 = e0;
+        Dn.ne = B;
+        Dn.pad = 0;
+        Dn.t_last = t_last;
+        Dn.now = t_now;
+        Dn.n_light = 0;
+        Dn.n_heavy = 0;
+        for (int i = 0; i < TPNET_MAX_LAYERS; ++i) Dn.decay[i] = 1.0f;            // (as wsort_batch: read by the eager mode only)
+        p.base.desc[bb] = Dn;
+    }
+}
+
 // ---- A (row shard): the batch holds the edges of ALL ranks (local ids: rows < own are this rank's, the rows behind them halo rows
 // of other ranks' nodes); only the contributions to OWNED targets are sorted -- ~2 B / G of the batch's 2 B, so a global batch of up
 // to 8 192 edges fits the one-workgroup sort -- and a halo node that is a target in this batch gets len = 1: its run is ONE slot of
@@ -596,7 +817,10 @@ int wplan_dense_build(const tpnet_state& st, const WPlan& p, const int64_t* src,
     }
 #define TPNET_WDENSE(BS_, IPT_) hipLaunchKernelGGL((k_dense_sort<BS_, IPT_>), dim3((unsigned)nb), dim3(BS_), 0, s, p, q, D, a)
     const int64_t n2 = 2 * batch;
+    static const int no_group = TPNET_DEV_INT(DENSE_SORT, 0);             // developer override: the sorting phase A for every batch size
     if (shard) hipLaunchKernelGGL((k_dense_sort_shard<1024, 4>), dim3((unsigned)nb), dim3(1024), 0, s, p, q, D, a);
+    else if (!no_group && n2 <= 2048 && st.N <= DENSE_GROUP_MAX_N)
+        hipLaunchKernelGGL((k_dense_group<1024, 2, DENSE_GROUP_MAX_N>), dim3((unsigned)nb), dim3(1024), 0, s, p, q, D, a);
     else if (n2 <= 512) TPNET_WDENSE(256, 2);
     else if (n2 <= 1024) TPNET_WDENSE(512, 2);
     else if (n2 <= 2048) TPNET_WDENSE(1024, 2);
