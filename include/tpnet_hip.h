@@ -314,6 +314,8 @@ int tpnet_run_stream(const tpnet_state* st, const int64_t* src, const int64_t* d
  *   stream_sig: identifies the CONTENTS of src / dst / t (equal value = unchanged arrays; 0 = never replay);
  *   table_sig:  identifies the table's per-node (current copy, reference time) state before the call -- e.g. one constant
  *               for "just after tpnet_state_init(t0)" per t0, a fresh value after anything else wrote the state (0 = never).
+ * A stream on the per-batch schedule that is ONE chunk (up to ~2 M edges) replays its plan too: that plan is a function of src / dst / t,
+ * now_time and the flags alone, so stream_sig decides and table_sig is not looked at.
  * A caller that lets anything else use the workspace in between clears the tag (memset 0).  tag == NULL: tpnet_run_stream. */
 typedef struct tpnet_plan_tag {
     uint64_t table_sig;   /* in */

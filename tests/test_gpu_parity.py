@@ -1060,6 +1060,98 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     np.testing.assert_array_equal(e4[2], c1[2])
 
 
+@pytest.mark.parametrize("d,L,N,B,nb", [(64, 2, 500, 1000, 5),      # 2 000 pairs in workgroups of 32 lane groups: half a workgroup left over
+                                        (64, 2, 500, 2049, 3),      # 4 098 pairs in workgroups of 16
+                                        (128, 3, 300, 1000, 4), (64, 2, 5000, 300, 6)])
+def test_exact_mode_stream_is_reproducible(d, L, N, B, nb):
+    """The exact mode of a stream is three launches per batch (readout, dense decay, update: models/TPNet.py:83-96).  Until round 5
+    the lane groups behind the last pair of the READOUT launch walked the first update items (step_impl.hpp): the same nodes were
+    then updated again behind the decay from the copy it had not scaled -- inside the mode's tolerance, but different bits run to
+    run.  Same bits every run, and the same state as the per-batch calls of the same mode."""
+    _need_gpu()
+    rng = np.random.RandomState(1)
+    E = nb * B
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dt = dev(src), dev(dst), dev(neg), dev(t)
+    rp = _module(N, d, L, 2e-6, t[0], P0=P0, exact=True)
+    outs = []
+    for _ in range(4):
+        rp.reset_random_projections()
+        rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+        fp, fn = rp.run_stream(ds, dd, dn, dt, B, replay=False)
+        outs.append((fp.clone(), fn.clone(), _layers(rp)))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        np.testing.assert_array_equal(o[2], outs[0][2])
+    # the stream without readouts (no readout launch at all) gives the same state
+    rp.reset_random_projections()
+    rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+    rp.run_stream(ds, dd, None, dt, B, want_pos=False, want_neg=False, replay=False)
+    np.testing.assert_array_equal(_layers(rp), outs[0][2])
+
+
+@pytest.mark.parametrize("d,L,N,B,nb,schedule,exact", [(256, 3, 3000, 5000, 12, "auto", False),     # the chunk planner (B > 4 096: C3 / C5)
+                                                        (128, 3, 2000, 10000, 6, "auto", False),
+                                                        (128, 3, 900, 300, 9, "batch", False),       # one workgroup per batch
+                                                        (64, 2, 500, 2500, 7, "batch", True)])       # the exact mode's plan
+def test_per_batch_plan_replay_across_epochs(d, L, N, B, nb, schedule, exact):
+    """The per-batch schedule's plan (item lists, coefficients, batch descriptors) depends on the stream and the clock at entry
+    alone: a stream of one chunk replays it in every later epoch (train_link_prediction.py:234-253) -- whatever the table holds --
+    and gives the bits a cold plan gives."""
+    _need_gpu()
+    rng = np.random.RandomState(d + B + nb)
+    E = nb * B - B // 3
+    lam = 2e-6
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    neg2 = rng.randint(0, N, E).astype(np.int64)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dn2, dt = dev(src), dev(dst), dev(neg), dev(neg2), dev(t)
+
+    def epoch(rp, negs, reset=True, **kw):
+        if reset:
+            rp.reset_random_projections()
+            rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+        fp, fn = rp.run_stream(ds, dd, negs, dt, B, schedule=schedule, **kw)
+        return fp.clone(), fn.clone(), _layers(rp), rp.last_stream_replayed
+
+    make = lambda: _module(N, d, L, lam, t[0], P0=P0, exact=exact)
+
+    cold = make()
+    c1 = epoch(cold, dn, replay=False)
+    c2_ = epoch(cold, dn2, replay=False)
+    assert not c1[3] and not c2_[3]
+    rp = make()
+    e1 = epoch(rp, dn)
+    e2 = epoch(rp, dn2)
+    e3 = epoch(rp, dn)
+    assert not e1[3] and e2[3] and e3[3]
+    for got, want in ((e1, c1), (e2, c2_), (e3, c1)):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        np.testing.assert_array_equal(got[2], want[2])
+    # an in-place write to the stream is seen, and so is another user of the workspace
+    dd[3] = dd[3]
+    assert not epoch(rp, dn)[3]
+    assert epoch(rp, dn)[3]
+    rp.reset_random_projections()
+    rp.update(src[:B], dst[:B], t[:B])
+    assert not epoch(rp, dn)[3]
+    # a different clock at entry is another plan (the first batch's descriptor carries it)
+    rp.reset_random_projections()
+    rp.random_projections[0].data.copy_(torch.from_numpy(P0))
+    rp.run_stream(ds[:B], dd[:B], dn[:B], dt[:B], B, schedule=schedule)
+    assert not epoch(rp, dn, reset=False)[3]
+    e4 = epoch(rp, dn)
+    assert not e4[3]                                       # (the clock is back at t[0]: not what the plan in place was built for)
+    e5 = epoch(rp, dn)
+    assert e5[3]
+    for got in (e4, e5):
+        assert torch.equal(got[0], c1[0]) and torch.equal(got[1], c1[1])
+        np.testing.assert_array_equal(got[2], c1[2])
+
+
 @pytest.mark.parametrize("d,L,N,B,nb,per,packed", [(64, 3, 2000, 100, 300, 130, False), (128, 3, 9000, 1000, 70, 30, False),
                                                    (64, 2, 3000, 200, 150, 70, False),
                                                    (64, 2, 4000, 1170, 90, 45, True)])      # (packed rows of 21 floats: chunks of whole 16 bytes)
@@ -1225,8 +1317,8 @@ def test_every_optional_pointer_null_on_both_schedules(d, L, N, B, nb, schedule)
                                       (20, 128, 9228, 1000)])     # (the driver's timed shape: C2, 20 batches)
 def test_auto_schedule_on_both_sides_of_its_threshold(nb, d, N, B):
     """The shipped default ("auto") takes the per-batch kernels below 16 batches and the windowed pipeline from there
-    (tpnet_amd/csrc/api.hip, window_chunk): both sides against the oracle, and the choice itself (a windowed run leaves a
-    plan that the next epoch replays; a per-batch run does not)."""
+    (tpnet_amd/csrc/api.hip, window_chunk): both sides against the oracle, and the choice itself (tpnet_stream_schedule; either
+    schedule leaves a plan that the next epoch replays -- the per-batch one since round 5)."""
     _need_gpu()
     L, lam = 3, 2e-6
     rng = np.random.RandomState(nb)
@@ -1248,7 +1340,9 @@ def test_auto_schedule_on_both_sides_of_its_threshold(nb, d, N, B):
     rp.reset_random_projections()
     rp.random_projections[0].data.copy_(torch.from_numpy(P0))
     rp.run_stream(ds, dd, dn, dt, B, schedule="auto")
-    assert rp.last_stream_replayed == (nb >= 16)
+    assert rp.last_stream_replayed
+    from tpnet_amd import _lib
+    assert (_lib.load().tpnet_stream_schedule(N, d, L, E, B, 0, rp._eng["ws"].numel()) == 1) == (nb >= 16)
 
 
 def test_multi_chunk_packed_rows_with_odd_row_length():

@@ -279,8 +279,22 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
             return run_stream_windowed(st, src, dst, neg, t, E, batch, now_time, lambda, launch_id_base, flags, out_pos,
                                        out_neg, ws, ws_bytes, wchunk, Kw, s, timer, tag, region);
     }
-    if (tag) { memset(tag->built, 0, sizeof(tag->built)); tag->replayed = 0; }   // (the per-batch planner overwrites the workspace)
     const int64_t chunk = max_chunk(ws_bytes, E, batch);
+    // the per-batch plan of a stream (item lists, coefficients, batch descriptors: plan.hip) is a function of src / dst / t, the
+    // clock at entry and the flags alone -- not of the table -- and the step kernels only read it: a stream that is ONE chunk (up
+    // to ~2 M edges: every dataset of the reference at any batch size) replays it when the caller vouches for the arrays
+    // (tag->stream_sig; table_sig is not looked at).  valid = 2 tells such a plan from a windowed one (valid = 1).
+    PlanBuilt now{};
+    bool replay = false;
+    if (tag && chunk >= E && tag->stream_sig) {
+        now.valid = 2; now.src = src; now.dst = dst; now.t = t; now.ws = ws; now.E = E; now.batch = batch; now.N = st.N;
+        now.ws_bytes = ws_bytes; now.now_time = now_time; now.lambda = lambda; now.d = st.d; now.L = st.L; now.K = 0;
+        now.flags = flags; now.table_sig = 0; now.stream_sig = tag->stream_sig;
+        now.have_readout = out_pos ? 1 : 0;                     // (the edge-fused update's lists exist for a (src, dst) readout only)
+        now.chunk = chunk; now.region = 0;
+        replay = memcmp(&now, tag->built, sizeof(PlanBuilt)) == 0;
+    }
+    if (tag) { memset(tag->built, 0, sizeof(tag->built)); tag->replayed = replay ? 1 : 0; }   // (invalid unless the call completes)
     if (chunk < 1) return TPNET_ERR_WORKSPACE;
     const int NN = 2 * st.L + 2;
     const int NG = (flags & TPNET_FLAG_PACKED) ? NN * (NN + 1) / 2 : NN * NN;   // floats per feature row of a chunk's outputs
@@ -298,9 +312,11 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
                           !(flags & (TPNET_FLAG_EAGER_DECAY | TPNET_FLAG_SEQUENTIAL)) &&
                           (fuse_env >= 0 ? fuse_env == 1 : batch > 1024);
         // the clock before a later chunk is t[c0-1], read on device (no host copy of the timestamps is needed)
-        rc = plan_build(st, p, src + c0, dst + c0, t + c0, Ec, batch, now_time, c0 > 0 ? t + c0 - 1 : nullptr, lambda,
-                        flags | (fuse ? PLAN_FUSE : 0u), s);
-        if (rc) return rc;
+        if (!replay) {
+            rc = plan_build(st, p, src + c0, dst + c0, t + c0, Ec, batch, now_time, c0 > 0 ? t + c0 - 1 : nullptr, lambda,
+                            flags | (fuse ? PLAN_FUSE : 0u), s);
+            if (rc) return rc;
+        }
         StreamArgs a;
         a.src = src + c0;
         a.dst = dst + c0;
@@ -342,6 +358,7 @@ static int run_stream_impl(const tpnet_state& st, const int64_t* src, const int6
             timer->edges += Ec;
         }
     }
+    if (now.valid) memcpy(tag->built, &now, sizeof(PlanBuilt));
     return TPNET_OK;
 }
 
