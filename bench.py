@@ -425,14 +425,29 @@ def launch_ranks(n, argv):
                              f"rehearses the N > 1 path with the ranks sharing a GPU)", gpus_visible=ndev), flush=True)
         return 2
     cmd, env = launcher_command(n, argv, free_port())
+    # the launcher and its ranks in a process group of their own: a run that outlives the limit is ended as a whole (the group this
+    # call created, by its id -- a launcher killed alone would leave its ranks holding the GPUs)
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True,
-                              timeout=float(os.environ.get("TPNET_BENCH_LAUNCH_TIMEOUT", "1500")))
-        out, rc = proc.stdout, proc.returncode
-    except subprocess.TimeoutExpired as ex:
-        out, rc = (ex.stdout or ""), 124
-        if isinstance(out, bytes):
-            out = out.decode(errors="replace")
+        out, _ = proc.communicate(timeout=float(os.environ.get("TPNET_BENCH_LAUNCH_TIMEOUT", "1500")))
+        rc = proc.returncode
+    except subprocess.TimeoutExpired:
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        try:
+            out = proc.communicate(timeout=5.0)[0] or ""
+        except Exception:
+            out = ""
+        rc = 124
     line = pick_result_line(out)
     for ln in out.splitlines():                      # whatever else the ranks printed goes to stderr: stdout carries ONE line
         if not (ln.strip().startswith("{") and "metric" in ln):

@@ -96,3 +96,42 @@ def test_stream_schedule_query(hip_lib):
     assert hip_lib.tpnet_stream_schedule(N, d, L, 20 * B, B, 0, 1 << 20) == 0     # a workspace that holds no window
     assert hip_lib.tpnet_stream_schedule(N, 126, L, 20 * B, B, 0, ws) == 0        # rows that take no 16-byte vectors
     assert hip_lib.tpnet_stream_schedule(0, d, L, 20 * B, B, 0, ws) < 0
+
+
+def test_a_launch_that_outlives_its_limit_is_ended_with_its_ranks(monkeypatch, tmp_path, capsys):
+    """launch_ranks starts the launcher in a process group of its own and, past TPNET_BENCH_LAUNCH_TIMEOUT, ends that GROUP: a stand-in
+    launcher that starts a 'rank' (a grandchild) and hangs must leave nothing behind -- a launcher killed alone would leave its ranks
+    holding the GPUs."""
+    import time
+    import torch
+    b = _bench()
+    pidfile = tmp_path / "rank.pid"
+    script = tmp_path / "hang.py"
+    script.write_text(
+        "import subprocess, sys, time\n"
+        "p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"
+        f"open({str(pidfile)!r}, 'w').write(str(p.pid))\n"
+        "time.sleep(600)\n")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(b, "launcher_command", lambda n, argv, port, python=None, script_=None: ([sys.executable, str(script)], dict(os.environ)))
+    monkeypatch.setenv("TPNET_BENCH_LAUNCH_TIMEOUT", "3")
+    monkeypatch.setenv("TPNET_BENCH_BACKEND", "gloo")
+    t0 = time.time()
+    rc = b.launch_ranks(2, ["--gpus", "2"])
+    assert rc == 124 and time.time() - t0 < 40
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2
+    rank_pid = int(pidfile.read_text())
+    for _ in range(50):                                   # the grandchild is gone (or a zombie of init's about to be reaped)
+        try:
+            os.kill(rank_pid, 0)
+        except ProcessLookupError:
+            break
+        try:
+            if open(f"/proc/{rank_pid}/stat").read().split(")")[-1].split()[0] == "Z":
+                break
+        except FileNotFoundError:
+            break
+        time.sleep(0.1)
+    else:
+        raise AssertionError("the stand-in rank survived its launcher")
