@@ -83,6 +83,49 @@ def test_sharding_plan_and_exchange_gloo_world2():
     assert res == [(0, True), (1, True)]
 
 
+def _agree_worker(rank, world, port, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from tpnet_amd.sharded import ShardedStreamRunner
+
+        class _R:                                    # what _agree_windowed touches of a runner
+            detached = False
+            group = dist.group.WORLD
+            rp = None
+        agree = lambda *a: ShardedStreamRunner._agree_windowed(_R(), *a)
+        out = []
+        out.append(agree(True, None))                                   # every rank planned: take the windowed shard
+        out.append(agree(rank != 1, None))                              # one rank declined: none takes it
+        released = []
+        try:                                                            # rank 0's plan raised: it re-raises ITS error, the others
+            agree(rank != 0, MemoryError("rank 0") if rank == 0 else None, lambda: released.append(1))   # free their plan and raise too
+            out.append("no error")
+        except MemoryError as ex:
+            out.append(("own", str(ex)))
+        except RuntimeError as ex:
+            out.append(("other", "another rank failed" in str(ex), released == [1]))
+        out.append(agree(True, None))                                   # (the group is still usable afterwards)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_windowed_shard_agreement_survives_a_rank_that_raises_gloo():
+    """run_stream_targeted: all ranks take the windowed shard or none does, and a rank whose tpnet_wshard_plan raised (out of memory,
+    a HIP error) tells the others BEFORE anyone enters the first exchange -- they raise too instead of hanging in it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == [True, False, ("own", "rank 0"), True]
+    assert res[1] == res[2] == [True, False, ("other", True, True), True]
+
+
 def test_plan_touched_single_rank_and_no_neg():
     from tpnet_amd.sharded import plan_touched
     src, dst, neg, t = _stream(1, 50, 100)

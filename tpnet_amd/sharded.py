@@ -745,6 +745,26 @@ class ShardedStreamRunner:
                 dist.all_reduce(out_neg, group=self.group)
         return out_pos, out_neg
 
+    def _agree_windowed(self, planned: bool, failed, release=None) -> bool:
+        """All ranks of a call take the windowed shard or none does.  `planned`: this rank's tpnet_wshard_plan served the call;
+        `failed`: the exception it raised instead (out of memory for its workspace, a HIP error), else None.  A rank that failed still
+        takes part in the agreement -- with -1 -- and raises its error behind it; the others raise too (after `release()`, which
+        frees their plan) instead of waiting for it in the first exchange."""
+        ok = planned and failed is None
+        if not self.detached:
+            flag = torch.tensor([-1 if failed is not None else (1 if planned else 0)], dtype=torch.int32,
+                                device=self.rp._dev() if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            worst = int(flag.item())
+            ok = worst > 0
+            if worst < 0 and failed is None:
+                if release is not None:
+                    release()
+                raise RuntimeError("run_stream: another rank failed while planning the windowed shard of this call")
+        if failed is not None:
+            raise failed
+        return ok
+
     def run_stream_targeted(self, src, dst, neg, t, batch_size: int, t_host_last=None, merge_outputs: bool = True, timing=None,
                             out_pos=None, out_neg=None):
         """run_stream with the TARGETED exchange: per batch, pack the owned rows each peer reads (a row repeats per reader), ONE
@@ -760,12 +780,12 @@ class ShardedStreamRunner:
             # every rank takes the same decision: tpnet_wshard_plan declines on shapes (all ranks alike) or on counts that all ranks
             # derive from the same stream -- except a batch whose OWNED contributions overflow one rank's sort: agreed on below
             self._check_pending_status()
-            W = self.plan_windowed(src, dst, neg, t, batch_size)
-            ok = W is not None
-            if not self.detached:
-                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=rp._dev() if dist.get_backend(self.group) == "nccl" else "cpu")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-                ok = bool(int(flag.item()))
+            W, failed = None, None
+            try:
+                W = self.plan_windowed(src, dst, neg, t, batch_size)
+            except Exception as ex:          # noqa: BLE001 -- re-raised by _agree_windowed, after every rank has heard of it
+                failed = ex
+            ok = self._agree_windowed(W is not None, failed, (lambda: _lib.load().tpnet_wshard_destroy(W["handle"])) if W is not None else None)
             if ok:
                 return self.run_stream_windowed(src, dst, neg, t, batch_size, t_host_last, merge_outputs, out_pos, out_neg, plan=W,
                                                 timing=timing)
