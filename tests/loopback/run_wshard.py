@@ -202,6 +202,23 @@ def main():
         layB = full_layers(runs_b, N, L, d)
         assert torch.equal(fpB, rfp) and torch.equal(fnB, rfn) and torch.equal(layB, rl), f"config {ci}: the loopback transport differs"
         assert float(runs_b[0].rp.now_time.item()) == float(t[-1])
+        # ---- (C) no negatives at all (run_stream(src, dst, None, t): the pointer the kernels get is null -- round 4's fault on the
+        # single-GPU pipeline lived exactly there): the (src, dst) features and the tables as the single-GPU run without negatives
+        if ci < 3 and not os.environ.get("TPNET_WSHARD_RANDOM"):
+            ref2 = tpnet_amd.RandomProjectionModule(node_num=N, edge_num=E, dim_factor=10, num_layer=L, time_decay_weight=lam,
+                                                    device="cuda:0", use_matrix=False, beginning_time=np.float64(t[0]),
+                                                    not_scale=False, enforce_dim=d)
+            ref2.random_projections[0].data = P0.clone()
+            ref2 = ref2.to(dev)
+            r2p, r2n = ref2.run_stream(D[0], D[1], None, D[3], B, schedule="windowed")
+            assert r2n is None and torch.equal(r2p, rfp)
+            runs_c = make_shards(G, N, d, L, E, B, lam, t[0], P0, dev, halo)
+            res_c = run_loopback(runs_c, (D[0], D[1], None, D[3]), B, lib, so)
+            assert all(o[1] is None for o in res_c)
+            assert torch.equal(sum(o[0] for o in res_c), rfp) and torch.equal(full_layers(runs_c, N, L, d), rl), \
+                f"config {ci}: the shards without negatives differ"
+            for r in range(G):
+                runs_c[r].rp.check_device_errors()
         summary.append((G, N, d, L, (E + B - 1) // B, nsteps, moved))
     print("WSHARD OK " + "; ".join(f"G={g} N={n} d={d} L={l} batches={nb}: {ns} launches per shard, {mv} rows moved"
                                    for g, n, d, l, nb, ns, mv in summary))
