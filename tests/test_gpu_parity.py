@@ -1060,6 +1060,60 @@ def test_plan_replay_across_epochs(d, L, N, B, nb):
     np.testing.assert_array_equal(e4[2], c1[2])
 
 
+@pytest.mark.parametrize("d,L,N,B,nb,schedule", [(128, 3, 9000, 1000, 20, "auto"), (64, 2, 700, 100, 9, "auto"), (256, 3, 900, 3000, 5, "batch")])
+def test_prepared_stream_call_equals_run_stream(d, L, N, B, nb, schedule):
+    """rp.prepare_stream(...) checks run_stream's arguments once; the prepared call then runs the stream every time it is called:
+    the same bits as run_stream, the plan of an earlier run replayed under the same rules (a new `neg` written into the held tensor
+    does not stop it, a write to src does), another use of the workspace in between is fine, bad arguments are refused at prepare."""
+    _need_gpu()
+    rng = np.random.RandomState(d + nb)
+    E = nb * B - B // 4
+    src, dst, neg, t = _random_stream(rng, N, E, 4.0e5)
+    neg2 = rng.randint(0, N, E).astype(np.int64)
+    P0 = (rng.randn(N, d) / np.sqrt(d)).astype(np.float32)
+    dev = lambda x: torch.from_numpy(x).to(DEV)
+    ds, dd, dn, dn2, dt = dev(src), dev(dst), dev(neg), dev(neg2), dev(t)
+    a = _module(N, d, L, 2e-6, t[0], P0=P0)
+    fa = a.run_stream(ds, dd, dn, dt, B, schedule=schedule, replay=False)
+    fa = (fa[0].clone(), fa[1].clone())
+    la = _layers(a)
+    fa2 = _module(N, d, L, 2e-6, t[0], P0=P0).run_stream(ds, dd, dn2, dt, B, schedule=schedule, replay=False)
+    b = _module(N, d, L, 2e-6, t[0], P0=P0)
+    held_neg = dn.clone()
+    call = b.prepare_stream(ds, dd, held_neg, dt, B, schedule=schedule, t_end=float(t[-1]))
+
+    def epoch():
+        b.reset_random_projections()
+        b.random_projections[0].data.copy_(torch.from_numpy(P0))
+        fp, fn = call()
+        assert fp is call.out_pos and fn is call.out_neg
+        return fp.clone(), fn.clone(), _layers(b), b.last_stream_replayed
+
+    e1 = epoch()
+    assert not e1[3] and torch.equal(e1[0], fa[0]) and torch.equal(e1[1], fa[1])
+    np.testing.assert_array_equal(e1[2], la)
+    held_neg.copy_(dn2)                                       # the next epoch's negatives, in place: the plan is still replayed
+    e2 = epoch()
+    assert e2[3] and torch.equal(e2[0], fa2[0]) and torch.equal(e2[1], fa2[1])
+    np.testing.assert_array_equal(e2[2], la)
+    b.reset_random_projections()
+    b.update(src[:B], dst[:B], t[:B])                         # another user of the workspace: the call plans again, same bits
+    e3 = epoch()
+    assert not e3[3] and torch.equal(e3[0], fa2[0])
+    dd[5] = dd[5]                                             # a write to the stream: noticed (torch's version counter)
+    assert not epoch()[3]
+    assert epoch()[3]
+    assert float(b.now_time.item()) == float(t[-1])
+    with pytest.raises(ValueError):
+        b.prepare_stream(ds, dd.to(torch.int32), dn, dt, B)
+    with pytest.raises(ValueError):
+        b.prepare_stream(ds, dd, dn, dt, B, schedule="fastest")
+    with pytest.raises(ValueError):
+        b.prepare_stream(ds, dd, dn, dt, B, out_pos=torch.empty((E, 3), device=DEV))
+    empty = b.prepare_stream(ds[:0], dd[:0], dn[:0], dt[:0], B)
+    assert empty()[0].shape[0] == 0
+
+
 @pytest.mark.parametrize("d,L,N,B,nb", [(64, 2, 500, 1000, 5),      # 2 000 pairs in workgroups of 32 lane groups: half a workgroup left over
                                         (64, 2, 500, 2049, 3),      # 4 098 pairs in workgroups of 16
                                         (128, 3, 300, 1000, 4), (64, 2, 5000, 300, 6)])

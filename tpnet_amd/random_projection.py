@@ -96,6 +96,17 @@ class _Stage:
             pass
 
 
+class PreparedStream:
+    """A run_stream call whose arguments have been checked and whose outputs exist (RandomProjectionModule.prepare_stream): calling
+    it runs the stream.  Attributes: the tensors it reads (`src`, `dst`, `neg`, `t`: their contents are read at every call) and
+    writes (`out_pos`, `out_neg`: what the call returns)."""
+    __slots__ = ("rp", "src", "dst", "neg", "t", "E", "batch_size", "nb", "want_pos", "want_neg", "out_pos", "out_neg", "t_end",
+                 "flags", "replay", "exact", "dev", "ptrs")
+
+    def __call__(self):
+        return self.rp._run_prepared(self)
+
+
 class RandomProjectionModule(nn.Module):
     # plan-replay bookkeeping (class-level defaults: tpnet_amd/matrix_memory.py builds instances without this constructor)
     _table_sig = 0
@@ -1069,7 +1080,21 @@ class RandomProjectionModule(nn.Module):
         state, then update().  src/dst/neg: int64 [E] on the GPU, t: float64 [E] on the GPU.  Returns
         (feat_pos, feat_neg) of shape [E, (2L+2)^2] (None where not requested).  `t_end` = t[-1] if the caller
         already has it on the host (avoids one 8-byte device->host copy).  `raw` / `packed`: features without the
-        x<0 -> 0, log(x+1) tail / only their distinct entries, rows of packed_feature_dim (see pair_gram)."""
+        x<0 -> 0, log(x+1) tail / only their distinct entries, rows of packed_feature_dim (see pair_gram).
+        = prepare_stream(...)(): an epoch loop that runs the same stream again holds the prepared call instead."""
+        return self._run_prepared(self.prepare_stream(src, dst, neg, t, batch_size, want_pos, want_neg, out_pos, out_neg, t_end, raw,
+                                                      packed, schedule, replay))
+
+    def prepare_stream(self, src: torch.Tensor, dst: torch.Tensor, neg, t: torch.Tensor, batch_size: int,
+                       want_pos: bool = True, want_neg: bool = True, out_pos=None, out_neg=None, t_end: float = None,
+                       raw: bool = False, packed: bool = False, schedule: str = None, replay: bool = None) -> "PreparedStream":
+        """run_stream's arguments checked ONCE (devices, dtypes, shapes, the schedule's name), its outputs allocated: the returned
+        PreparedStream runs the stream every time it is called -- `call()` = run_stream(...) without the ~10 us of argument
+        checking per call that a 20-batch stream of ~130 us notices.  What `train_link_prediction.py:234-253` does every epoch (the
+        same chronological arrays from a reset table) is one prepared call per split, called once per epoch (a new `neg` every epoch:
+        write it into the tensor the call holds -- `call.neg.copy_(...)` -- or prepare again).  The call holds references to its
+        tensors; their CONTENTS are read when it runs (and torch's version counters decide whether the plan of an earlier run may be
+        replayed, exactly as in run_stream); replacing a tensor's storage (`resize_`, `set_`) behind a prepared call is not supported."""
         self._ensure_engine()
         dev = self._dev()
         E = int(src.numel())
@@ -1088,13 +1113,9 @@ class RandomProjectionModule(nn.Module):
             out_pos = torch.empty((E, NG), dtype=torch.float32, device=dev)
         if want_neg and out_neg is None:
             out_neg = torch.empty((E, NG), dtype=torch.float32, device=dev)
-        if E == 0:
-            return out_pos, out_neg
-        ws = self._workspace(E, batch_size, stream=True, keep_plan=True)
-        self._st_ref()                                   # (the cached tpnet_state struct: rebuilt only when a buffer moved)
-        st = self.__dict__["_st_cache"][2]
-        nb = (E + batch_size - 1) // batch_size
-        lid = self._next_launch_ids(nb)
+        batch_size = int(batch_size)
+        if batch_size < 1:
+            raise ValueError("run_stream: batch_size must be positive")
         flags = (_lib.FLAG_NOT_SCALE if (self.not_scale or raw or packed) else 0)
         if packed:
             flags |= _lib.FLAG_PACKED
@@ -1106,43 +1127,64 @@ class RandomProjectionModule(nn.Module):
         flags |= {"auto": 0, "windowed": _lib.FLAG_SCHED_WINDOWED, "batch": _lib.FLAG_SCHED_BATCH,
                   "windowed-sorted": _lib.FLAG_SCHED_WINDOWED | _lib.FLAG_PLAN_SORTED,
                   "windowed-hashed": _lib.FLAG_SCHED_WINDOWED | _lib.FLAG_PLAN_HASHED}[schedule]
+        p = PreparedStream()
+        p.rp, p.src, p.dst, p.neg, p.t = self, src, dst, neg, t
+        p.E, p.batch_size, p.nb = E, batch_size, (E + batch_size - 1) // batch_size
+        p.want_pos, p.want_neg = bool(want_pos), bool(want_neg)
+        p.out_pos, p.out_neg = (out_pos if want_pos else None), (out_neg if want_neg else None)
+        p.t_end = None if t_end is None else float(t_end)
+        p.flags, p.replay, p.exact, p.dev = flags, replay, self.exact, dev
+        p.ptrs = (src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else 0, t.data_ptr(),
+                  out_pos.data_ptr() if want_pos else 0, out_neg.data_ptr() if want_neg else 0)
+        return p
+
+    def _run_prepared(self, p: "PreparedStream"):
+        if p.E == 0:
+            return p.out_pos, p.out_neg
+        self._ensure_engine()
+        if p.exact != self.exact or p.dev != self._dev():
+            raise RuntimeError("this prepared stream was made for another mode / device of the module: prepare it again")
+        E, batch_size = p.E, p.batch_size
+        src, dst, t = p.src, p.dst, p.t
+        ws = self._workspace(E, batch_size, stream=True, keep_plan=True)
+        self._st_ref()                                   # (the cached tpnet_state struct: rebuilt only when a buffer moved)
+        st = self.__dict__["_st_cache"][2]
+        lid = self._next_launch_ids(p.nb)
+        flags = p.flags
         t_out = C.c_double(0.0)
         # a stream that is run again on the same table state (every epoch of train_link_prediction.py:234-253: reset, then the
         # same chronological batches) replays its plan: the tag tells the C side that src / dst / t hold what they held when
         # the plan in the workspace was built (torch bumps a tensor's _version on every in-place write; a write through a raw
         # pointer or .data is not seen -- pass replay=False then) and names the table's per-node state
         tag = None
-        if replay is not False and self.plan_replay:
+        ps, pd, pn, pt, pop, pon = p.ptrs
+        if p.replay is not False and self.plan_replay:
             tag = self.__dict__.get("_plan_tag")
             if tag is None:
                 tag = self.__dict__["_plan_tag"] = _lib.PlanTag()
             tag.table_sig = self._table_sig
-            tag.stream_sig = (hash((src.data_ptr(), src._version, dst.data_ptr(), dst._version, t.data_ptr(), t._version, E))
-                              & 0xFFFFFFFFFFFFFFFF) | 1
+            tag.stream_sig = (hash((ps, src._version, pd, dst._version, pt, t._version, E)) & 0xFFFFFFFFFFFFFFFF) | 1
         else:
             self._drop_plan()
+        t_end = p.t_end
         fast = _lib.fast()
         if fast is not None:
-            rc, t_got = fast.run_stream(C.addressof(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else 0,
-                                        t.data_ptr(), E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
-                                        out_pos.data_ptr() if want_pos else 0, out_neg.data_ptr() if want_neg else 0,
-                                        ws.data_ptr(), ws.numel(), 0 if t_end is not None else 1,
+            rc, t_got = fast.run_stream(C.addressof(st), ps, pd, pn, pt, E, batch_size, self._now_host, float(self.time_decay_weight),
+                                        lid, flags, pop, pon, ws.data_ptr(), ws.numel(), 0 if t_end is not None else 1,
                                         _raw_stream(self._eng["dev_index"]), C.addressof(tag) if tag is not None else 0)
             t_out.value = t_got
             _lib.check(rc, "run_stream")
         else:
             _lib.check(_lib.load().tpnet_run_stream_tagged(
-                C.byref(st), src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else None, t.data_ptr(),
-                E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
-                out_pos.data_ptr() if want_pos else None, out_neg.data_ptr() if want_neg else None,
-                ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream(),
+                C.byref(st), ps, pd, pn or None, pt, E, batch_size, self._now_host, float(self.time_decay_weight), lid, flags,
+                pop or None, pon or None, ws.data_ptr(), ws.numel(), None if t_end is not None else C.byref(t_out), self._stream(),
                 C.byref(tag) if tag is not None else None), "run_stream")
         self.last_stream_replayed = bool(tag is not None and tag.replayed)
-        self._now_host = float(t_end) if t_end is not None else float(t_out.value)
+        self._now_host = t_end if t_end is not None else float(t_out.value)
         self._params_valid = False
         self._now_dirty = True
         self._table_written()
-        return (out_pos if want_pos else None), (out_neg if want_neg else None)
+        return p.out_pos, p.out_neg
 
     def check_device_errors(self):
         """Raise IndexError if a kernel met a node id outside [0, node_num) since the last check."""
