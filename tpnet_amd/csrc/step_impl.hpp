@@ -42,7 +42,11 @@ __global__ __launch_bounds__(BS, step_min_waves(LPP, VPL, W, BS)) void k_step(co
     // (round 4, measured and not kept: the multi-pass launches' NEXT pair fetched ahead -- its ids two passes early into registers,
     // its two meta records one pass early straight into LDS with global_load_lds_dwordx4, so that a pass starts with its row loads:
     // bit-identical results, but the kernel sits at the 168 registers three waves per SIMD allow, the pipeline's state spilled
-    // 17 of them, and a batch of 10 000 edges took 52.4 us instead of 46.5 on the C4 table, 40.4 instead of 32.6 at C3)
+    // 17 of them, and a batch of 10 000 edges took 52.4 us instead of 46.5 on the C4 table, 40.4 instead of 32.6 at C3;
+    // round 5, the lightest form of it -- only the NEXT pair's two ids and its edge-fused flags fetched while the current pair is computed:
+    // scratch 12 -> 40 bytes per lane, 46.9 us against 44.8 on the C4 table, 35.5 against 32.5 at C3: not kept either.  What IS kept from
+    // round 5: the layer-0 rows of a pair, whose addresses need no record, are requested with the records (readout.hpp: EARLY0) -- C4
+    // 44.4 -> 43.3 us, C3 / C5 unchanged)
     unsigned long long* dbg = p.dbg;
     (void)dbg;
     STAMP(0);

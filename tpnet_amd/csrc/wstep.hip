@@ -855,8 +855,13 @@ __global__ __launch_bounds__(WB, wpipe_min_waves(LPP, VPL, L, FULL)) void k_wpip
             float rs[NN];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const uint32_t ref = idok ? P.e_ref[(int64_t)which[s] * Ec + e] : WREF_TABLE;
-                const float gs = idok ? P.e_g[(int64_t)which[s] * Ec + e] : 1.0f;
+                // (indexed by the EDGE, not by the ids: requested together with the ids -- as `idok ? P.e_ref[..] : ..` the two loads
+                // waited for the ids' round trip, a third dependent one in front of every pair's rows until round 5; e is a valid index
+                // for every lane group, and the entries of an edge with a bad id are never used)
+                const uint32_t ref_e = P.e_ref[(int64_t)which[s] * Ec + e];
+                const float gs_e = P.e_g[(int64_t)which[s] * Ec + e];
+                const uint32_t ref = idok ? ref_e : WREF_TABLE;
+                const float gs = idok ? gs_e : 1.0f;
                 const float* qb = (ref & WREF_TABLE) ? S.q + ((int64_t)(ref & 1u) * S.N + ids[s]) * ((int64_t)L * d)
                                                      : P.log + (int64_t)(ref & WREF_SLOT_MASK) * ((int64_t)L * d);
                 rowp[s * NR] = S.p0 + ids[s] * (int64_t)d;
