@@ -917,11 +917,14 @@ def main():
             s_, d_, n_, t_, op_, on_, te_, sched = pre if pre is not None else prep_args(a, b_)
             rp.run_stream(s_, d_, n_, t_, Bg, out_pos=op_, out_neg=on_, t_end=te_, schedule=sched, replay=False)
         # a short timed region (the driver's 20 steps are ~150 us) is ONE sample of a quantity that scatters by 10-20 % with the
-        # state the process and the GPU's clocks are in: up to 64 steps the region is measured five times in this process -- each
+        # state the process and the GPU's clocks are in: up to 64 steps the region is measured nine times in this process (five until the end of round 5) -- each
         # time from a reset table: W warm-up steps, then the K timed steps -- and `value` is the median; the first region's number
         # stays beside it (`first_region`: the first timed call of a process is 25-40 us slower than every later one, eight runs of
         # the driver's line in profiles/r04_driver_line_runs.md)
-        n_regions = 5 if K <= 64 else 1
+        # (nine regions since the end of round 5, five before: the first region of a process is always the slow one -- host time, DESIGN.md
+        # section 7 item 5 -- and one more in five is often disturbed by the host, so the median of five sat in the upper half of the quiet
+        # ones; every region's time stays in the line)
+        n_regions = 9 if K <= 64 else 1
         regions = []
         for r_ in range(n_regions):
             if r_ > 0:
@@ -930,7 +933,7 @@ def main():
         elapsed = float(np.median(regions))
         plain_regions = []
         if n_regions > 1:
-            for r_ in range(3):
+            for r_ in range(5):
                 rp.reset_random_projections()
                 plain_regions.append(time_leg(run_plain, K, prep_args))
         gc.enable()
@@ -975,7 +978,7 @@ def main():
                                      "plain_call": {"value": K * Bg / float(np.median(plain_regions)),
                                                     "wall_us": [r_ * 1e6 for r_ in plain_regions],
                                                     "what": "the same steps through rp.run_stream (its argument checks inside the "
-                                                            "region), median of three regions timed behind the five"}}
+                                                            "region), median of five regions timed behind the nine"}}
         if extra:
             line.update(extra)
         write_line(json.dumps(line))
