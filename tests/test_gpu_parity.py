@@ -1112,6 +1112,8 @@ def test_prepared_stream_call_equals_run_stream(d, L, N, B, nb, schedule):
         b.prepare_stream(ds, dd, dn, dt, B, out_pos=torch.empty((E, 3), device=DEV))
     empty = b.prepare_stream(ds[:0], dd[:0], dn[:0], dt[:0], B)
     assert empty()[0].shape[0] == 0
+    with pytest.raises(AttributeError):                       # a tensor swapped in behind the prepared pointers is refused
+        call.neg = dn2
 
 
 @pytest.mark.parametrize("d,L,N,B,nb", [(64, 2, 500, 1000, 5),      # 2 000 pairs in workgroups of 32 lane groups: half a workgroup left over

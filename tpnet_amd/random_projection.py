@@ -106,6 +106,13 @@ class PreparedStream:
     def __call__(self):
         return self.rp._run_prepared(self)
 
+    def __setattr__(self, name, value):
+        # the call's device pointers were taken when it was prepared: a tensor swapped in afterwards would not be the one that is read
+        # (write INTO the held tensor -- call.neg.copy_(new_negatives) -- or prepare the stream again)
+        if hasattr(self, name):
+            raise AttributeError(f"PreparedStream.{name} is fixed once the call is prepared: copy into the held tensor or prepare again")
+        object.__setattr__(self, name, value)
+
 
 class RandomProjectionModule(nn.Module):
     # plan-replay bookkeeping (class-level defaults: tpnet_amd/matrix_memory.py builds instances without this constructor)
