@@ -932,10 +932,29 @@ def main():
             regions.append(time_leg(run, K, prep))
         elapsed = float(np.median(regions))
         plain_regions = []
+        copy_regions = []
         if n_regions > 1:
             for r_ in range(5):
                 rp.reset_random_projections()
                 plain_regions.append(time_leg(run_plain, K, prep_args))
+            # the PCIe-inclusive rate (never `value`): the timed steps' four arrays start in pinned HOST memory and are copied to the
+            # device inside the region, in front of the same prepared call
+            sl_k = slice(W * Bg, (W + K) * Bg)
+            h_pin = [torch.from_numpy(np.ascontiguousarray(x[sl_k])).pin_memory() for x in (src, dst, neg, t)]
+            d_dst_views = [d_src[sl_k], d_dst[sl_k], d_neg[sl_k], d_t[sl_k]]
+
+            def run_copy(a, b_, pre=None):
+                if pre is not None:
+                    for hv, dv in zip(h_pin, d_dst_views):
+                        dv.copy_(hv, non_blocking=True)
+                (pre if pre is not None else prep(a, b_))()
+            for _ in range(2):                           # (the copy path's own first-use costs stay outside the regions)
+                for hv, dv in zip(h_pin, d_dst_views):
+                    dv.copy_(hv, non_blocking=True)
+            torch.cuda.synchronize()
+            for r_ in range(5):
+                rp.reset_random_projections()
+                copy_regions.append(time_leg(run_copy, K, prep))
         gc.enable()
         rp.check_device_errors()
     elif shard == "cols":
@@ -978,7 +997,12 @@ def main():
                                      "plain_call": {"value": K * Bg / float(np.median(plain_regions)),
                                                     "wall_us": [r_ * 1e6 for r_ in plain_regions],
                                                     "what": "the same steps through rp.run_stream (its argument checks inside the "
-                                                            "region), median of five regions timed behind the nine"}}
+                                                            "region), median of five regions timed behind the nine"},
+                                     "with_host_copy": {"value": K * Bg / float(np.median(copy_regions)),
+                                                        "wall_us": [r_ * 1e6 for r_ in copy_regions],
+                                                        "what": "the PCIe-inclusive rate: src / dst / neg / t of the timed steps copied from "
+                                                                "pinned host memory inside the region (four asynchronous copies, "
+                                                                f"{K * Bg * 32} bytes), then the same prepared call; median of five regions"}}
         if extra:
             line.update(extra)
         write_line(json.dumps(line))
