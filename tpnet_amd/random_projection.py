@@ -101,7 +101,7 @@ class PreparedStream:
     it runs the stream.  Attributes: the tensors it reads (`src`, `dst`, `neg`, `t`: their contents are read at every call) and
     writes (`out_pos`, `out_neg`: what the call returns)."""
     __slots__ = ("rp", "src", "dst", "neg", "t", "E", "batch_size", "nb", "want_pos", "want_neg", "out_pos", "out_neg", "t_end",
-                 "flags", "replay", "exact", "dev", "ptrs")
+                 "flags", "replay", "exact", "dev", "ptrs", "ws_need", "ws_cap")
 
     def __call__(self):
         return self.rp._run_prepared(self)
@@ -1143,6 +1143,12 @@ class RandomProjectionModule(nn.Module):
         p.flags, p.replay, p.exact, p.dev = flags, replay, self.exact, dev
         p.ptrs = (src.data_ptr(), dst.data_ptr(), neg.data_ptr() if neg is not None else 0, t.data_ptr(),
                   out_pos.data_ptr() if want_pos else 0, out_neg.data_ptr() if want_neg else 0)
+        p.ws_cap = self.stream_log_cap_bytes
+        need = 0
+        if E > 0:
+            w0 = self._workspace(E, batch_size, stream=True, keep_plan=True)
+            need = self.__dict__["_ws_need"].get((E, batch_size, True, 0, int(self.stream_log_cap_bytes or 0)), w0.numel())
+        p.ws_need = need
         return p
 
     def _run_prepared(self, p: "PreparedStream"):
@@ -1153,7 +1159,9 @@ class RandomProjectionModule(nn.Module):
             raise RuntimeError("this prepared stream was made for another mode / device of the module: prepare it again")
         E, batch_size = p.E, p.batch_size
         src, dst, t = p.src, p.dst, p.t
-        ws = self._workspace(E, batch_size, stream=True, keep_plan=True)
+        ws = self._eng["ws"]                             # (the stream's workspace: sized when the call was prepared; looked up again
+        if ws is None or ws.numel() < p.ws_need or p.ws_cap != self.stream_log_cap_bytes:   #  only if somebody replaced it since)
+            ws = self._workspace(E, batch_size, stream=True, keep_plan=True)
         self._st_ref()                                   # (the cached tpnet_state struct: rebuilt only when a buffer moved)
         st = self.__dict__["_st_cache"][2]
         lid = self._next_launch_ids(p.nb)
